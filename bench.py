@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE.json's config, on N GPUs of one node.
+
+Workload (config.workload): BASELINE configs[1] per GPU -- synthetic 2,504 samples x 1,000,000 variants
+fp32 (10.0 GB), resident in HBM before the timed region (weak scaling: every rank holds its own 1M-variant
+shard of one 1M*N_gpus-variant cohort; the generator is counter-based, so the cohort does not depend on N).
+
+One step = one pass of the hot path over the resident batch:
+    reset S -> Gram accumulation (fp32 MFMA, exact) -> finalize (mirror) -> [N>1: RCCL all-reduce of S].
+value = variants of ALL ranks per step * steps / max-over-ranks wall time of the K timed steps.
+The PCoA wall-clock (centring + eigensolve + D2H of N x 2, rank 0) is reported in `pcoa_wall_ms`.
+
+Contract: one JSON line on stdout from rank 0.  Launched by the driver as
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "variants/sec into N×N Gram + PCoA wall-clock, 2504 samples, 1/2/4/8 GPU"
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 flop/clk/CU
+N_SAMPLES = 2504
+SEED = 1002                     # seed of configs[1]
+
+
+def pkg(sub=None):
+    return importlib.import_module("spark-examples_amd" + ("." + sub if sub else ""))
+
+
+def cpu_baseline(x_dev, n, budget_s=12.0):
+    """The oracle's faithful pair loop (reference VariantsPca.scala:184-190 restated in C/OpenMP) timed
+    on this box's host cores, on a bounded sample of the same workload.  Baseline only."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    oracle = importlib.import_module("variants_pca_oracle")
+    cores = oracle.num_threads()
+    probe = min(2048, x_dev.shape[0])
+    xs = x_dev[:probe].cpu().numpy()
+    t0 = time.perf_counter()
+    oracle.similarity_from_dense(xs, n)
+    dt = max(time.perf_counter() - t0, 1e-4)
+    rate = probe / dt
+    sample = int(min(x_dev.shape[0], max(probe, rate * budget_s), 400000))
+    xs = x_dev[:sample].cpu().numpy()
+    t0 = time.perf_counter()
+    s_ref = oracle.similarity_from_dense(xs, n)
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    nb = min(sample, 100000)
+    oracle.similarity_from_dense_blas(xs[:nb])
+    dtb = time.perf_counter() - t0
+    return {"value": sample / dt, "unit": "variants/s", "cores": cores, "kind": "port",
+            "sample": "first %d variants of rank 0's shard, faithful pair loop (OpenMP, %d threads)" % (sample, cores),
+            "seconds": dt, "blas_value": nb / dtb,
+            "blas_note": "best-effort numpy/OpenBLAS sgemm X^T X on %d variants" % nb}, s_ref, sample
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--variants", type=int, default=1000000, help="variants per GPU (default = BASELINE configs[1])")
+    ap.add_argument("--samples", type=int, default=N_SAMPLES)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pcoa-reps", type=int, default=3)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as td
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    P = pkg()
+    dist = pkg("dist")
+    synth = pkg("synth")
+    n, v = args.samples, args.variants
+    eng = P.PcoaEngine(n, device=local_rank)
+    dev_name, cus = eng.device_info()
+
+    # ---- resident input: this rank's shard of the cohort, generated on device --------------------------
+    first = rank * v
+    offs = synth.pop_offsets(n)
+    x = torch.empty((v, n), dtype=torch.float32, device=dev)
+    step_rows = 1 << 18
+    for v0 in range(0, v, step_rows):
+        v1 = min(v, v0 + step_rows)
+        eng.synth_fill(SEED, offs, synth.thresholds(SEED, first + v0, v1 - v0), first + v0, x[v0:v1].data_ptr(), n)
+    eng.sync()
+
+    scratch = None
+
+    def one_step():
+        nonlocal scratch
+        eng.reset()
+        eng.accumulate_dense(x)
+        if world > 1:
+            scratch = dist.allreduce_engine(eng, scratch=scratch)
+        else:
+            eng.finalize()
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            td.barrier()
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    eng.reset_timings()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    tim = eng.timings()
+
+    out = None
+    if rank == 0:
+        steps = max(args.steps, 1)
+        ms_per_step = 1e3 * elapsed / steps
+        value = world * v * steps / elapsed
+        launches = max(int(tim["gram_kernel_launches"]), 1)
+        kern_s = tim["gram_kernel_seconds"] / launches           # average Gram-kernel launch duration (HIP events)
+        flops_per_launch = 2.0 * (tim["gram_variants"] / launches) * n * n   # algorithmic 2*V*N^2
+        achieved = flops_per_launch / kern_s / 1e12 if kern_s > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "gram_pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        # PCoA wall-clock on rank 0 (S of the last step is in place)
+        pcoa = []
+        for _ in range(max(args.pcoa_reps, 1)):
+            t1 = time.perf_counter()
+            comps, lam, nz = eng.compute(2)
+            pcoa.append(1e3 * (time.perf_counter() - t1))
+        tim2 = eng.timings()
+        out = {
+            "metric": METRIC, "value": value, "unit": "variants/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: synthetic %d samples x %d variants fp32 per GPU, resident in HBM "
+                                   "(Gram + eig on rank 0)" % (n, v),
+                       "n_samples": n, "variants_per_gpu": v, "seed": SEED, "parallelism": "variant-sharded x%d" % world,
+                       "gram_kernel": "fp32 MFMA v_mfma_f32_32x32x2_f32, upper-triangular 128x128 tiles, split-K"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                         "kernel": "gram_f32_kernel", "avg_launch_ms": 1e3 * kern_s,
+                         "flops_convention": "algorithmic 2*V*N^2 per launch; the kernel issues the SYRK half "
+                                             "(upper-triangular tiles only: %.3f of the MFMA work)" %
+                                             (syrk_fraction(n)),
+                         "issued_tflops": achieved * syrk_fraction(n)},
+            "pcoa_wall_ms": float(np.median(pcoa)), "pcoa_wall_ms_all": pcoa,
+            "pcoa_breakdown_ms": {k: 1e3 * tim2[k] / max(args.pcoa_reps, 1) for k in
+                                  ("center_seconds", "tridiag_seconds", "eig_seconds", "backtransform_seconds")},
+            "eigenvalues": [float(t) for t in lam], "nonzero_rows": int(nz),
+            "device": dev_name, "cu_count": cus,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, s_ref, sample = cpu_baseline(x, n)
+            out["cpu_baseline"] = base
+            # the CPU sample doubles as an end-of-run parity check of the measured path
+            eng.reset()
+            eng.accumulate_dense(x[:sample])
+            out["parity_vs_cpu_sample"] = bool(np.array_equal(eng.gram(), s_ref))
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        td.barrier()
+        td.destroy_process_group()
+    eng.close()
+    return 0
+
+
+def syrk_fraction(n, bm=128):
+    t = (n + bm - 1) // bm
+    return (t * (t + 1) / 2.0) / float(t * t)
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,213 @@
+/*
+ * pcoa.h -- C ABI of the MI355X-native PCoA engine (libpcoa_hip.so).
+ *
+ * Drop-in boundary for ONE path of googlegenomics/spark-examples: VariantsPcaDriver's
+ *   getSimilarityMatrix -> computePca
+ * (reference: src/main/scala/com/google/cloud/genomics/spark/examples/VariantsPca.scala, below
+ * "VariantsPca.scala"; Python twin src/main/python/variants_pca.py, below "variants_pca.py").
+ * The reference has no FFI; the seam is the method boundary of class VariantsPcaDriver
+ * (VariantsPca.scala:81).  Every entry point below names the reference interface it replaces.
+ * The JNI / ctypes bindings a maintainer would add are shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; little-endian int32_t / int64_t / float / double;
+ *   - every function returns 0 on success or a negative pcoa_status; it never throws or aborts;
+ *     the message of the last failure is available from pcoa_last_error();
+ *   - a pcoa_ctx owns all of its device memory and one HIP stream on ONE GPU; the caller owns every
+ *     host buffer passed in; a ctx is used from one host thread at a time, different ctxs are
+ *     independent (one per Spark task / per rank);
+ *   - matrices are row-major unless stated; "device pointer" means HIP device memory on the ctx's GPU;
+ *   - accumulate calls are asynchronous on the ctx stream; read/compute calls synchronise.
+ */
+#ifndef PCOA_H_
+#define PCOA_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCOA_VERSION_MAJOR 0
+#define PCOA_VERSION_MINOR 1
+
+typedef struct pcoa_ctx pcoa_ctx;
+
+typedef enum pcoa_status {
+  PCOA_OK = 0,
+  PCOA_ERR_INVALID_ARG = -1,   /* null pointer, negative size, num_pc out of (0, N] ...          */
+  PCOA_ERR_NO_DEVICE = -2,     /* no HIP device / ordinal out of range: the product has NO CPU fallback */
+  PCOA_ERR_HIP = -3,           /* a HIP runtime call or kernel failed (message has the HIP error) */
+  PCOA_ERR_OUT_OF_MEMORY = -4,
+  PCOA_ERR_INDEX_RANGE = -5,   /* a callset index outside [0, N): the reference throws here
+                                  (mapping(call.callsetId), VariantsPca.scala:59; Breeze bounds check :188) */
+  PCOA_ERR_RCCL = -6,
+  PCOA_ERR_NOT_CONVERGED = -7, /* eigen-iteration failed to converge */
+  PCOA_ERR_STATE = -8          /* call order violated (e.g. compute before any finalize)         */
+} pcoa_status;
+
+/* flags for pcoa_create */
+#define PCOA_FLAG_DEFAULT        0u
+#define PCOA_FLAG_GRAM_F32_MFMA  0x1u  /* force the fp32-MFMA Gram kernel (v_mfma_f32_32x32x2_f32)      */
+#define PCOA_FLAG_GRAM_I8_MFMA   0x2u  /* force the i8-MFMA Gram kernel (v_mfma_i32_32x32x32_i8)        */
+#define PCOA_FLAG_NO_SIGN_NORM   0x10u /* keep the eigensolver's native sign instead of sign-normalising */
+
+/* Per-stage timings, filled by pcoa_get_timings(); times in seconds, measured with HIP events on
+ * the ctx stream.  Counters are cumulative since pcoa_create / pcoa_reset_timings. */
+typedef struct pcoa_timings {
+  double gram_kernel_seconds;   /* sum of Gram-kernel launch durations                               */
+  int64_t gram_kernel_launches;
+  int64_t gram_variants;        /* variants pushed through the Gram kernels                           */
+  double gram_flops;            /* algorithmic 2*V*N^2                                                */
+  double gram_bytes;            /* algorithmic 4*V*N (X read once) + 4*N^2 per launch                 */
+  double densify_seconds;       /* CSR -> dense tile kernels                                          */
+  double synth_seconds;         /* synthetic genotype generation                                      */
+  double finalize_seconds;      /* symmetrise + fold                                                  */
+  double center_seconds;        /* row sums + double centring                                         */
+  double tridiag_seconds;       /* Householder tridiagonalisation                                     */
+  double eig_seconds;           /* tridiagonal eigenvalues + inverse iteration                        */
+  double backtransform_seconds; /* reflector back-transform + normalisation                           */
+  double compute_total_seconds; /* wall of the last pcoa_compute (centring..D2H)                      */
+  int32_t gram_kernel_kind;     /* 1 = fp32 MFMA, 2 = i8 MFMA                                        */
+  int32_t reserved;
+} pcoa_timings;
+
+/* Synthetic genotype model (bench / tests only; not part of the reference).  Sample i belongs to
+ * population p iff pop_offsets[p] <= i < pop_offsets[p+1].  Genotype X[v,i] = 1 iff
+ * philox4x32-10(key = seed, counter = (v, i/4, 0, 0))[i%4] < thresholds[v*n_pops + p].
+ * Pure integer arithmetic => bit-identical on host and device and invariant to sharding. */
+typedef struct pcoa_synth_params {
+  uint64_t seed;
+  int32_t n_pops;
+  int32_t reserved;
+  const int32_t* pop_offsets;   /* host, n_pops + 1 entries, pop_offsets[n_pops] == n_samples        */
+  const uint32_t* thresholds;   /* host, [n_variants][n_pops] for the range being generated          */
+} pcoa_synth_params;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+
+/* Creates an engine for an N x N similarity matrix on GPU `device_ordinal`.
+ * Replaces: the per-partition DenseMatrix.zeros[Int](size, size) (VariantsPca.scala:183-185) plus
+ * the SparkContext the driver holds (VariantsPca.scala:83-85).  N = common.indexes.size. */
+int pcoa_create(pcoa_ctx** out, int32_t n_samples, int32_t device_ordinal, uint32_t flags);
+
+/* Replaces: VariantsPcaDriver.stop (VariantsPca.scala:283-285). */
+void pcoa_destroy(pcoa_ctx* ctx);
+
+/* Message of the last error on this ctx (or of the last failed pcoa_create when ctx == NULL).
+ * Replaces: the JVM exception message. */
+const char* pcoa_last_error(const pcoa_ctx* ctx);
+
+/* Zeroes the accumulated similarity matrix (a fresh getSimilarityMatrix run). */
+int pcoa_reset(pcoa_ctx* ctx);
+
+int pcoa_n_samples(const pcoa_ctx* ctx);
+
+/* Runs ctx work on a caller-provided hipStream_t (e.g. the host framework's current stream).
+ * NULL restores the ctx-owned stream. */
+int pcoa_set_stream(pcoa_ctx* ctx, void* hip_stream);
+
+/* Blocks until all queued work of the ctx has finished. */
+int pcoa_sync(pcoa_ctx* ctx);
+
+/* ---- Gram accumulation: getSimilarityMatrix -------------------------------------------------- */
+
+/* The faithful boundary: exactly what RDD[Seq[Int]] carries (getCallsRdd, VariantsPca.scala:153-168).
+ * Variant v's carriers are sample_idx[row_offsets[v] .. row_offsets[v+1]).  Host pointers.
+ * Adds, for every variant and every ORDERED pair (c1, c2) of its carriers, 1 to S(c1, c2).
+ * Replaces: the mapPartitions body of getSimilarityMatrix (VariantsPca.scala:184-189) and
+ * sum_similarity (variants_pca.py:67-72).  Empty rows are legal (they add nothing; the reference
+ * filters them at :166).  Repeated indices within a row count with multiplicity, as the
+ * reference's double loop does.  An index outside [0, N) -> PCOA_ERR_INDEX_RANGE, S unchanged by
+ * that call's remaining chunks (reported at the next synchronising call at the latest). */
+int pcoa_accumulate_calls(pcoa_ctx* ctx, const int32_t* sample_idx, const int64_t* row_offsets,
+                          int64_t n_variants);
+
+/* Dense boundary: a variants x samples tile, x[v*ld + i] = carrier multiplicity (0.0f / 1.0f for
+ * well-formed input: extractCallInfo's hasVariation, VariantsPca.scala:56-60).  `x` is a host
+ * pointer (is_device_ptr = 0; staged through pinned memory) or a device pointer (is_device_ptr = 1;
+ * read in place, must stay valid until the next synchronising call).  ld >= N.
+ * Replaces: the same mapPartitions body, with the RDD partition materialised as a matrix tile
+ * (BASELINE.json configs[1]: "2,504 samples x 1M variants fp32"). */
+int pcoa_accumulate_dense_f32(pcoa_ctx* ctx, const float* x, int64_t n_variants, int64_t ld,
+                              int is_device_ptr);
+
+/* Generates variants [first_variant, first_variant + n_variants) of the synthetic model directly
+ * in HBM and accumulates them (no host tile).  params->thresholds covers exactly that range. */
+int pcoa_accumulate_synthetic(pcoa_ctx* ctx, const pcoa_synth_params* params, int64_t first_variant,
+                              int64_t n_variants);
+
+/* Fills a caller-owned DEVICE buffer x_dev[n_variants][ld] with the synthetic genotypes (0.0f/1.0f)
+ * without accumulating -- used by bench.py to make the input resident before the timed region. */
+int pcoa_synth_fill_f32(pcoa_ctx* ctx, const pcoa_synth_params* params, int64_t first_variant,
+                        int64_t n_variants, float* x_dev, int64_t ld);
+
+/* Completes the local accumulation: mirrors the computed triangle, folds int32 partials.
+ * After it the full symmetric S of THIS ctx is readable.  Accumulation may continue afterwards
+ * (S is additive: a natural checkpoint/resume point).
+ * Replaces (single GPU): reduceByKey(_ + _) (VariantsPca.scala:190). */
+int pcoa_gram_finalize(pcoa_ctx* ctx);
+
+/* Cross-GPU sum of the finalized S over all ranks of an RCCL communicator (ncclComm_t passed as
+ * void*), in place on every rank, on the ctx stream.  One rank per GPU / per process.
+ * Replaces (multi GPU): reduceByKey(_ + _, numReducePartitions) (VariantsPca.scala:190). */
+int pcoa_gram_allreduce_rccl(pcoa_ctx* ctx, void* nccl_comm);
+
+/* RCCL bootstrap helpers for hosts without their own (e.g. the Scala/JNI host): rank 0 obtains a
+ * 128-byte unique id, ships it to the other ranks by its own means (Spark broadcast), then every
+ * rank calls pcoa_comm_init.  *comm_out is an ncclComm_t. */
+int pcoa_comm_unique_id(uint8_t out_id[128]);
+int pcoa_comm_init(pcoa_ctx* ctx, const uint8_t id[128], int32_t rank, int32_t n_ranks,
+                   void** comm_out);
+int pcoa_comm_destroy(void* nccl_comm);
+
+/* Host-driven reduction alternative (bench.py uses torch.distributed, whose "nccl" backend is RCCL):
+ * export copies the finalized S as int64 [N][N] into a DEVICE buffer; import replaces S with the
+ * (reduced) contents of a DEVICE buffer. */
+int pcoa_gram_export_device_i64(pcoa_ctx* ctx, int64_t* dst_dev);
+int pcoa_gram_import_device_i64(pcoa_ctx* ctx, const int64_t* src_dev);
+
+/* Copies the finalized S to host as int64 [N][N] (all N^2 entries, zeros included, as
+ * matrix.iterator emits them, VariantsPca.scala:189).  For parity tests and checkpoints. */
+int pcoa_gram_read_i64(pcoa_ctx* ctx, int64_t* out_nxn);
+
+/* Loads S from host int64 [N][N] (resume from a checkpoint, or enter at computePca with matrix
+ * entries produced elsewhere: computePca(matrixEntries), VariantsPca.scala:198). */
+int pcoa_gram_load_i64(pcoa_ctx* ctx, const int64_t* in_nxn);
+
+/* ---- computePca ------------------------------------------------------------------------------ */
+
+/* Runs row sums + double-centring only and copies B (fp64 [N][N]) and the row sums to host.
+ * Either output may be NULL.  Replaces: computePca lines VariantsPca.scala:206-223
+ * (center_matrix, variants_pca.py:84-121).  For parity tests of that stage. */
+int pcoa_center_read_f64(pcoa_ctx* ctx, double* out_b_nxn, double* out_row_sums, int32_t* out_nonzero_rows,
+                         double* out_matrix_mean);
+
+/* computePca (VariantsPca.scala:198-231; perform_pca variants_pca.py:123-152) on the finalized S:
+ * centring, then the num_pc principal components of B.
+ *   out_components : N x num_pc COLUMN-major, i.e. the layout of pca.toArray (VariantsPca.scala:227):
+ *                    component c of sample i is out_components[i + c*N]; unit 2-norm columns;
+ *                    sign-normalised (largest-magnitude entry positive, ties -> lowest index)
+ *                    unless PCOA_FLAG_NO_SIGN_NORM.
+ *   out_eigenvalues: num_pc eigenvalues of B, ordered by decreasing magnitude -- the order of the
+ *                    singular values of Cov that MLlib's SVD sorts by (s = lambda^2/(N-1)). May be NULL.
+ *   out_nonzero_rows: rowSums.filter(_ > 0).size (VariantsPca.scala:207). May be NULL.
+ * 0 < num_pc <= N, else PCOA_ERR_INVALID_ARG (MLlib: require(k > 0 && k <= n)). */
+int pcoa_compute(pcoa_ctx* ctx, int32_t num_pc, double* out_components, double* out_eigenvalues,
+                 int32_t* out_nonzero_rows);
+
+/* ---- instrumentation ------------------------------------------------------------------------- */
+
+/* Synchronises and fills *out.  Replaces: reportIoStats' role of printing what was processed
+ * (VariantsPca.scala:48,281). */
+int pcoa_get_timings(pcoa_ctx* ctx, pcoa_timings* out);
+int pcoa_reset_timings(pcoa_ctx* ctx);
+
+/* Name of the GPU the ctx runs on, its CU count and the library version string. */
+int pcoa_device_info(pcoa_ctx* ctx, char* name_out, int32_t name_cap, int32_t* cu_count_out);
+const char* pcoa_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCOA_H_ */

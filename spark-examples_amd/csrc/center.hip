@@ -1,0 +1,110 @@
+// center.hip -- computePca part 1+2 (reference VariantsPca.scala:199-223; variants_pca.py:84-121):
+//
+//   rowSums(i)  = sum_j S(i,j)                               (:206)
+//   nonZeroRows = #{ rowSums > 0 }                           (:207)
+//   matrixMean  = (sum_i rowSums(i)) / N / N                 (:210-211)  two divisions, in that order
+//   B(i,j)      = ((S(i,j) - rowSums(i)/N) - rowSums(j)/N) + matrixMean   (:216-221)
+//
+// Row sums are accumulated as int64 (exact); the reference folds doubles left to right, which is
+// also exact while the sums stay below 2^53, so both give the same double.  The centring expression
+// is evaluated in the reference's operation order with IEEE fp64 +,-,/ and no fused multiply-add,
+// so B is bit-identical to the JVM's result.  HBM-bound streaming: reads 4 (or 12) B, writes 8 B
+// per entry.
+#include "pcoa_internal.h"
+
+namespace pcoa {
+namespace {
+
+__device__ __forceinline__ int64_t wave_sum_i64(int64_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// one workgroup (256 threads) per row
+__global__ __launch_bounds__(256) void row_sums_kernel(const int32_t* __restrict__ s32,
+                                                       const int64_t* __restrict__ s64, int32_t n,
+                                                       double* __restrict__ row_sums,
+                                                       int64_t* __restrict__ row_sums_i64) {
+  __shared__ int64_t part[4];
+  const int i = blockIdx.x;
+  const int64_t base = (int64_t)i * n;
+  int64_t acc = 0;
+  for (int j = threadIdx.x; j < n; j += 256) acc += (int64_t)s32[base + j] + (s64 ? s64[base + j] : 0);
+  acc = wave_sum_i64(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int64_t t = part[0] + part[1] + part[2] + part[3];
+    row_sums_i64[i] = t;
+    row_sums[i] = (double)t;
+  }
+}
+
+// single workgroup: matrix sum, mean, non-zero rows
+__global__ __launch_bounds__(256) void stats_kernel(const int64_t* __restrict__ row_sums_i64, int32_t n,
+                                                    double* __restrict__ stats, int32_t* __restrict__ nz) {
+  __shared__ int64_t part[4];
+  __shared__ int64_t cnt[4];
+  int64_t acc = 0, c = 0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int64_t r = row_sums_i64[i];
+    acc += r;
+    c += (r > 0) ? 1 : 0;
+  }
+  acc = wave_sum_i64(acc);
+  c = wave_sum_i64(c);
+  if ((threadIdx.x & 63) == 0) {
+    part[threadIdx.x >> 6] = acc;
+    cnt[threadIdx.x >> 6] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma clang fp contract(off)
+    const double msum = (double)(part[0] + part[1] + part[2] + part[3]);
+    const double rc = (double)n;
+    stats[0] = msum;
+    stats[1] = msum / rc / rc;
+    nz[0] = (int32_t)(cnt[0] + cnt[1] + cnt[2] + cnt[3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void center_kernel(const int32_t* __restrict__ s32,
+                                                     const int64_t* __restrict__ s64, int32_t n,
+                                                     const double* __restrict__ row_sums,
+                                                     const double* __restrict__ stats, double* __restrict__ b,
+                                                     int32_t nbx) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x / nbx;
+  const int j = (blockIdx.x - i * nbx) * 256 + threadIdx.x;
+  if (j >= n) return;
+  const double rc = (double)n;
+  const double row_mean = row_sums[i] / rc;
+  const double col_mean = row_sums[j] / rc;
+  const double mmean = stats[1];
+  const int64_t idx = (int64_t)i * n + j;
+  const double data = (double)((int64_t)s32[idx] + (s64 ? s64[idx] : 0));
+  double t = data - row_mean;
+  t = t - col_mean;
+  t = t + mmean;
+  b[idx] = t;
+}
+
+}  // namespace
+
+hipError_t launch_center(const int32_t* s32, const int64_t* s64_or_null, int32_t n, double* row_sums,
+                         double* stats, int32_t* nz, double* b, hipStream_t stream) {
+  // row_sums_i64 lives right behind stats[0..1] (the caller allocates stats as 2 + n doubles)
+  int64_t* rs_i64 = reinterpret_cast<int64_t*>(stats + 2);
+  hipLaunchKernelGGL(row_sums_kernel, dim3((unsigned)n), dim3(256), 0, stream, s32, s64_or_null, n, row_sums,
+                     rs_i64);
+  hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(256), 0, stream, rs_i64, n, stats, nz);
+  if (b) {
+    const int32_t nbx = (n + 255) / 256;
+    hipLaunchKernelGGL(center_kernel, dim3((unsigned)((int64_t)nbx * n)), dim3(256), 0, stream, s32, s64_or_null,
+                       n, row_sums, stats, b, nbx);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace pcoa

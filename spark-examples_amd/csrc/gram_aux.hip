@@ -1,0 +1,174 @@
+// gram_aux.hip -- the small HBM-bound kernels around the Gram contraction:
+//   densify_csr      RDD[Seq[Int]] carrier lists (getCallsRdd, VariantsPca.scala:153-168) -> dense tile
+//   symmetrize_i32   mirror the computed upper triangle (the reference fills both, :187)
+//   fold / export    int32 partial <-> int64 total (Scala Int wraps at 2^31; we do not)
+//   synth_fill_f32   counter-based synthetic genotypes (bench / tests only)
+// All are plain coalesced streaming kernels; none is on the roofline-critical path.
+#include "pcoa_internal.h"
+
+namespace pcoa {
+namespace {
+
+// One wave per variant row: lanes stride over the row's carrier list and add 1.0f at
+// x[row][sample].  Float atomics keep multiplicity semantics for repeated indices (the reference's
+// double loop counts a repeated carrier twice).  Rows are disjoint, so contention only arises
+// from genuine repeats.
+__global__ __launch_bounds__(256) void densify_csr_kernel(const int32_t* __restrict__ idx,
+                                                          const int64_t* __restrict__ offs, int64_t v0,
+                                                          int64_t nv, int64_t offs_base,
+                                                          float* __restrict__ x, int64_t ld, int32_t n,
+                                                          int32_t* __restrict__ err_flag) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nv) return;
+  const int64_t b = offs[v0 + row] - offs_base;
+  const int64_t e = offs[v0 + row + 1] - offs_base;
+  float* xr = x + row * ld;
+  for (int64_t p = b + lane; p < e; p += 64) {
+    const int32_t c = idx[p];
+    if (c < 0 || c >= n) {
+      atomicOr(err_flag, 1);
+    } else {
+      atomicAdd(&xr[c], 1.0f);
+    }
+  }
+}
+
+// s[i][j] = s[j][i] for i > j, 32x32 tiles staged through LDS so both sides stay coalesced.
+__global__ __launch_bounds__(256) void symmetrize_i32_kernel(int32_t* __restrict__ s, int32_t n) {
+  __shared__ int32_t t[32][33];
+  const int bi = blockIdx.y, bj = blockIdx.x;  // destination tile (rows bi, cols bj), bi >= bj
+  if (bi < bj) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  // read source tile (rows bj*32.., cols bi*32..) = the upper-triangular one
+  for (int r = ty; r < 32; r += 8) {
+    const int i = bj * 32 + r, j = bi * 32 + tx;
+    t[r][tx] = (i < n && j < n) ? s[(int64_t)i * n + j] : 0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int i = bi * 32 + r, j = bj * 32 + tx;
+    if (i < n && j < n && i > j) s[(int64_t)i * n + j] = t[tx][r];
+  }
+}
+
+__global__ __launch_bounds__(256) void fold_kernel(int32_t* __restrict__ s32, int64_t* __restrict__ s64,
+                                                   int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    s64[i] += (int64_t)s32[i];
+    s32[i] = 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void export_kernel(const int32_t* __restrict__ s32,
+                                                     const int64_t* __restrict__ s64, int64_t* __restrict__ dst,
+                                                     int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    dst[i] = (int64_t)s32[i] + (s64 ? s64[i] : 0);
+  }
+}
+
+// ---- Philox4x32-10 (Salmon et al., SC'11), the counter-based generator of the synthetic model ---
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// One thread per (variant, group of 4 samples): counter = (v_lo, v_hi, i/4, 0), key = seed.
+// X[v][i] = 1.0f iff word[i % 4] < thresholds[v_local][pop(i)].
+__global__ __launch_bounds__(256) void synth_fill_kernel(uint64_t seed, const uint32_t* __restrict__ thr,
+                                                         const int32_t* __restrict__ sample_pop, int32_t n_pops,
+                                                         int64_t first_variant, int64_t nv, int32_t n,
+                                                         int32_t ngroups, float* __restrict__ x, int64_t ld,
+                                                         int vec_ok) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = nv * ngroups;
+  if (gid >= total) return;
+  const int64_t vl = gid / ngroups;
+  const int32_t g = (int32_t)(gid - vl * ngroups);
+  const uint64_t v = (uint64_t)(first_variant + vl);
+  uint32_t w[4];
+  philox4x32_10((uint32_t)v, (uint32_t)(v >> 32), (uint32_t)g, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+  const uint32_t* tv = thr + vl * n_pops;
+  float o[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int i = g * 4 + t;
+    o[t] = (i < n && w[t] < tv[sample_pop[i]]) ? 1.0f : 0.0f;
+  }
+  float* dst = x + vl * ld + (int64_t)g * 4;
+  if (vec_ok && g * 4 + 3 < ld) {
+    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (g * 4 + t < ld) dst[t] = o[t];
+  }
+}
+
+inline unsigned grid_for(int64_t count, int block, int64_t cap) {
+  int64_t g = (count + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace
+
+hipError_t launch_densify_csr(const int32_t* idx_dev, const int64_t* offs_dev, int64_t v0, int64_t nv,
+                              int64_t offs_base, float* x_dev, int64_t ld, int32_t n, int32_t* err_flag_dev,
+                              hipStream_t stream) {
+  if (nv <= 0) return hipSuccess;
+  const int64_t blocks = (nv + 3) / 4;
+  hipLaunchKernelGGL(densify_csr_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, idx_dev, offs_dev, v0, nv,
+                     offs_base, x_dev, ld, n, err_flag_dev);
+  return hipGetLastError();
+}
+
+hipError_t launch_symmetrize_i32(int32_t* s32, int32_t n, hipStream_t stream) {
+  const unsigned t = (unsigned)((n + 31) / 32);
+  hipLaunchKernelGGL(symmetrize_i32_kernel, dim3(t, t), dim3(256), 0, stream, s32, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_fold_i32_to_i64(int32_t* s32, int64_t* s64, int64_t count, hipStream_t stream) {
+  hipLaunchKernelGGL(fold_kernel, dim3(grid_for(count, 256, 8192)), dim3(256), 0, stream, s32, s64, count);
+  return hipGetLastError();
+}
+
+hipError_t launch_export_i64(const int32_t* s32, const int64_t* s64_or_null, int64_t* dst, int64_t count,
+                             hipStream_t stream) {
+  hipLaunchKernelGGL(export_kernel, dim3(grid_for(count, 256, 8192)), dim3(256), 0, stream, s32, s64_or_null,
+                     dst, count);
+  return hipGetLastError();
+}
+
+hipError_t launch_synth_fill_f32(uint64_t seed, const uint32_t* thresholds_dev, const int32_t* sample_pop_dev,
+                                 int32_t n_pops, int64_t first_variant, int64_t nv, int32_t n, float* x_dev,
+                                 int64_t ld, hipStream_t stream) {
+  if (nv <= 0) return hipSuccess;
+  const int32_t ngroups = (int32_t)((ld + 3) / 4);  // also zero-fills the padding columns [n, ld)
+  const int64_t total = nv * ngroups;
+  const int vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(x_dev) & 15) == 0);
+  const int64_t blocks = (total + 255) / 256;
+  if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(synth_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, seed, thresholds_dev,
+                     sample_pop_dev, n_pops, first_variant, nv, n, ngroups, x_dev, ld, vec_ok);
+  return hipGetLastError();
+}
+
+}  // namespace pcoa

@@ -1,0 +1,775 @@
+// pcoa_capi.hip -- the C ABI of include/pcoa.h on top of the HIP kernels.
+//
+// Host-side orchestration only: device memory ownership, chunking (fp32 accumulators stay exact
+// below 2^24 per launch, int32 partials are folded into int64 before 2^31), stream ordering,
+// HIP-event timing, and the RCCL all-reduce.  There is deliberately NO CPU fallback: without a HIP
+// device pcoa_create fails with PCOA_ERR_NO_DEVICE.
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "pcoa_internal.h"
+
+using namespace pcoa;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+enum TimeCat { T_GRAM = 0, T_DENSIFY, T_SYNTH, T_FINALIZE, T_CENTER, T_TRIDIAG, T_EIG, T_BACK, T_NCAT };
+
+struct EventPair {
+  hipEvent_t a, b;
+  int cat;
+};
+
+}  // namespace
+
+struct pcoa_ctx {
+  int32_t n = 0;
+  int device = 0;
+  uint32_t flags = 0;
+  int num_cu = 256;
+  char dev_name[256] = {0};
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string last_error;
+
+  // Gram state
+  int32_t* s32 = nullptr;          // [n][n] partial, upper-triangular tiles authoritative
+  int64_t* s64 = nullptr;          // [n][n] folded total (lazy), always symmetric
+  int64_t variants_in_s32 = 0;     // variants accumulated into s32 since the last fold
+  bool dirty = false;              // s32 has contributions not yet mirrored
+  bool have_data = false;
+  float* zeros = nullptr;          // 4 KiB of zeros
+  int32_t* err_flag = nullptr;     // device
+
+  // staging (lazy)
+  float* tile = nullptr;
+  int64_t tile_elems = 0;
+  int32_t* csr_idx = nullptr;
+  int64_t csr_idx_cap = 0;
+  int64_t* csr_offs = nullptr;
+  int64_t csr_offs_cap = 0;
+  uint32_t* thr_dev = nullptr;
+  int64_t thr_cap = 0;
+  int32_t* sample_pop = nullptr;   // [n]
+  int64_t* xfer = nullptr;         // [n][n] int64 exchange buffer (lazy)
+
+  // computePca workspace (lazy)
+  bool ws_ready = false;
+  EigWorkspace ws{};
+  double* row_sums = nullptr;      // [n]
+  double* stats = nullptr;         // [2 + n] (sum, mean, then int64 row sums)
+  int32_t* nz = nullptr;           // [1]
+  double* out_dev = nullptr;       // [kmax][n]
+  int32_t kmax = 0;
+
+  // timings
+  std::vector<EventPair> pending;
+  std::vector<hipEvent_t> pool;
+  double tsec[T_NCAT] = {0};
+  int64_t gram_launches = 0;
+  int64_t gram_variants = 0;
+  double gram_flops = 0, gram_bytes = 0;
+  double compute_total = 0;
+  int gram_kind = 1;
+  int64_t max_launch = (int64_t)1 << 24;
+  int64_t fold_threshold = (int64_t)1 << 30;
+};
+
+namespace {
+
+int fail(pcoa_ctx* c, int code, const std::string& msg) {
+  if (c) c->last_error = msg; else g_create_error = msg;
+  return code;
+}
+
+int hip_fail(pcoa_ctx* c, hipError_t e, const char* what) {
+  std::string m = std::string(what) + ": " + hipGetErrorString(e);
+  (void)hipGetLastError();  // clear sticky launch errors
+  return fail(c, e == hipErrorOutOfMemory ? PCOA_ERR_OUT_OF_MEMORY : PCOA_ERR_HIP, m);
+}
+
+#define HIP_TRY(ctx, expr)                                     \
+  do {                                                         \
+    hipError_t _e = (expr);                                    \
+    if (_e != hipSuccess) return hip_fail((ctx), _e, #expr);   \
+  } while (0)
+
+#define CHECK_CTX(ctx)                                                      \
+  do {                                                                      \
+    if (!(ctx)) return fail(nullptr, PCOA_ERR_INVALID_ARG, "ctx is NULL");  \
+    hipError_t _e = hipSetDevice((ctx)->device);                            \
+    if (_e != hipSuccess) return hip_fail((ctx), _e, "hipSetDevice");       \
+  } while (0)
+
+hipEvent_t get_event(pcoa_ctx* c) {
+  if (!c->pool.empty()) {
+    hipEvent_t e = c->pool.back();
+    c->pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
+// resolves finished (or, if wait, all) event pairs into the per-category sums
+void drain_events(pcoa_ctx* c, bool wait) {
+  if (wait) (void)hipStreamSynchronize(c->stream);
+  size_t keep = 0;
+  for (size_t i = 0; i < c->pending.size(); ++i) {
+    EventPair& p = c->pending[i];
+    float ms = 0.f;
+    hipError_t e = hipEventElapsedTime(&ms, p.a, p.b);
+    if (e == hipSuccess) {
+      c->tsec[p.cat] += (double)ms * 1e-3;
+      c->pool.push_back(p.a);
+      c->pool.push_back(p.b);
+    } else if (!wait && e == hipErrorNotReady) {
+      c->pending[keep++] = p;
+    } else {
+      (void)hipGetLastError();
+      c->pool.push_back(p.a);
+      c->pool.push_back(p.b);
+    }
+  }
+  c->pending.resize(keep);
+}
+
+struct ScopedTimer {
+  pcoa_ctx* c;
+  EventPair p;
+  bool on;
+  ScopedTimer(pcoa_ctx* ctx, int cat) : c(ctx), on(false) {
+    p.a = get_event(c);
+    p.b = get_event(c);
+    p.cat = cat;
+    if (p.a && p.b && hipEventRecord(p.a, c->stream) == hipSuccess) on = true;
+  }
+  ~ScopedTimer() {
+    if (on && hipEventRecord(p.b, c->stream) == hipSuccess) {
+      c->pending.push_back(p);
+      if (c->pending.size() > 2048) drain_events(c, true);
+    } else {
+      if (p.a) c->pool.push_back(p.a);
+      if (p.b) c->pool.push_back(p.b);
+    }
+  }
+};
+
+template <typename T>
+int ensure(pcoa_ctx* c, T** buf, int64_t* cap, int64_t need) {
+  if (need <= *cap) return PCOA_OK;
+  // the old buffer may still be read by queued kernels
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (*buf) (void)hipFree(*buf);
+  *buf = nullptr;
+  *cap = 0;
+  int64_t newcap = std::max<int64_t>(need, 1024);
+  HIP_TRY(c, hipMalloc((void**)buf, sizeof(T) * (size_t)newcap));
+  *cap = newcap;
+  return PCOA_OK;
+}
+
+int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+constexpr int64_t kMaxLaunchVariants = (int64_t)1 << 24;  // fp32 accumulators exact below 2^24
+constexpr int64_t kFoldThreshold = (int64_t)1 << 30;      // fold int32 partials long before 2^31
+
+// Test hooks: PCOA_DEBUG_MAX_LAUNCH / PCOA_DEBUG_FOLD_THRESHOLD shrink the two limits so that the
+// multi-launch and int64-fold paths can be exercised with small inputs (read at pcoa_create).
+int64_t env_limit(const char* name, int64_t dflt) {
+  const char* v = std::getenv(name);
+  if (!v || !*v) return dflt;
+  const long long x = std::atoll(v);
+  return (x > 0 && x < dflt) ? (int64_t)x : dflt;
+}
+
+int fold_now(pcoa_ctx* c) {
+  const int64_t count = (int64_t)c->n * c->n;
+  if (!c->s64) {
+    HIP_TRY(c, hipMalloc((void**)&c->s64, sizeof(int64_t) * (size_t)count));
+    HIP_TRY(c, hipMemsetAsync(c->s64, 0, sizeof(int64_t) * (size_t)count, c->stream));
+  }
+  // s64 is kept symmetric: mirror the partial before it is folded in
+  HIP_TRY(c, launch_symmetrize_i32(c->s32, c->n, c->stream));
+  HIP_TRY(c, launch_fold_i32_to_i64(c->s32, c->s64, count, c->stream));
+  c->variants_in_s32 = 0;
+  c->dirty = false;
+  return PCOA_OK;
+}
+
+// X tile already resident on the device: split into launches that keep fp32/int32 exact.
+int gram_device(pcoa_ctx* c, const float* x_dev, int64_t nv, int64_t ld) {
+  int64_t done = 0;
+  while (done < nv) {
+    const int64_t cur = std::min(nv - done, c->max_launch);
+    if (c->variants_in_s32 + cur > c->fold_threshold) {
+      ScopedTimer t(c, T_FINALIZE);
+      int rc = fold_now(c);
+      if (rc != PCOA_OK) return rc;
+    }
+    GramLaunch g;
+    g.x = x_dev + done * ld;
+    g.ld = ld;
+    g.nv = cur;
+    g.n = c->n;
+    g.s32 = c->s32;
+    g.zeros = c->zeros;
+    g.num_cu = c->num_cu;
+    g.stream = c->stream;
+    {
+      ScopedTimer t(c, T_GRAM);
+      hipError_t e = launch_gram_f32(g, nullptr);
+      if (e != hipSuccess) return hip_fail(c, e, "gram kernel launch");
+    }
+    c->gram_launches += 1;
+    c->gram_variants += cur;
+    c->gram_flops += 2.0 * (double)cur * (double)c->n * (double)c->n;
+    c->gram_bytes += 4.0 * (double)cur * (double)c->n + 4.0 * (double)c->n * (double)c->n;
+    c->variants_in_s32 += cur;
+    c->dirty = true;
+    c->have_data = true;
+    done += cur;
+  }
+  return PCOA_OK;
+}
+
+int ensure_workspace(pcoa_ctx* c, int32_t k) {
+  const int64_t n = c->n;
+  if (!c->ws_ready) {
+    HIP_TRY(c, hipMalloc((void**)&c->ws.a, sizeof(double) * (size_t)(n * n)));
+    HIP_TRY(c, hipMalloc((void**)&c->ws.d, sizeof(double) * (size_t)n));
+    HIP_TRY(c, hipMalloc((void**)&c->ws.e, sizeof(double) * (size_t)n));
+    HIP_TRY(c, hipMalloc((void**)&c->ws.tau, sizeof(double) * (size_t)n));
+    HIP_TRY(c, hipMalloc((void**)&c->ws.q, sizeof(double) * (size_t)n));
+    HIP_TRY(c, hipMalloc((void**)&c->ws.w, sizeof(double) * (size_t)(2 * n)));
+    HIP_TRY(c, hipMalloc((void**)&c->ws.scratch, sizeof(double) * (size_t)(6 * n)));
+    HIP_TRY(c, hipMalloc((void**)&c->ws.iscratch, sizeof(int32_t) * (size_t)std::max<int64_t>(n, 64)));
+    HIP_TRY(c, hipMalloc((void**)&c->ws.status, sizeof(int32_t) * 4));
+    HIP_TRY(c, hipMalloc((void**)&c->row_sums, sizeof(double) * (size_t)n));
+    HIP_TRY(c, hipMalloc((void**)&c->stats, sizeof(double) * (size_t)(2 + n)));
+    HIP_TRY(c, hipMalloc((void**)&c->nz, sizeof(int32_t) * 4));
+    HIP_TRY(c, hipMemsetAsync(c->ws.tau, 0, sizeof(double) * (size_t)n, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->ws.e, 0, sizeof(double) * (size_t)n, c->stream));
+    c->ws_ready = true;
+  }
+  if (k > c->kmax) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->ws.lam) (void)hipFree(c->ws.lam);
+    if (c->ws.z) (void)hipFree(c->ws.z);
+    if (c->out_dev) (void)hipFree(c->out_dev);
+    c->ws.lam = nullptr; c->ws.z = nullptr; c->out_dev = nullptr; c->kmax = 0;
+    HIP_TRY(c, hipMalloc((void**)&c->ws.lam, sizeof(double) * (size_t)(2 * k + 2)));
+    HIP_TRY(c, hipMalloc((void**)&c->ws.z, sizeof(double) * (size_t)((int64_t)k * n)));
+    HIP_TRY(c, hipMalloc((void**)&c->out_dev, sizeof(double) * (size_t)((int64_t)k * n)));
+    c->kmax = k;
+  }
+  return PCOA_OK;
+}
+
+int finalize_impl(pcoa_ctx* c) {
+  if (c->dirty) {
+    ScopedTimer t(c, T_FINALIZE);
+    HIP_TRY(c, launch_symmetrize_i32(c->s32, c->n, c->stream));
+    c->dirty = false;
+  }
+  return PCOA_OK;
+}
+
+int upload_synth(pcoa_ctx* c, const pcoa_synth_params* p, int64_t nv) {
+  if (!p || !p->pop_offsets || !p->thresholds || p->n_pops <= 0)
+    return fail(c, PCOA_ERR_INVALID_ARG, "synthetic params: null pointer or n_pops <= 0");
+  if (p->pop_offsets[0] != 0 || p->pop_offsets[p->n_pops] != c->n)
+    return fail(c, PCOA_ERR_INVALID_ARG, "synthetic params: pop_offsets must run from 0 to n_samples");
+  std::vector<int32_t> pop((size_t)c->n);
+  for (int32_t q = 0; q < p->n_pops; ++q) {
+    if (p->pop_offsets[q + 1] < p->pop_offsets[q])
+      return fail(c, PCOA_ERR_INVALID_ARG, "synthetic params: pop_offsets not monotone");
+    for (int32_t i = p->pop_offsets[q]; i < p->pop_offsets[q + 1]; ++i) pop[(size_t)i] = q;
+  }
+  if (!c->sample_pop) HIP_TRY(c, hipMalloc((void**)&c->sample_pop, sizeof(int32_t) * (size_t)c->n));
+  // pageable-source async copies return after staging, so the local vector may die afterwards
+  HIP_TRY(c, hipMemcpyAsync(c->sample_pop, pop.data(), sizeof(int32_t) * (size_t)c->n, hipMemcpyHostToDevice,
+                            c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int rc = ensure(c, &c->thr_dev, &c->thr_cap, nv * p->n_pops);
+  if (rc != PCOA_OK) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->thr_dev, p->thresholds, sizeof(uint32_t) * (size_t)(nv * p->n_pops),
+                            hipMemcpyHostToDevice, c->stream));
+  return PCOA_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+const char* pcoa_version(void) { return "pcoa_hip 0.1 (gfx950)"; }
+
+int pcoa_create(pcoa_ctx** out, int32_t n_samples, int32_t device_ordinal, uint32_t flags) {
+  if (!out) return fail(nullptr, PCOA_ERR_INVALID_ARG, "out is NULL");
+  *out = nullptr;
+  if (n_samples <= 0) return fail(nullptr, PCOA_ERR_INVALID_ARG, "n_samples must be positive");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    return fail(nullptr, PCOA_ERR_NO_DEVICE,
+                "no HIP device visible: this engine has no CPU fallback (hipGetDeviceCount failed or returned 0)");
+  }
+  if (device_ordinal < 0 || device_ordinal >= ndev)
+    return fail(nullptr, PCOA_ERR_NO_DEVICE, "device ordinal out of range");
+  pcoa_ctx* c = new (std::nothrow) pcoa_ctx();
+  if (!c) return fail(nullptr, PCOA_ERR_OUT_OF_MEMORY, "host allocation failed");
+  c->n = n_samples;
+  c->device = device_ordinal;
+  c->flags = flags;
+  c->max_launch = env_limit("PCOA_DEBUG_MAX_LAUNCH", kMaxLaunchVariants);
+  c->fold_threshold = env_limit("PCOA_DEBUG_FOLD_THRESHOLD", kFoldThreshold);
+  auto bail = [&](hipError_t err, const char* what) {
+    int rc = hip_fail(c, err, what);
+    g_create_error = c->last_error;
+    pcoa_destroy(c);
+    return rc;
+  };
+  if ((e = hipSetDevice(device_ordinal)) != hipSuccess) return bail(e, "hipSetDevice");
+  hipDeviceProp_t prop;
+  if ((e = hipGetDeviceProperties(&prop, device_ordinal)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
+  c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  std::snprintf(c->dev_name, sizeof(c->dev_name), "%s (%s)", prop.name, prop.gcnArchName);
+  if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess)
+    return bail(e, "hipStreamCreate");
+  c->stream = c->own_stream;
+  const size_t nn = (size_t)n_samples * (size_t)n_samples;
+  if ((e = hipMalloc((void**)&c->s32, sizeof(int32_t) * nn)) != hipSuccess) return bail(e, "hipMalloc(S)");
+  if ((e = hipMemsetAsync(c->s32, 0, sizeof(int32_t) * nn, c->stream)) != hipSuccess) return bail(e, "memset(S)");
+  if ((e = hipMalloc((void**)&c->zeros, 4096)) != hipSuccess) return bail(e, "hipMalloc(zeros)");
+  if ((e = hipMemsetAsync(c->zeros, 0, 4096, c->stream)) != hipSuccess) return bail(e, "memset(zeros)");
+  if ((e = hipMalloc((void**)&c->err_flag, 16)) != hipSuccess) return bail(e, "hipMalloc(flag)");
+  if ((e = hipMemsetAsync(c->err_flag, 0, 16, c->stream)) != hipSuccess) return bail(e, "memset(flag)");
+  if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
+  *out = c;
+  return PCOA_OK;
+}
+
+void pcoa_destroy(pcoa_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+  for (auto& ev : c->pool) (void)hipEventDestroy(ev);
+  void* bufs[] = {c->s32, c->s64, c->zeros, c->err_flag, c->tile, c->csr_idx, c->csr_offs, c->thr_dev,
+                  c->sample_pop, c->xfer, c->ws.a, c->ws.d, c->ws.e, c->ws.tau, c->ws.q, c->ws.w, c->ws.lam,
+                  c->ws.z, c->ws.scratch, c->ws.iscratch, c->ws.status, c->row_sums, c->stats, c->nz,
+                  c->out_dev};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+const char* pcoa_last_error(const pcoa_ctx* c) { return c ? c->last_error.c_str() : g_create_error.c_str(); }
+
+int pcoa_n_samples(const pcoa_ctx* c) { return c ? c->n : PCOA_ERR_INVALID_ARG; }
+
+int pcoa_set_stream(pcoa_ctx* c, void* hip_stream) {
+  CHECK_CTX(c);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drain_events(c, true);
+  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  return PCOA_OK;
+}
+
+int pcoa_sync(pcoa_ctx* c) {
+  CHECK_CTX(c);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return PCOA_OK;
+}
+
+int pcoa_reset(pcoa_ctx* c) {
+  CHECK_CTX(c);
+  const size_t nn = (size_t)c->n * (size_t)c->n;
+  HIP_TRY(c, hipMemsetAsync(c->s32, 0, sizeof(int32_t) * nn, c->stream));
+  if (c->s64) HIP_TRY(c, hipMemsetAsync(c->s64, 0, sizeof(int64_t) * nn, c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->err_flag, 0, 16, c->stream));
+  c->variants_in_s32 = 0;
+  c->dirty = false;
+  c->have_data = false;
+  return PCOA_OK;
+}
+
+int pcoa_accumulate_dense_f32(pcoa_ctx* c, const float* x, int64_t n_variants, int64_t ld, int is_device_ptr) {
+  CHECK_CTX(c);
+  if (n_variants < 0 || (n_variants > 0 && !x)) return fail(c, PCOA_ERR_INVALID_ARG, "x is NULL or n_variants < 0");
+  if (ld < c->n) return fail(c, PCOA_ERR_INVALID_ARG, "ld must be >= n_samples");
+  if (n_variants == 0) return PCOA_OK;
+  if (is_device_ptr) return gram_device(c, x, n_variants, ld);
+  // host tile: stage through a device tile of at most ~256 MiB, rows packed at ld4 = round_up(n, 4)
+  const int64_t ld4 = round_up(c->n, 4);
+  const int64_t rows_cap = std::max<int64_t>(1, std::min<int64_t>(n_variants, ((int64_t)64 << 20) / ld4));
+  int rc = ensure(c, &c->tile, &c->tile_elems, rows_cap * ld4);
+  if (rc != PCOA_OK) return rc;
+  for (int64_t v0 = 0; v0 < n_variants; v0 += rows_cap) {
+    const int64_t rows = std::min(rows_cap, n_variants - v0);
+    if (ld4 != c->n) HIP_TRY(c, hipMemsetAsync(c->tile, 0, sizeof(float) * (size_t)(rows * ld4), c->stream));
+    HIP_TRY(c, hipMemcpy2DAsync(c->tile, sizeof(float) * (size_t)ld4, x + v0 * ld, sizeof(float) * (size_t)ld,
+                                sizeof(float) * (size_t)c->n, (size_t)rows, hipMemcpyHostToDevice, c->stream));
+    rc = gram_device(c, c->tile, rows, ld4);
+    if (rc != PCOA_OK) return rc;
+  }
+  // the caller may free/overwrite x after we return: pageable copies have been staged, but keep it simple
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return PCOA_OK;
+}
+
+int pcoa_accumulate_calls(pcoa_ctx* c, const int32_t* sample_idx, const int64_t* row_offsets, int64_t n_variants) {
+  CHECK_CTX(c);
+  if (n_variants < 0 || !row_offsets) return fail(c, PCOA_ERR_INVALID_ARG, "row_offsets is NULL or n_variants < 0");
+  if (n_variants == 0) return PCOA_OK;
+  const int64_t nnz_total = row_offsets[n_variants] - row_offsets[0];
+  if (nnz_total < 0 || (nnz_total > 0 && !sample_idx))
+    return fail(c, PCOA_ERR_INVALID_ARG, "sample_idx is NULL or row_offsets decreasing");
+  // validate before touching S: the reference throws on an unknown callset (VariantsPca.scala:59)
+  for (int64_t v = 0; v < n_variants; ++v)
+    if (row_offsets[v + 1] < row_offsets[v]) return fail(c, PCOA_ERR_INVALID_ARG, "row_offsets not monotone");
+  const int64_t base0 = row_offsets[0];
+  for (int64_t p = 0; p < nnz_total; ++p) {
+    const int32_t s = sample_idx[base0 + p];
+    if (s < 0 || s >= c->n) {
+      char buf[160];
+      std::snprintf(buf, sizeof(buf), "callset index %d out of range [0, %d) at entry %lld", s, c->n,
+                    (long long)(base0 + p));
+      return fail(c, PCOA_ERR_INDEX_RANGE, buf);
+    }
+  }
+  const int64_t ld4 = round_up(c->n, 4);
+  const int64_t rows_cap = std::max<int64_t>(1, std::min<int64_t>(n_variants, ((int64_t)64 << 20) / ld4));
+  int rc = ensure(c, &c->tile, &c->tile_elems, rows_cap * ld4);
+  if (rc != PCOA_OK) return rc;
+  rc = ensure(c, &c->csr_offs, &c->csr_offs_cap, rows_cap + 1);
+  if (rc != PCOA_OK) return rc;
+  for (int64_t v0 = 0; v0 < n_variants; v0 += rows_cap) {
+    const int64_t rows = std::min(rows_cap, n_variants - v0);
+    const int64_t b = row_offsets[v0], e = row_offsets[v0 + rows];
+    const int64_t nnz = e - b;
+    if (nnz == 0) continue;  // only empty rows: they add nothing (filtered at VariantsPca.scala:166)
+    rc = ensure(c, &c->csr_idx, &c->csr_idx_cap, nnz);
+    if (rc != PCOA_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->csr_idx, sample_idx + b, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice,
+                              c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->csr_offs, row_offsets + v0, sizeof(int64_t) * (size_t)(rows + 1),
+                              hipMemcpyHostToDevice, c->stream));
+    {
+      ScopedTimer t(c, T_DENSIFY);
+      HIP_TRY(c, hipMemsetAsync(c->tile, 0, sizeof(float) * (size_t)(rows * ld4), c->stream));
+      HIP_TRY(c, launch_densify_csr(c->csr_idx, c->csr_offs, 0, rows, b, c->tile, ld4, c->n, c->err_flag,
+                                    c->stream));
+    }
+    rc = gram_device(c, c->tile, rows, ld4);
+    if (rc != PCOA_OK) return rc;
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // host arrays may be released by the caller now
+  return PCOA_OK;
+}
+
+int pcoa_synth_fill_f32(pcoa_ctx* c, const pcoa_synth_params* p, int64_t first_variant, int64_t n_variants,
+                        float* x_dev, int64_t ld) {
+  CHECK_CTX(c);
+  if (n_variants < 0 || first_variant < 0 || (n_variants > 0 && !x_dev) || ld < c->n)
+    return fail(c, PCOA_ERR_INVALID_ARG, "synth_fill: bad argument");
+  if (n_variants == 0) return PCOA_OK;
+  int rc = upload_synth(c, p, n_variants);
+  if (rc != PCOA_OK) return rc;
+  {
+    ScopedTimer t(c, T_SYNTH);
+    HIP_TRY(c, launch_synth_fill_f32(p->seed, c->thr_dev, c->sample_pop, p->n_pops, first_variant, n_variants,
+                                     c->n, x_dev, ld, c->stream));
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // thresholds were copied from caller memory
+  return PCOA_OK;
+}
+
+int pcoa_accumulate_synthetic(pcoa_ctx* c, const pcoa_synth_params* p, int64_t first_variant, int64_t n_variants) {
+  CHECK_CTX(c);
+  if (n_variants < 0 || first_variant < 0) return fail(c, PCOA_ERR_INVALID_ARG, "synthetic: negative range");
+  if (n_variants == 0) return PCOA_OK;
+  if (!p || !p->thresholds) return fail(c, PCOA_ERR_INVALID_ARG, "synthetic params: null");
+  const int64_t ld4 = round_up(c->n, 4);
+  const int64_t rows_cap = std::max<int64_t>(1, std::min<int64_t>(n_variants, ((int64_t)64 << 20) / ld4));
+  int rc = ensure(c, &c->tile, &c->tile_elems, rows_cap * ld4);
+  if (rc != PCOA_OK) return rc;
+  for (int64_t v0 = 0; v0 < n_variants; v0 += rows_cap) {
+    const int64_t rows = std::min(rows_cap, n_variants - v0);
+    pcoa_synth_params q = *p;
+    q.thresholds = p->thresholds + v0 * p->n_pops;
+    rc = upload_synth(c, &q, rows);
+    if (rc != PCOA_OK) return rc;
+    {
+      ScopedTimer t(c, T_SYNTH);
+      HIP_TRY(c, launch_synth_fill_f32(q.seed, c->thr_dev, c->sample_pop, q.n_pops, first_variant + v0, rows, c->n,
+                                       c->tile, ld4, c->stream));
+    }
+    rc = gram_device(c, c->tile, rows, ld4);
+    if (rc != PCOA_OK) return rc;
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return PCOA_OK;
+}
+
+int pcoa_gram_finalize(pcoa_ctx* c) {
+  CHECK_CTX(c);
+  return finalize_impl(c);
+}
+
+int pcoa_gram_export_device_i64(pcoa_ctx* c, int64_t* dst_dev) {
+  CHECK_CTX(c);
+  if (!dst_dev) return fail(c, PCOA_ERR_INVALID_ARG, "dst_dev is NULL");
+  int rc = finalize_impl(c);
+  if (rc != PCOA_OK) return rc;
+  HIP_TRY(c, launch_export_i64(c->s32, c->s64, dst_dev, (int64_t)c->n * c->n, c->stream));
+  return PCOA_OK;
+}
+
+int pcoa_gram_import_device_i64(pcoa_ctx* c, const int64_t* src_dev) {
+  CHECK_CTX(c);
+  if (!src_dev) return fail(c, PCOA_ERR_INVALID_ARG, "src_dev is NULL");
+  const size_t nn = (size_t)c->n * (size_t)c->n;
+  if (!c->s64) HIP_TRY(c, hipMalloc((void**)&c->s64, sizeof(int64_t) * nn));
+  HIP_TRY(c, hipMemcpyAsync(c->s64, src_dev, sizeof(int64_t) * nn, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->s32, 0, sizeof(int32_t) * nn, c->stream));
+  c->variants_in_s32 = 0;
+  c->dirty = false;
+  c->have_data = true;
+  return PCOA_OK;
+}
+
+int pcoa_gram_read_i64(pcoa_ctx* c, int64_t* out_nxn) {
+  CHECK_CTX(c);
+  if (!out_nxn) return fail(c, PCOA_ERR_INVALID_ARG, "out is NULL");
+  const size_t nn = (size_t)c->n * (size_t)c->n;
+  if (!c->xfer) HIP_TRY(c, hipMalloc((void**)&c->xfer, sizeof(int64_t) * nn));
+  int rc = pcoa_gram_export_device_i64(c, c->xfer);
+  if (rc != PCOA_OK) return rc;
+  HIP_TRY(c, hipMemcpyAsync(out_nxn, c->xfer, sizeof(int64_t) * nn, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int32_t flag = 0;
+  HIP_TRY(c, hipMemcpy(&flag, c->err_flag, sizeof(flag), hipMemcpyDeviceToHost));
+  if (flag) return fail(c, PCOA_ERR_INDEX_RANGE, "a callset index outside [0, N) reached the device");
+  return PCOA_OK;
+}
+
+int pcoa_gram_load_i64(pcoa_ctx* c, const int64_t* in_nxn) {
+  CHECK_CTX(c);
+  if (!in_nxn) return fail(c, PCOA_ERR_INVALID_ARG, "in is NULL");
+  const size_t nn = (size_t)c->n * (size_t)c->n;
+  if (!c->xfer) HIP_TRY(c, hipMalloc((void**)&c->xfer, sizeof(int64_t) * nn));
+  HIP_TRY(c, hipMemcpyAsync(c->xfer, in_nxn, sizeof(int64_t) * nn, hipMemcpyHostToDevice, c->stream));
+  int rc = pcoa_gram_import_device_i64(c, c->xfer);
+  if (rc != PCOA_OK) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return PCOA_OK;
+}
+
+int pcoa_comm_unique_id(uint8_t out_id[128]) {
+  if (!out_id) return fail(nullptr, PCOA_ERR_INVALID_ARG, "out_id is NULL");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId id;
+  ncclResult_t r = ncclGetUniqueId(&id);
+  if (r != ncclSuccess) return fail(nullptr, PCOA_ERR_RCCL, std::string("ncclGetUniqueId: ") + ncclGetErrorString(r));
+  std::memcpy(out_id, &id, 128);
+  return PCOA_OK;
+}
+
+int pcoa_comm_init(pcoa_ctx* c, const uint8_t id[128], int32_t rank, int32_t n_ranks, void** comm_out) {
+  CHECK_CTX(c);
+  if (!id || !comm_out || n_ranks <= 0 || rank < 0 || rank >= n_ranks)
+    return fail(c, PCOA_ERR_INVALID_ARG, "comm_init: bad argument");
+  ncclUniqueId uid;
+  std::memcpy(&uid, id, 128);
+  ncclComm_t comm = nullptr;
+  ncclResult_t r = ncclCommInitRank(&comm, n_ranks, uid, rank);
+  if (r != ncclSuccess) return fail(c, PCOA_ERR_RCCL, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+  *comm_out = (void*)comm;
+  return PCOA_OK;
+}
+
+int pcoa_comm_destroy(void* nccl_comm) {
+  if (!nccl_comm) return PCOA_OK;
+  ncclResult_t r = ncclCommDestroy((ncclComm_t)nccl_comm);
+  return r == ncclSuccess ? PCOA_OK : fail(nullptr, PCOA_ERR_RCCL, std::string("ncclCommDestroy: ") + ncclGetErrorString(r));
+}
+
+int pcoa_gram_allreduce_rccl(pcoa_ctx* c, void* nccl_comm) {
+  CHECK_CTX(c);
+  if (!nccl_comm) return fail(c, PCOA_ERR_INVALID_ARG, "nccl_comm is NULL");
+  const size_t nn = (size_t)c->n * (size_t)c->n;
+  if (!c->xfer) HIP_TRY(c, hipMalloc((void**)&c->xfer, sizeof(int64_t) * nn));
+  int rc = pcoa_gram_export_device_i64(c, c->xfer);
+  if (rc != PCOA_OK) return rc;
+  ncclResult_t r = ncclAllReduce(c->xfer, c->xfer, nn, ncclInt64, ncclSum, (ncclComm_t)nccl_comm, c->stream);
+  if (r != ncclSuccess) return fail(c, PCOA_ERR_RCCL, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+  return pcoa_gram_import_device_i64(c, c->xfer);
+}
+
+int pcoa_center_read_f64(pcoa_ctx* c, double* out_b, double* out_row_sums, int32_t* out_nonzero_rows,
+                         double* out_matrix_mean) {
+  CHECK_CTX(c);
+  int rc = finalize_impl(c);
+  if (rc != PCOA_OK) return rc;
+  rc = ensure_workspace(c, 1);
+  if (rc != PCOA_OK) return rc;
+  const size_t n = (size_t)c->n;
+  {
+    ScopedTimer t(c, T_CENTER);
+    HIP_TRY(c, launch_center(c->s32, c->s64, c->n, c->row_sums, c->stats, c->nz, out_b ? c->ws.a : nullptr,
+                             c->stream));
+  }
+  if (out_b) HIP_TRY(c, hipMemcpyAsync(out_b, c->ws.a, sizeof(double) * n * n, hipMemcpyDeviceToHost, c->stream));
+  if (out_row_sums)
+    HIP_TRY(c, hipMemcpyAsync(out_row_sums, c->row_sums, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  double st[2] = {0, 0};
+  int32_t nzh = 0;
+  HIP_TRY(c, hipMemcpyAsync(st, c->stats, sizeof(st), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(&nzh, c->nz, sizeof(nzh), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (out_nonzero_rows) *out_nonzero_rows = nzh;
+  if (out_matrix_mean) *out_matrix_mean = st[1];
+  return PCOA_OK;
+}
+
+int pcoa_compute(pcoa_ctx* c, int32_t num_pc, double* out_components, double* out_eigenvalues,
+                 int32_t* out_nonzero_rows) {
+  CHECK_CTX(c);
+  const int32_t n = c->n;
+  if (num_pc <= 0 || num_pc > n) {
+    char buf[128];
+    std::snprintf(buf, sizeof(buf), "num_pc = %d out of range (0, n = %d]", num_pc, n);  // MLlib require(k > 0 && k <= n)
+    return fail(c, PCOA_ERR_INVALID_ARG, buf);
+  }
+  if (!out_components) return fail(c, PCOA_ERR_INVALID_ARG, "out_components is NULL");
+  int rc = finalize_impl(c);
+  if (rc != PCOA_OK) return rc;
+  rc = ensure_workspace(c, num_pc);
+  if (rc != PCOA_OK) return rc;
+
+  hipEvent_t w0 = get_event(c), w1 = get_event(c);
+  if (w0) (void)hipEventRecord(w0, c->stream);
+
+  {
+    ScopedTimer t(c, T_CENTER);
+    HIP_TRY(c, launch_center(c->s32, c->s64, n, c->row_sums, c->stats, c->nz, c->ws.a, c->stream));
+  }
+  {
+    ScopedTimer t(c, T_TRIDIAG);
+    HIP_TRY(c, launch_tridiagonalize(c->ws, n, c->stream));
+  }
+  // candidates: the k algebraically largest and the k smallest eigenvalues of T; MLlib ranks by the
+  // singular values of Cov, i.e. by |lambda| (B = J S J is PSD up to rounding, so normally the largest)
+  std::vector<int32_t> idx;
+  for (int32_t t = 0; t < num_pc; ++t) idx.push_back(n - 1 - t);
+  for (int32_t t = 0; t < num_pc; ++t)
+    if (t < n - num_pc) idx.push_back(t);
+  std::vector<double> cand(idx.size());
+  {
+    ScopedTimer t(c, T_EIG);
+    HIP_TRY(c, launch_bisect(c->ws, n, idx.data(), (int32_t)idx.size(), c->ws.lam, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(cand.data(), c->ws.lam, sizeof(double) * cand.size(), hipMemcpyDeviceToHost,
+                              c->stream));
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  std::vector<int> order(cand.size());
+  for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    const double fa = std::fabs(cand[a]), fb = std::fabs(cand[b]);
+    if (fa != fb) return fa > fb;
+    return cand[a] > cand[b];
+  });
+  std::vector<double> sel((size_t)num_pc);
+  for (int32_t t = 0; t < num_pc; ++t) {
+    if (!std::isfinite(cand[order[t]])) return fail(c, PCOA_ERR_NOT_CONVERGED, "non-finite eigenvalue");
+    sel[(size_t)t] = cand[order[t]];
+  }
+  {
+    ScopedTimer t(c, T_EIG);
+    HIP_TRY(c, launch_inverse_iteration(c->ws, n, sel.data(), num_pc, c->stream));
+  }
+  {
+    ScopedTimer t(c, T_BACK);
+    HIP_TRY(c, launch_backtransform(c->ws, n, num_pc, (c->flags & PCOA_FLAG_NO_SIGN_NORM) ? 0 : 1, c->out_dev,
+                                    c->stream));
+  }
+  HIP_TRY(c, hipMemcpyAsync(out_components, c->out_dev, sizeof(double) * (size_t)num_pc * (size_t)n,
+                            hipMemcpyDeviceToHost, c->stream));
+  int32_t nzh = 0;
+  HIP_TRY(c, hipMemcpyAsync(&nzh, c->nz, sizeof(nzh), hipMemcpyDeviceToHost, c->stream));
+  if (w1) (void)hipEventRecord(w1, c->stream);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (w0 && w1) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, w0, w1) == hipSuccess) c->compute_total = (double)ms * 1e-3;
+  }
+  if (w0) c->pool.push_back(w0);
+  if (w1) c->pool.push_back(w1);
+  for (int32_t t = 0; t < num_pc; ++t) {
+    for (int32_t i = 0; i < n; ++i)
+      if (!std::isfinite(out_components[(size_t)t * n + i]))
+        return fail(c, PCOA_ERR_NOT_CONVERGED, "non-finite eigenvector entry");
+  }
+  if (out_eigenvalues)
+    for (int32_t t = 0; t < num_pc; ++t) out_eigenvalues[t] = sel[(size_t)t];
+  if (out_nonzero_rows) *out_nonzero_rows = nzh;
+  return PCOA_OK;
+}
+
+int pcoa_get_timings(pcoa_ctx* c, pcoa_timings* out) {
+  CHECK_CTX(c);
+  if (!out) return fail(c, PCOA_ERR_INVALID_ARG, "out is NULL");
+  drain_events(c, true);
+  std::memset(out, 0, sizeof(*out));
+  out->gram_kernel_seconds = c->tsec[T_GRAM];
+  out->gram_kernel_launches = c->gram_launches;
+  out->gram_variants = c->gram_variants;
+  out->gram_flops = c->gram_flops;
+  out->gram_bytes = c->gram_bytes;
+  out->densify_seconds = c->tsec[T_DENSIFY];
+  out->synth_seconds = c->tsec[T_SYNTH];
+  out->finalize_seconds = c->tsec[T_FINALIZE];
+  out->center_seconds = c->tsec[T_CENTER];
+  out->tridiag_seconds = c->tsec[T_TRIDIAG];
+  out->eig_seconds = c->tsec[T_EIG];
+  out->backtransform_seconds = c->tsec[T_BACK];
+  out->compute_total_seconds = c->compute_total;
+  out->gram_kernel_kind = c->gram_kind;
+  return PCOA_OK;
+}
+
+int pcoa_reset_timings(pcoa_ctx* c) {
+  CHECK_CTX(c);
+  drain_events(c, true);
+  for (double& t : c->tsec) t = 0;
+  c->gram_launches = 0;
+  c->gram_variants = 0;
+  c->gram_flops = c->gram_bytes = 0;
+  c->compute_total = 0;
+  return PCOA_OK;
+}
+
+int pcoa_device_info(pcoa_ctx* c, char* name_out, int32_t name_cap, int32_t* cu_count_out) {
+  CHECK_CTX(c);
+  if (name_out && name_cap > 0) {
+    std::strncpy(name_out, c->dev_name, (size_t)name_cap - 1);
+    name_out[name_cap - 1] = 0;
+  }
+  if (cu_count_out) *cu_count_out = c->num_cu;
+  return PCOA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,79 @@
+// Internal declarations shared by the HIP translation units of libpcoa_hip.so.
+// gfx950 (MI355X / CDNA4) only: 64-wide wavefronts, MFMA, 160 KiB LDS per CU, 8 XCDs x 32 CUs.
+#ifndef PCOA_INTERNAL_H_
+#define PCOA_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "pcoa.h"
+
+namespace pcoa {
+
+constexpr int kWave = 64;     // CDNA wavefront
+constexpr int kNumXcd = 8;    // MI355X: block b is dispatched to XCD b % 8 (speed only, never correctness)
+
+// ---- Gram kernels (gram_f32.hip / gram_i8.hip) ------------------------------------------------
+struct GramLaunch {
+  const float* x;        // device, [nv][ld] carrier multiplicities (0/1)
+  int64_t ld;
+  int64_t nv;            // variants in this launch (<= 2^24 so fp32 accumulators stay exact)
+  int32_t n;             // samples
+  int32_t* s32;          // device, [n][n] int32 partial (upper-triangular tiles only)
+  const float* zeros;    // device, >= 4 KiB of zeros (source for out-of-range rows)
+  int num_cu;
+  hipStream_t stream;
+};
+// Returns hipSuccess or the launch error.  *splitk_out (optional) receives the split-K factor used.
+hipError_t launch_gram_f32(const GramLaunch& g, int* splitk_out);
+hipError_t launch_gram_i8(const GramLaunch& g, int* splitk_out);
+
+// ---- auxiliary Gram kernels (gram_aux.hip) ----------------------------------------------------
+hipError_t launch_densify_csr(const int32_t* idx_dev, const int64_t* offs_dev, int64_t v0, int64_t nv,
+                              int64_t offs_base, float* x_dev, int64_t ld, int32_t n, int32_t* err_flag_dev,
+                              hipStream_t stream);
+hipError_t launch_symmetrize_i32(int32_t* s32, int32_t n, hipStream_t stream);
+hipError_t launch_fold_i32_to_i64(int32_t* s32, int64_t* s64, int64_t count, hipStream_t stream);
+hipError_t launch_export_i64(const int32_t* s32, const int64_t* s64_or_null, int64_t* dst, int64_t count,
+                             hipStream_t stream);
+hipError_t launch_synth_fill_f32(uint64_t seed, const uint32_t* thresholds_dev, const int32_t* sample_pop_dev,
+                                 int32_t n_pops, int64_t first_variant, int64_t nv, int32_t n, float* x_dev,
+                                 int64_t ld, hipStream_t stream);
+
+// ---- centring (center.hip) --------------------------------------------------------------------
+// s = s32 + (s64 ? s64 : 0).  row_sums[n] (fp64), stats[0] = matrix sum, stats[1] = matrix mean,
+// nz[0] = #rows with sum > 0.  b = centred matrix fp64 [n][n].
+hipError_t launch_center(const int32_t* s32, const int64_t* s64_or_null, int32_t n, double* row_sums,
+                         double* stats, int32_t* nz, double* b, hipStream_t stream);
+
+// ---- symmetric eigensolver (eig.hip) ----------------------------------------------------------
+struct EigWorkspace {
+  double* a;        // [n][n] in: symmetric matrix B; out: reflector vectors in rows (row k, cols k+1..n-1)
+  double* d;        // [n]   diagonal of T
+  double* e;        // [n]   off-diagonal of T (n-1 used)
+  double* tau;      // [n]   reflector scalars (n-2 used)
+  double* q;        // [n]   A22 * v  (raw matvec of the current step)
+  double* w;        // [2][n] rank-2 update vectors, ping-pong
+  double* lam;      // [2*kmax] candidate eigenvalues (k largest then k smallest)
+  double* z;        // [kmax][n] eigenvectors of T, then of A (column c at z + c*n)
+  double* scratch;  // [6][n] LU factors for inverse iteration
+  int32_t* iscratch;// [n]
+  int32_t* status;  // [4] device status words (0 = ok)
+};
+hipError_t launch_tridiagonalize(const EigWorkspace& ws, int32_t n, hipStream_t stream);
+// eigenvalues with ascending indices idx[0..count) of T -> lam_out[0..count) (device)
+hipError_t launch_bisect(const EigWorkspace& ws, int32_t n, const int32_t* idx_host, int32_t count,
+                         double* lam_out_dev, hipStream_t stream);
+// eigenvectors of T for lam_sel[0..k) (host values) -> ws.z
+hipError_t launch_inverse_iteration(const EigWorkspace& ws, int32_t n, const double* lam_sel_host, int32_t k,
+                                    hipStream_t stream);
+// ws.z <- Q * ws.z, normalise, sign-normalise (optional); out_dev[c*n + i] column-major
+hipError_t launch_backtransform(const EigWorkspace& ws, int32_t n, int32_t k, int sign_normalize,
+                                double* out_dev, hipStream_t stream);
+
+}  // namespace pcoa
+
+#endif  // PCOA_INTERNAL_H_

@@ -1,0 +1,57 @@
+"""Multi-GPU sharding of the Gram accumulation: one process per GPU, variants partitioned, one
+all-reduce of the partial N x N matrix (replaces reduceByKey(_ + _), VariantsPca.scala:190).
+
+S = sum_v x_v x_v^T is a sum over variants, so rank r takes the contiguous variant range
+shard_range(r, world, V) exactly as the reference's partitions do (VariantsPca.scala:184-190);
+integer partials make the result independent of the number of ranks and of the reduction order.
+The eigendecomposition runs on rank 0 (every rank holds the reduced S, so any rank could).
+
+torch.distributed is used for rendezvous and the collective only (backend "nccl" is RCCL on ROCm;
+"gloo" in the CPU tests).  The C ABI also offers a torch-free path: pcoa_comm_* +
+pcoa_gram_allreduce_rccl.
+"""
+import numpy as np
+
+
+def shard_range(rank, world_size, n_variants):
+    """Contiguous, balanced partition of [0, n_variants): the first (V mod W) ranks get one extra."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank %d outside [0, %d)" % (rank, world_size))
+    base, extra = divmod(int(n_variants), int(world_size))
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def allreduce_gram_tensor(t, group=None):
+    """In-place sum of an int64 [N][N] tensor over the process group (CPU/gloo or GPU/RCCL)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def allreduce_engine(engine, group=None, scratch=None):
+    """All-reduce the finalized S of a PcoaEngine across ranks through a torch int64 device tensor
+    (export -> all_reduce over RCCL/xGMI -> import).  Returns the scratch tensor for reuse."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        engine.finalize()
+        return scratch
+    if scratch is None:
+        scratch = torch.empty((engine.n, engine.n), dtype=torch.int64, device="cuda:%d" % engine.device)
+    engine.export_device(scratch.data_ptr())
+    engine.sync()  # the export ran on the engine's stream; the collective runs on torch's
+    dist.all_reduce(scratch, op=dist.ReduceOp.SUM, group=group)
+    torch.cuda.current_stream(scratch.device).synchronize()
+    engine.import_device(scratch.data_ptr())
+    engine.sync()
+    return scratch
+
+
+def allreduce_gram_numpy(s_local, group=None):
+    """CPU twin used by the gloo tests: numpy int64 partial -> summed numpy int64."""
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(s_local, dtype=np.int64).copy())
+    allreduce_gram_tensor(t, group)
+    return t.numpy()

@@ -1,0 +1,215 @@
+"""PcoaEngine -- thin object wrapper over the C ABI (include/pcoa.h).
+
+One engine = one pcoa_ctx = one GPU.  The method names follow the stages of the reference driver
+(VariantsPca.scala:44-47): getSimilarityMatrix -> accumulate_* / finalize, computePca -> compute.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib as L
+
+
+class PcoaError(RuntimeError):
+    def __init__(self, code, message):
+        RuntimeError.__init__(self, "pcoa error %d: %s" % (code, message))
+        self.code = code
+
+
+class IndexRangeError(PcoaError, IndexError):
+    """A callset index outside [0, N): the reference throws NoSuchElementException /
+    IndexOutOfBounds here (VariantsPca.scala:59, :188)."""
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+class PcoaEngine(object):
+    def __init__(self, n_samples, device=0, flags=L.PCOA_FLAG_DEFAULT):
+        self._lib = L.load()
+        self._ctx = ctypes.c_void_p()
+        rc = self._lib.pcoa_create(ctypes.byref(self._ctx), int(n_samples), int(device), int(flags))
+        if rc != L.PCOA_OK:
+            msg = self._lib.pcoa_last_error(None)
+            self._ctx = None
+            raise PcoaError(rc, msg.decode() if msg else "pcoa_create failed")
+        self.n = int(n_samples)
+        self.device = int(device)
+        self._keepalive = []
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc):
+        if rc != L.PCOA_OK:
+            msg = self._lib.pcoa_last_error(self._ctx)
+            msg = msg.decode() if msg else ""
+            if rc == L.PCOA_ERR_INDEX_RANGE:
+                raise IndexRangeError(rc, msg)
+            raise PcoaError(rc, msg)
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.pcoa_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def sync(self):
+        self._check(self._lib.pcoa_sync(self._ctx))
+        self._keepalive = []
+
+    def reset(self):
+        self._check(self._lib.pcoa_reset(self._ctx))
+
+    def set_stream(self, hip_stream_ptr):
+        self._check(self._lib.pcoa_set_stream(self._ctx, ctypes.c_void_p(hip_stream_ptr or 0)))
+
+    def device_info(self):
+        buf = ctypes.create_string_buffer(256)
+        cu = ctypes.c_int32(0)
+        self._check(self._lib.pcoa_device_info(self._ctx, buf, 256, ctypes.byref(cu)))
+        return buf.value.decode(), int(cu.value)
+
+    # ------------------------------------------------------------------ getSimilarityMatrix
+    def accumulate_calls(self, sample_idx, row_offsets):
+        """CSR carrier lists: exactly what RDD[Seq[Int]] carries (VariantsPca.scala:153-168)."""
+        idx = np.ascontiguousarray(sample_idx, dtype=np.int32)
+        offs = np.ascontiguousarray(row_offsets, dtype=np.int64)
+        if offs.ndim != 1 or offs.size < 1:
+            raise ValueError("row_offsets must have n_variants + 1 entries")
+        if idx.size == 0:
+            idx = np.zeros(1, dtype=np.int32)
+        self._check(self._lib.pcoa_accumulate_calls(self._ctx, _ptr(idx), _ptr(offs), offs.size - 1))
+
+    def accumulate_callsets(self, callsets):
+        """Convenience: list of per-variant index lists."""
+        offs = np.zeros(len(callsets) + 1, dtype=np.int64)
+        for v, c in enumerate(callsets):
+            offs[v + 1] = offs[v] + len(c)
+        idx = np.fromiter((i for c in callsets for i in c), dtype=np.int32, count=int(offs[-1]))
+        self.accumulate_calls(idx, offs)
+
+    def accumulate_dense(self, x, n_variants=None, ld=None):
+        """Dense variants x samples fp32 tile.  `x` is a numpy array (host) or any object with
+        data_ptr()/is_cuda (a torch CUDA tensor: read in place, kept alive until sync())."""
+        if hasattr(x, "data_ptr") and getattr(x, "is_cuda", False):
+            import torch  # plumbing only: device memory handle
+            assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+            nv = int(x.shape[0]) if n_variants is None else int(n_variants)
+            ldv = int(x.stride(0)) if ld is None else int(ld)
+            self._keepalive.append(x)
+            self._check(self._lib.pcoa_accumulate_dense_f32(self._ctx, ctypes.c_void_p(x.data_ptr()), nv, ldv, 1))
+            return
+        a = np.ascontiguousarray(x, dtype=np.float32)
+        if a.ndim != 2:
+            raise ValueError("x must be 2-D [variants][samples]")
+        nv = a.shape[0] if n_variants is None else int(n_variants)
+        ldv = a.shape[1] if ld is None else int(ld)
+        self._check(self._lib.pcoa_accumulate_dense_f32(self._ctx, _ptr(a), nv, ldv, 0))
+
+    def accumulate_dense_device_ptr(self, ptr, n_variants, ld):
+        self._check(self._lib.pcoa_accumulate_dense_f32(self._ctx, ctypes.c_void_p(int(ptr)), int(n_variants),
+                                                        int(ld), 1))
+
+    def _synth_params(self, seed, pop_offsets, thresholds):
+        po = np.ascontiguousarray(pop_offsets, dtype=np.int32)
+        th = np.ascontiguousarray(thresholds, dtype=np.uint32)
+        p = L.PcoaSynthParams()
+        p.seed = int(seed)
+        p.n_pops = int(po.size - 1)
+        p.pop_offsets = po.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        p.thresholds = th.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+        return p, (po, th)
+
+    def accumulate_synthetic(self, seed, pop_offsets, thresholds, first_variant):
+        th = np.asarray(thresholds)
+        p, keep = self._synth_params(seed, pop_offsets, th)
+        self._check(self._lib.pcoa_accumulate_synthetic(self._ctx, ctypes.byref(p), int(first_variant),
+                                                        int(th.shape[0])))
+        del keep
+
+    def synth_fill(self, seed, pop_offsets, thresholds, first_variant, x_dev_ptr, ld):
+        th = np.asarray(thresholds)
+        p, keep = self._synth_params(seed, pop_offsets, th)
+        self._check(self._lib.pcoa_synth_fill_f32(self._ctx, ctypes.byref(p), int(first_variant), int(th.shape[0]),
+                                                  ctypes.c_void_p(int(x_dev_ptr)), int(ld)))
+        del keep
+
+    def finalize(self):
+        self._check(self._lib.pcoa_gram_finalize(self._ctx))
+
+    def gram(self):
+        """All N^2 entries of S as int64 (zeros included, as matrix.iterator emits them, :189)."""
+        out = np.zeros((self.n, self.n), dtype=np.int64)
+        self._check(self._lib.pcoa_gram_read_i64(self._ctx, _ptr(out)))
+        return out
+
+    def load_gram(self, s):
+        a = np.ascontiguousarray(s, dtype=np.int64)
+        if a.shape != (self.n, self.n):
+            raise ValueError("expected an %d x %d matrix" % (self.n, self.n))
+        self._check(self._lib.pcoa_gram_load_i64(self._ctx, _ptr(a)))
+
+    def export_device(self, dst_ptr):
+        self._check(self._lib.pcoa_gram_export_device_i64(self._ctx, ctypes.c_void_p(int(dst_ptr))))
+
+    def import_device(self, src_ptr):
+        self._check(self._lib.pcoa_gram_import_device_i64(self._ctx, ctypes.c_void_p(int(src_ptr))))
+
+    # ------------------------------------------------------------------ native RCCL
+    def comm_unique_id(self):
+        buf = (ctypes.c_uint8 * 128)()
+        self._check(self._lib.pcoa_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, n_ranks):
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(unique_id)
+        comm = ctypes.c_void_p()
+        self._check(self._lib.pcoa_comm_init(self._ctx, ctypes.cast(buf, ctypes.c_void_p), int(rank), int(n_ranks),
+                                             ctypes.byref(comm)))
+        return comm
+
+    def comm_destroy(self, comm):
+        self._check(self._lib.pcoa_comm_destroy(comm))
+
+    def allreduce_rccl(self, comm):
+        self._check(self._lib.pcoa_gram_allreduce_rccl(self._ctx, comm))
+
+    # ------------------------------------------------------------------ computePca
+    def center(self, want_matrix=True):
+        """Row sums + double-centring (VariantsPca.scala:206-223).  Returns (B, row_sums, nonzero_rows, mean)."""
+        b = np.zeros((self.n, self.n), dtype=np.float64) if want_matrix else None
+        rs = np.zeros(self.n, dtype=np.float64)
+        nz = ctypes.c_int32(0)
+        mm = ctypes.c_double(0.0)
+        self._check(self._lib.pcoa_center_read_f64(self._ctx, _ptr(b) if want_matrix else None, _ptr(rs),
+                                                   ctypes.byref(nz), ctypes.byref(mm)))
+        return b, rs, int(nz.value), float(mm.value)
+
+    def compute(self, num_pc=2):
+        """computePca (VariantsPca.scala:198-231).  Returns (components [N, k], eigenvalues [k], nonzero_rows)."""
+        k = int(num_pc)
+        comps = np.zeros((max(k, 1), self.n), dtype=np.float64)  # column-major N x k == row-major k x N
+        lam = np.zeros(max(k, 1), dtype=np.float64)
+        nz = ctypes.c_int32(0)
+        self._check(self._lib.pcoa_compute(self._ctx, k, _ptr(comps), _ptr(lam), ctypes.byref(nz)))
+        return np.ascontiguousarray(comps[:k].T), lam[:k].copy(), int(nz.value)
+
+    # ------------------------------------------------------------------ instrumentation
+    def timings(self):
+        t = L.PcoaTimings()
+        self._check(self._lib.pcoa_get_timings(self._ctx, ctypes.byref(t)))
+        return dict((f[0], getattr(t, f[0])) for f in L.PcoaTimings._fields_ if f[0] != "reserved")
+
+    def reset_timings(self):
+        self._check(self._lib.pcoa_reset_timings(self._ctx))

@@ -1,0 +1,118 @@
+"""Local data sources for the driver (host-side ETL; not on the GPU hot path).
+
+The reference streamed variants from the Google Genomics API (VariantsRDD.scala:205-235) and listed
+callsets over REST (VariantsCommon.scala:38-50); that service is gone.  These loaders reproduce the
+semantics that matter downstream: callset index = position in the callset list
+(VariantsCommon.scala:44-45), hasVariation = any allele index > 0 (VariantsPca.scala:56-60),
+variants without a varying call dropped (VariantsPca.scala:164-167), `dataset` = callset id up to
+the first '-' (VariantsPca.scala:235).
+"""
+import gzip
+import os
+import re
+
+import numpy as np
+
+from . import synth
+
+# contig normalisation of the reference (VariantsRDD.scala:103-110): only [a-z]*[0-9]* survives,
+# which drops X / Y / MT; the numeric part is the contig key.
+_CONTIG_RE = re.compile(r"^([a-z]*)?([0-9]+)$")
+
+
+def normalize_contig(name):
+    m = _CONTIG_RE.match(name.lower())
+    return m.group(2) if m else None
+
+
+def parse_references(refs):
+    """'chr17:41196311:41277499' (optionally comma separated) -> [(contig, start, end)]"""
+    out = []
+    for item in refs or []:
+        for tup in item.split(","):
+            if not tup:
+                continue
+            contig, start, end = tup.split(":")
+            out.append((normalize_contig(contig) or contig, int(start), int(end)))
+    return out
+
+
+def load_npz(path):
+    z = np.load(path, allow_pickle=False)
+    ids = [str(s) for s in z["callset_ids"]]
+    names = [str(s) for s in z["callset_names"]] if "callset_names" in z.files else ids
+    indexes = dict((cid, i) for i, cid in enumerate(ids))
+    name_map = dict(zip(ids, names))
+    return indexes, name_map, [("csr", z["sample_idx"].astype(np.int32), z["row_offsets"].astype(np.int64))]
+
+
+def load_vcf(path, references=None):
+    """Minimal VCF reader: GT only.  Returns CSR carrier lists directly."""
+    regions = parse_references(references)
+    opener = gzip.open if path.endswith(".gz") else open
+    set_id = os.path.basename(path).split(".")[0].replace("-", "_")
+    samples = None
+    idx_chunks, offs = [], [0]
+    with opener(path, "rt") as f:
+        for line in f:
+            if line.startswith("##"):
+                continue
+            if line.startswith("#CHROM"):
+                samples = line.rstrip("\n").split("\t")[9:]
+                continue
+            if samples is None:
+                raise ValueError("VCF header line (#CHROM) missing")
+            rec = line.rstrip("\n").split("\t")
+            if len(rec) < 10:
+                continue
+            contig = normalize_contig(rec[0])
+            if contig is None:
+                continue  # the reference drops contigs such as X, Y, MT (VariantsRDD.scala:132-136)
+            start = int(rec[1]) - 1
+            if regions and not any(c == contig and s <= start < e for (c, s, e) in regions):
+                continue
+            fmt = rec[8].split(":")
+            if "GT" not in fmt:
+                continue
+            gti = fmt.index("GT")
+            carriers = []
+            for i, cell in enumerate(rec[9:]):
+                parts = cell.split(":")
+                gt = parts[gti] if gti < len(parts) else "."
+                has_variation = False
+                for allele in re.split(r"[/|]", gt):
+                    if allele not in (".", "") and int(allele) > 0:
+                        has_variation = True
+                if has_variation:
+                    carriers.append(i)
+            if carriers:
+                idx_chunks.append(np.asarray(carriers, dtype=np.int32))
+                offs.append(offs[-1] + len(carriers))
+    if samples is None:
+        raise ValueError("no #CHROM header in %s" % path)
+    ids = ["%s-%d" % (set_id, i) for i in range(len(samples))]
+    idx = np.concatenate(idx_chunks) if idx_chunks else np.zeros(0, dtype=np.int32)
+    indexes = dict((cid, i) for i, cid in enumerate(ids))
+    return indexes, dict(zip(ids, samples)), [("csr", idx, np.asarray(offs, dtype=np.int64))]
+
+
+def synthetic_dataset(spec):
+    """'V,N,seed' -> Balding-Nichols synthetic carriers as CSR (host generated; small V only)."""
+    v, n, seed = [int(t) for t in spec.split(",")]
+    offsets = synth.pop_offsets(n)
+    thr = synth.thresholds(seed, 0, v, n_pops=len(offsets) - 1)
+    x = synth.genotypes(seed, 0, thr, offsets, dtype=np.uint8)
+    keep = x.any(axis=1)
+    x = x[keep]
+    counts = x.sum(axis=1).astype(np.int64)
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    idx = np.nonzero(x)[1].astype(np.int32)
+    pops = ["AFR", "AMR", "EAS", "EUR", "SAS"]
+    ids, names = [], {}
+    for i in range(n):
+        p = int(np.searchsorted(offsets, i, side="right") - 1)
+        cid = "%s-%d" % (pops[p % len(pops)], i)
+        ids.append(cid)
+        names[cid] = "S%06d" % i
+    indexes = dict((cid, i) for i, cid in enumerate(ids))
+    return indexes, names, [("csr", idx, offs)]

@@ -1,0 +1,284 @@
+"""Host-side mirror of the reference's PCoA driver, on top of the HIP engine.
+
+Same names, argument meaning and error behaviour as the reference interface for this path:
+
+  reference (Scala, VariantsPca.scala)                     here
+  ---------------------------------------------------------------------------------------------
+  VariantsPcaDriver.extractCallInfo            :56-60      extract_call_info
+  VariantsPcaDriver.getCallsRdd                :153-168    VariantsPcaDriver.getCallsRdd / prepare_call_data
+  VariantsPcaDriver.getSimilarityMatrix        :182-191    VariantsPcaDriver.getSimilarityMatrix / calculate_similarity_matrix
+  VariantsPcaDriver.computePca                 :198-231    VariantsPcaDriver.computePca / center_matrix + perform_pca
+  VariantsPcaDriver.emitResult                 :233-246    VariantsPcaDriver.emitResult
+  VariantsPcaDriver.main                       :38-50      main
+  PcaConf / GenomicsConf flags                 GenomicsConf.scala:31-101   PcaConf
+
+and of the Python twin src/main/python/variants_pca.py (prepare_call_data :19-52,
+calculate_similarity_matrix :54-82, center_matrix :84-121, perform_pca :123-152).
+
+An "RDD" here is a plain Python list (of variant dicts, or of per-variant index lists); the
+distributed part of the reference (partitions + reduceByKey) is the GPU Gram kernel + all-reduce.
+Nothing in this module computes on the CPU: every matrix operation goes through libpcoa_hip.so.
+"""
+from __future__ import print_function
+
+import argparse
+import sys
+
+import numpy as np
+
+from .engine import PcoaEngine
+
+
+# --------------------------------------------------------------------------------------------- a1/a2
+def extract_call_info(variant, mapping):
+    """VariantsPcaDriver.extractCallInfo (VariantsPca.scala:56-60).
+
+    variant: dict with optional 'calls' -> list of {'callSetId'|'callsetId': str, 'genotype': [int]}.
+    Returns [(hasVariation, callsetIndex)]; hasVariation = genotype.exists(_ > 0) -- a missing
+    allele (-1) or hom-ref (0) does not vary.  An unknown callset id raises KeyError, as
+    mapping(call.callsetId) throws NoSuchElementException in the reference."""
+    out = []
+    for call in (variant.get("calls") or []):
+        cid = call["callSetId"] if "callSetId" in call else call["callsetId"]
+        has_variation = False
+        for allele in call.get("genotype", []):
+            has_variation = has_variation or allele > 0
+        out.append((has_variation, mapping[cid]))
+    return out
+
+
+def prepare_call_data(py_rdd, py_id_to_index):
+    """prepare_call_data (variants_pca.py:19-52) == getCallsRdd for one variant set
+    (VariantsPca.scala:153-157,163-167): keep calls with variation, drop variants with none,
+    map callset ids to indices.  Returns a list of index lists (RDD[Seq[Int]]).
+
+    Note: the Python twin tests any(genotype) (non-zero, so -1 counts) where the Scala driver tests
+    _ > 0; this mirror follows the Scala driver."""
+    call_rdd = []
+    for variant in py_rdd:
+        calls = [idx for (has_variation, idx) in extract_call_info(variant, py_id_to_index) if has_variation]
+        if len(calls) > 0:
+            call_rdd.append(calls)
+    return call_rdd
+
+
+# --------------------------------------------------------------------------------------------- a3
+def calculate_similarity_matrix(call_rdd, matrix_size, engine=None, device=0):
+    """calculate_similarity_matrix (variants_pca.py:54-82) == getSimilarityMatrix
+    (VariantsPca.scala:182-191).  call_rdd: list of index lists, or a (sample_idx, row_offsets) CSR
+    pair.  Returns the PcoaEngine holding S in HBM (use .gram() for the N^2 entries)."""
+    eng = engine if engine is not None else PcoaEngine(matrix_size, device=device)
+    if isinstance(call_rdd, tuple):
+        eng.accumulate_calls(call_rdd[0], call_rdd[1])
+    else:
+        eng.accumulate_callsets(call_rdd)
+    eng.finalize()
+    return eng
+
+
+# --------------------------------------------------------------------------------------------- a5/a6
+def center_matrix(sim_matrix, row_count):
+    """center_matrix (variants_pca.py:84-121; VariantsPca.scala:199-223).
+    sim_matrix: PcoaEngine (as returned above) or an N x N integer array.  Returns B (N x N fp64)."""
+    eng = _as_engine(sim_matrix, row_count)
+    b, _, _, _ = eng.center()
+    return b
+
+
+# --------------------------------------------------------------------------------------------- a7
+def perform_pca(matrix, row_count, nr_principal_components=2):
+    """perform_pca (variants_pca.py:123-152; VariantsPca.scala:224-227).  `matrix` is the engine
+    holding S (centring is part of computePca on the device) or an N x N similarity array.
+    Returns an N x k numpy array (unit-norm columns, sign-normalised)."""
+    eng = _as_engine(matrix, row_count)
+    comps, _, _ = eng.compute(nr_principal_components)
+    return comps
+
+
+def _as_engine(obj, row_count):
+    if isinstance(obj, PcoaEngine):
+        if obj.n != row_count:
+            raise ValueError("row_count %d does not match the engine's N = %d" % (row_count, obj.n))
+        return obj
+    eng = PcoaEngine(row_count)
+    eng.load_gram(np.asarray(obj))
+    return eng
+
+
+# --------------------------------------------------------------------------------------------- conf
+class PcaConf(object):
+    """Flags of PcaConf / GenomicsConf (GenomicsConf.scala:31-101), same names and defaults.
+    Spark- and cloud-specific flags are accepted and ignored; --input-path names a local dataset
+    (the Genomics API the reference streamed from no longer exists)."""
+
+    def __init__(self, arguments):
+        p = argparse.ArgumentParser(prog="VariantsPcaDriver", description=self.__doc__)
+        p.add_argument("--bases-per-partition", type=int, default=1000000)
+        p.add_argument("--client-secrets", type=str, default=None)
+        p.add_argument("--input-path", type=str, default=None,
+                       help=".npz (callset_ids, [callset_names], sample_idx, row_offsets) or .vcf[.gz]")
+        p.add_argument("--num-reduce-partitions", type=int, default=10)
+        p.add_argument("--output-path", type=str, default=None)
+        p.add_argument("--references", type=str, nargs="*", default=["chr17:41196311:41277499"])
+        p.add_argument("--spark-master", type=str, default=None)
+        p.add_argument("--variant-set-id", type=str, nargs="*", default=["3049512673186936334"])
+        p.add_argument("--all-references", action="store_true")
+        p.add_argument("--debug-datasets", action="store_true")
+        p.add_argument("--min-allele-frequency", type=float, default=None)
+        p.add_argument("--num-pc", type=int, default=2)
+        # additions of this engine
+        p.add_argument("--synthetic", type=str, default=None, help="V,N,seed: synthetic Balding-Nichols input")
+        p.add_argument("--gpu", type=int, default=0)
+        a = p.parse_args(list(arguments))
+        self.__dict__.update(vars(a))
+        self.numPc = a.num_pc
+        self.outputPath = a.output_path
+        self.inputPath = a.input_path
+        self.minAlleleFrequency = a.min_allele_frequency
+
+
+def java_double_to_string(d):
+    """Double.toString, which the reference's string interpolation uses (VariantsPca.scala:239):
+    decimal for 1e-3 <= |d| < 1e7, otherwise computerised scientific notation (1.0E-4)."""
+    d = float(d)
+    if d != d:
+        return "NaN"
+    if d in (float("inf"), float("-inf")):
+        return "Infinity" if d > 0 else "-Infinity"
+    if d == 0.0:
+        return "-0.0" if str(d).startswith("-") else "0.0"
+    r = repr(abs(d))
+    mant, _, exp = r.partition("e")
+    e10 = int(exp) if exp else 0
+    ip, _, fp = mant.partition(".")
+    digits = (ip + fp).lstrip("0")
+    # decimal exponent of the first significant digit
+    if ip.strip("0"):
+        e10 += len(ip.lstrip("0")) - 1
+    else:
+        e10 -= len(fp) - len(fp.lstrip("0")) + 1
+    digits = digits.rstrip("0") or "0"
+    sign = "-" if d < 0 else ""
+    if 1e-3 <= abs(d) < 1e7:
+        if e10 >= 0:
+            whole = digits[:e10 + 1].ljust(e10 + 1, "0")
+            frac = digits[e10 + 1:] or "0"
+        else:
+            whole = "0"
+            frac = "0" * (-e10 - 1) + digits
+        return "%s%s.%s" % (sign, whole, frac)
+    return "%s%s.%sE%d" % (sign, digits[0], digits[1:] or "0", e10)
+
+
+# --------------------------------------------------------------------------------------------- driver
+class VariantsPcaDriver(object):
+    """class VariantsPcaDriver (VariantsPca.scala:81-286) over a local dataset.
+
+    indexes: callset id -> 0..N-1 in callset-list order, names: callset id -> name
+    (VariantsCommon.scala:44-47; the ordering rule is preserved)."""
+
+    def __init__(self, conf, indexes, names, data):
+        self.conf = conf
+        self.indexes = dict(indexes)
+        self.names = dict(names)
+        self.data = data  # list of datasets, each a list of variant dicts (or ('csr', idx, offs))
+        print("Matrix size: %d." % len(self.indexes))  # VariantsCommon.scala:48
+        self.engine = None
+
+    # filterDataset, VariantsPca.scala:96-108
+    def filterDataset(self, data):
+        maf = self.conf.minAlleleFrequency
+        if maf is None or isinstance(data, tuple):
+            return data
+        print("Min allele frequency %s." % java_double_to_string(np.float32(maf)))
+        out = []
+        for variant in data:
+            af = (variant.get("info") or {}).get("AF")
+            if af is not None and len(af) > 0 and np.float32(af[0]) >= np.float32(maf):
+                out.append(variant)
+        return out
+
+    # getCallsRdd, VariantsPca.scala:153-168 (single-dataset branch; join/merge are SURVEY 8f "next")
+    def getCallsRdd(self, data):
+        if len(data) != 1:
+            raise NotImplementedError("multi-dataset join/merge (VariantsPca.scala:115-148) is not on the hot path yet")
+        d = data[0]
+        if isinstance(d, tuple):
+            return (d[1], d[2])
+        return prepare_call_data(d, self.indexes)
+
+    # getSimilarityMatrix, VariantsPca.scala:182-191
+    def getSimilarityMatrix(self, callsets):
+        self.engine = calculate_similarity_matrix(callsets, len(self.indexes), device=self.conf.gpu)
+        return self.engine
+
+    # computePca, VariantsPca.scala:198-231
+    def computePca(self, sim_matrix):
+        n = len(self.indexes)
+        comps, _, nonzero = sim_matrix.compute(self.conf.numPc)
+        print("Non zero rows in matrix: %d / %d." % (nonzero, n))  # :208
+        if comps.shape[1] < 2:
+            # the reference indexes array(i + pca.numRows) unconditionally (:230) and fails for --num-pc 1
+            raise IndexError("computePca emits exactly PC1 and PC2 (VariantsPca.scala:229-230); --num-pc must be >= 2")
+        reverse = dict((v, k) for (k, v) in self.indexes.items())
+        return [(reverse[i], float(comps[i, 0]), float(comps[i, 1])) for i in range(n)]
+
+    # emitResult, VariantsPca.scala:233-246
+    def emitResult(self, result, out=None):
+        out = out or sys.stdout
+        rows = []
+        for (callset_id, pc1, pc2) in result:
+            dataset = callset_id.split("-")[0]
+            rows.append((self.names[callset_id], pc1, pc2, dataset))
+        rows.sort(key=lambda t: t[0])
+        for (name, pc1, pc2, dataset) in rows:
+            out.write("%s\t%s\t%s\t%s\n" % (name, dataset, java_double_to_string(pc1), java_double_to_string(pc2)))
+        if self.conf.outputPath:
+            with open(self.conf.outputPath + "-pca.tsv", "w") as f:
+                for (name, pc1, pc2, dataset) in rows:
+                    f.write("%s\t%s\t%s\t%s\n" % (name, java_double_to_string(pc1), java_double_to_string(pc2), dataset))
+
+    def reportIoStats(self, out=None):
+        out = out or sys.stdout
+        if self.engine is not None:
+            t = self.engine.timings()
+            out.write("Variants accumulated: %d; Gram kernel %.3f ms; PCoA %.3f ms\n" %
+                      (t["gram_variants"], 1e3 * t["gram_kernel_seconds"], 1e3 * t["compute_total_seconds"]))
+
+    def stop(self):
+        if self.engine is not None:
+            self.engine.close()
+            self.engine = None
+
+
+def load_dataset(conf):
+    """Local stand-in for VariantsCommon (VariantsCommon.scala:33-66): callset index/name maps +
+    the variant data.  Returns (indexes, names, [dataset])."""
+    from . import ingest
+    if conf.synthetic:
+        return ingest.synthetic_dataset(conf.synthetic)
+    if not conf.inputPath:
+        raise SystemExit("--input-path (local .npz or .vcf[.gz]) or --synthetic V,N,seed is required: "
+                         "the Google Genomics API the reference read from has been shut down")
+    if conf.inputPath.endswith(".npz"):
+        return ingest.load_npz(conf.inputPath)
+    return ingest.load_vcf(conf.inputPath, conf.references if not conf.all_references else None)
+
+
+def main(args):
+    """VariantsPcaDriver.main (VariantsPca.scala:38-50)."""
+    conf = PcaConf(args)
+    indexes, names, data = load_dataset(conf)
+    driver = VariantsPcaDriver(conf, indexes, names, data)
+    filtered = [driver.filterDataset(d) for d in driver.data]
+    calls_rdd = driver.getCallsRdd(filtered)
+    sim_matrix = driver.getSimilarityMatrix(calls_rdd)
+    result = driver.computePca(sim_matrix)
+    driver.emitResult(result)
+    driver.reportIoStats(sys.stderr)
+    driver.stop()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))

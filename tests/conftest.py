@@ -1,0 +1,67 @@
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")
+
+
+def load_pkg(sub=None):
+    """The package directory is 'spark-examples_amd' (hyphen) -> importlib."""
+    name = "spark-examples_amd" + ("." + sub if sub else "")
+    return importlib.import_module(name)
+
+
+def load_oracle():
+    """oracle/ is test infrastructure: imported by tests only."""
+    odir = os.path.join(ROOT, "oracle")
+    if odir not in sys.path:
+        sys.path.insert(0, odir)
+    return importlib.import_module("variants_pca_oracle")
+
+
+def golden_cases():
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    return load_oracle()
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return load_pkg()
+
+
+def align_sign(v, ref):
+    """Eigenvectors are defined up to sign: flip columns of v to match ref."""
+    v = np.array(v, dtype=np.float64, copy=True)
+    for c in range(v.shape[1]):
+        if np.dot(v[:, c], ref[:, c]) < 0:
+            v[:, c] = -v[:, c]
+    return v
+
+
+def planted_callsets(rng, n, v, k=3, hi=0.5, lo=0.05):
+    """Random carrier lists with planted population structure (clear spectral gaps)."""
+    pops = np.sort(rng.integers(0, k, size=n))
+    x = np.zeros((v, n), dtype=np.float32)
+    for row in range(v):
+        which = rng.integers(0, k + 1)
+        p = np.where(pops == which, hi, lo) if which < k else np.full(n, rng.uniform(0.02, 0.4))
+        x[row] = rng.random(n) < p
+    return x

@@ -1,0 +1,381 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle on the same inputs.
+
+Bars (BASELINE.json north_star): Gram bit-exact (integers); centred matrix bit-exact (fp64, same
+operation order); sign-normalised eigenpairs within 1e-6 relative.
+"""
+import io
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, align_sign, golden_cases, load_golden, load_oracle, load_pkg, planted_callsets
+
+pytestmark = pytest.mark.gpu
+
+EIG_TOL = 1e-6  # north_star: 1e-6 relative on sign-normalised eigenpairs
+
+
+@pytest.fixture(scope="module")
+def P():
+    return load_pkg()
+
+
+@pytest.fixture(scope="module")
+def O():
+    return load_oracle()
+
+
+def callsets_of(x):
+    return [list(np.nonzero(r)[0]) for r in x]
+
+
+# ------------------------------------------------------------------------------------------ Gram
+@pytest.mark.parametrize("name", golden_cases())
+def test_gram_and_centering_match_reference_python_goldens(P, name):
+    g = load_golden(name)
+    n = int(g["n_samples"])
+    with P.PcoaEngine(n) as eng:
+        eng.accumulate_calls(g["sample_idx"], g["row_offsets"])
+        eng.finalize()
+        assert np.array_equal(eng.gram(), g["similarity"])
+        b, rs, nz, mm = eng.center()
+        assert np.array_equal(b, g["centered"])  # bit for bit
+        assert np.array_equal(rs, g["similarity"].sum(axis=1).astype(np.float64))
+        assert nz == int((g["similarity"].sum(axis=1) > 0).sum())
+
+
+def test_known_answer_survey_8c(P):
+    callsets = [[0, 1], [0, 1, 2], [3, 4], [2, 3, 4], [0], [1, 4]]
+    with P.PcoaEngine(5) as eng:
+        eng.accumulate_callsets(callsets)
+        s = eng.gram()
+        assert s.tolist() == [[3, 2, 1, 0, 0], [2, 3, 1, 0, 1], [1, 1, 2, 1, 1], [0, 0, 1, 2, 2], [0, 1, 1, 2, 3]]
+        comps, lam, nz = eng.compute(2)
+    assert nz == 5
+    assert np.allclose(lam, [4.291279249547, 1.505156222449], rtol=0, atol=1e-11)
+    pc1 = [0.578932130782, 0.427318800977, -0.024951663211, -0.482297462206, -0.499001806342]
+    pc2 = [-0.290911908486, 0.610085542084, -0.521742006736, -0.252576095428, 0.455144468566]
+    assert np.allclose(comps[:, 0], pc1, atol=1e-11) and np.allclose(comps[:, 1], pc2, atol=1e-11)
+
+
+@pytest.mark.parametrize("n,v", [(1, 1), (2, 3), (3, 17), (5, 16), (63, 100), (64, 15), (65, 33), (127, 1),
+                                 (128, 64), (129, 257), (200, 1000), (257, 129), (384, 2048), (777, 300)])
+def test_gram_dense_csr_oracle_agree_on_ragged_shapes(P, O, n, v):
+    rng = np.random.default_rng(1000 * n + v)
+    x = (rng.random((v, n)) < rng.uniform(0.05, 0.5)).astype(np.float32)
+    want = O.similarity_from_dense(x, n)
+    with P.PcoaEngine(n) as eng:
+        eng.accumulate_dense(x)               # host tile; ld = n (vec4 path iff n % 4 == 0 after staging)
+        got_dense = eng.gram()
+        eng.reset()
+        eng.accumulate_callsets(callsets_of(x))
+        got_csr = eng.gram()
+    assert np.array_equal(got_dense, want)
+    assert np.array_equal(got_csr, want)
+
+
+def test_gram_device_pointer_paths_and_padding_is_ignored(P, O):
+    import torch
+    rng = np.random.default_rng(3)
+    n, v = 300, 500
+    x = (rng.random((v, n)) < 0.3).astype(np.float32)
+    want = O.similarity_from_dense(x, n)
+    for ld in (300, 301, 303, 304, 320):  # ld % 4 != 0 -> 4-byte DMA kernel; padding holds NaN
+        buf = torch.full((v, ld), float("nan"), dtype=torch.float32, device="cuda")
+        buf[:, :n] = torch.from_numpy(x).cuda()
+        with P.PcoaEngine(n) as eng:
+            eng.accumulate_dense(buf)
+            assert np.array_equal(eng.gram(), want), "ld=%d" % ld
+    # misaligned base pointer (4-byte aligned only)
+    flat = torch.zeros(v * 304 + 1, dtype=torch.float32, device="cuda")
+    view = flat[1:].view(v, 304)
+    view[:, :n] = torch.from_numpy(x).cuda()
+    with P.PcoaEngine(n) as eng:
+        eng.accumulate_dense(view)
+        assert np.array_equal(eng.gram(), want)
+
+
+def test_repeated_indices_count_with_multiplicity_like_the_reference_double_loop(P, O):
+    callsets = [[0, 0, 1], [2], [1, 2, 2, 2]]
+    want = O.similarity_matrix_python_loops(callsets, 4)
+    assert want[0, 0] == 4 and want[2, 2] == 10
+    with P.PcoaEngine(4) as eng:
+        eng.accumulate_callsets(callsets)
+        assert np.array_equal(eng.gram(), want)
+
+
+def test_empty_and_ragged_inputs(P):
+    with P.PcoaEngine(7) as eng:
+        eng.accumulate_calls(np.zeros(0, dtype=np.int32), np.zeros(1, dtype=np.int64))       # no variants
+        eng.accumulate_calls(np.zeros(0, dtype=np.int32), np.zeros(4, dtype=np.int64))       # 3 empty rows
+        eng.accumulate_dense(np.zeros((0, 7), dtype=np.float32))
+        assert not eng.gram().any()
+        eng.accumulate_callsets([[], [6], [], [0, 6]])
+        s = eng.gram()
+        assert s[6, 6] == 2 and s[0, 6] == 1 and s[6, 0] == 1 and s[0, 0] == 1 and s.sum() == 5
+
+
+def test_index_out_of_range_is_rejected_and_leaves_s_unchanged(P):
+    with P.PcoaEngine(5) as eng:
+        eng.accumulate_callsets([[0, 1]])
+        before = eng.gram()
+        for bad in ([[0, 5]], [[-1]], [[1], [2, 7]]):
+            with pytest.raises(P.IndexRangeError):
+                eng.accumulate_callsets(bad)
+        assert np.array_equal(eng.gram(), before)
+        with pytest.raises(P.PcoaError):
+            eng.compute(0)
+        with pytest.raises(P.PcoaError):
+            eng.compute(6)  # MLlib: require(k > 0 && k <= n)
+
+
+def test_accumulation_is_additive_shard_invariant_and_resumable(P, O):
+    rng = np.random.default_rng(11)
+    n, v = 150, 900
+    x = (rng.random((v, n)) < 0.2).astype(np.float32)
+    want = O.similarity_from_dense(x, n)
+    with P.PcoaEngine(n) as eng:
+        for lo, hi in ((0, 1), (1, 400), (400, 401), (401, 900)):
+            eng.accumulate_dense(x[lo:hi])
+        assert np.array_equal(eng.gram(), want)       # finalize, then keep accumulating
+        eng.accumulate_dense(x[:100])
+        want2 = want + O.similarity_from_dense(x[:100], n)
+        assert np.array_equal(eng.gram(), want2)
+        # checkpoint / resume: load S into a fresh engine and continue
+        with P.PcoaEngine(n) as eng2:
+            eng2.load_gram(want)
+            eng2.accumulate_dense(x[:100])
+            assert np.array_equal(eng2.gram(), want2)
+
+
+def test_multi_launch_and_int64_fold_paths(P, O):
+    rng = np.random.default_rng(12)
+    n, v = 90, 700
+    x = (rng.random((v, n)) < 0.4).astype(np.float32)
+    want = O.similarity_from_dense(x, n)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r);"
+            "from conftest import load_pkg; P = load_pkg(); x = np.load(sys.argv[1]);"
+            "e = P.PcoaEngine(x.shape[1]); e.accumulate_dense(x); e.accumulate_dense(x[:50]);"
+            "np.save(sys.argv[2], e.gram())") % (ROOT, os.path.join(ROOT, "tests"))
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        np.save(os.path.join(td, "x.npy"), x)
+        env = dict(os.environ, PCOA_DEBUG_MAX_LAUNCH="64", PCOA_DEBUG_FOLD_THRESHOLD="200")
+        subprocess.check_call([sys.executable, "-c", code, os.path.join(td, "x.npy"), os.path.join(td, "s.npy")],
+                              env=env)
+        got = np.load(os.path.join(td, "s.npy"))
+    assert np.array_equal(got, want + O.similarity_from_dense(x[:50], n))
+
+
+def test_synthetic_device_generator_is_bit_identical_to_host_twin(P, O):
+    import torch
+    synth = load_pkg("synth")
+    n, v, seed = 2504, 4096, 1002
+    offs = synth.pop_offsets(n)
+    thr = synth.thresholds(seed, 1000, v)
+    x_host = synth.genotypes(seed, 1000, thr, offs)
+    buf = torch.empty((v, n), dtype=torch.float32, device="cuda")
+    with P.PcoaEngine(n) as eng:
+        eng.synth_fill(seed, offs, thr, 1000, buf.data_ptr(), n)
+        assert np.array_equal(buf.cpu().numpy(), x_host)
+        eng.accumulate_synthetic(seed, offs, thr, 1000)
+        s_synth = eng.gram()
+        eng.reset()
+        eng.accumulate_dense(buf)
+        s_dense = eng.gram()
+    want = O.similarity_from_dense_blas(x_host)
+    assert np.array_equal(s_synth, want) and np.array_equal(s_dense, want)
+
+
+def test_config2_shape_against_faithful_pair_loop(P, O):
+    """N = 2504 (the BASELINE configs[1] sample count), 20k variants: HIP vs the faithful pair loop."""
+    synth = load_pkg("synth")
+    n, v, seed = 2504, 20000, 1002
+    offs = synth.pop_offsets(n)
+    thr = synth.thresholds(seed, 0, v)
+    x = synth.genotypes(seed, 0, thr, offs)
+    want = O.similarity_from_dense(x, n)
+    with P.PcoaEngine(n) as eng:
+        eng.accumulate_synthetic(seed, offs, thr, 0)
+        got = eng.gram()
+    assert np.array_equal(got, want)
+
+
+def test_full_config2_size_properties(P):
+    """BASELINE configs[1] at full size (2,504 samples x 1M variants fp32, 10 GB resident):
+    size-independent properties -- diagonal = column popcounts, symmetry, checksum
+    sum(S) = sum_v k_v^2, and split invariance (two half calls == one call)."""
+    import torch
+    synth = load_pkg("synth")
+    n, v, seed = 2504, 1000000, 1002
+    offs = synth.pop_offsets(n)
+    x = torch.empty((v, n), dtype=torch.float32, device="cuda")
+    with P.PcoaEngine(n) as eng:
+        step = 1 << 18
+        for v0 in range(0, v, step):
+            v1 = min(v, v0 + step)
+            eng.synth_fill(seed, offs, synth.thresholds(seed, v0, v1 - v0), v0, x[v0:v1].data_ptr(), n)
+        eng.accumulate_dense(x)
+        s = eng.gram()
+        col = x.sum(dim=0, dtype=torch.float64).cpu().numpy().astype(np.int64)
+        kv = x.sum(dim=1, dtype=torch.float64)
+        checksum = int((kv * kv).sum().item())
+        assert np.array_equal(np.diag(s), col)
+        assert np.array_equal(s, s.T)
+        assert int(s.sum()) == checksum
+        eng.reset()
+        eng.accumulate_dense(x[:400001])
+        eng.accumulate_dense(x[400001:])
+        assert np.array_equal(eng.gram(), s)
+
+
+# ------------------------------------------------------------------------------------------ PCA
+def check_eigenpairs(comps, lam, ref_comps, ref_lam, b):
+    n = b.shape[0]
+    assert np.allclose(lam, ref_lam, rtol=EIG_TOL, atol=0)
+    c = align_sign(comps, ref_comps)
+    for k in range(c.shape[1]):
+        assert abs(np.linalg.norm(c[:, k]) - 1.0) < 1e-12
+        assert np.linalg.norm(c[:, k] - ref_comps[:, k]) <= EIG_TOL, "PC%d" % (k + 1)
+        resid = np.linalg.norm(b @ c[:, k] - lam[k] * c[:, k]) / abs(lam[k])
+        assert resid < 1e-10
+    assert np.abs(c.T @ c - np.eye(c.shape[1])).max() < 1e-10
+
+
+@pytest.mark.parametrize("n,v,k", [(6, 40, 2), (40, 300, 2), (64, 500, 3), (129, 800, 2), (500, 3000, 4)])
+def test_compute_pca_matches_oracle(P, O, n, v, k):
+    rng = np.random.default_rng(n * 31 + v)
+    x = planted_callsets(rng, n, v, k=max(3, k + 1))
+    s = O.similarity_from_dense(x, n)
+    ref = O.compute_pca(s, k)
+    with P.PcoaEngine(n) as eng:
+        eng.accumulate_dense(x)
+        comps, lam, nz = eng.compute(k)
+    assert nz == ref["nonzero_rows"]
+    check_eigenpairs(comps, lam, ref["components"], ref["eigenvalues"], ref["B"])
+    # library output is sign-normalised exactly like the oracle's convention
+    for c in range(k):
+        i = int(np.argmax(np.abs(comps[:, c])))
+        assert comps[i, c] > 0
+
+
+def test_compute_pca_config2_sample_count(P, O):
+    """N = 2504 with planted 5-population structure: eigenpairs vs the MLlib-path oracle (dgesdd)."""
+    synth = load_pkg("synth")
+    n, v, seed = 2504, 30000, 1002
+    offs = synth.pop_offsets(n)
+    thr = synth.thresholds(seed, 0, v)
+    x = synth.genotypes(seed, 0, thr, offs)
+    s = O.similarity_from_dense_blas(x)
+    ref = O.compute_pca(s, 2)
+    with P.PcoaEngine(n) as eng:
+        eng.accumulate_synthetic(seed, offs, thr, 0)
+        assert np.array_equal(eng.gram(), s)
+        b, _, _, _ = eng.center()
+        assert np.array_equal(b, ref["B"])
+        comps, lam, nz = eng.compute(2)
+        t = eng.timings()
+    check_eigenpairs(comps, lam, ref["components"], ref["eigenvalues"], ref["B"])
+    assert nz == ref["nonzero_rows"]
+    print("PCoA wall %.1f ms (tridiag %.1f, eig %.1f, back %.1f)" %
+          (1e3 * t["compute_total_seconds"], 1e3 * t["tridiag_seconds"], 1e3 * t["eig_seconds"],
+           1e3 * t["backtransform_seconds"]))
+
+
+def test_compute_from_loaded_matrix_entries_and_degenerate_inputs(P, O):
+    # computePca(matrixEntries) boundary: S produced elsewhere
+    rng = np.random.default_rng(21)
+    x = planted_callsets(rng, 33, 200)
+    s = O.similarity_from_dense(x, 33)
+    ref = O.compute_pca(s, 2)
+    with P.PcoaEngine(33) as eng:
+        eng.load_gram(s)
+        comps, lam, _ = eng.compute(2)
+    check_eigenpairs(comps, lam, ref["components"], ref["eigenvalues"], ref["B"])
+    # all-zero S (no variants): B = 0, every eigenvalue 0, vectors still unit-norm and finite
+    with P.PcoaEngine(10) as eng:
+        comps, lam, nz = eng.compute(2)
+    assert nz == 0 and np.allclose(lam, 0) and np.isfinite(comps).all()
+    assert np.allclose(np.linalg.norm(comps, axis=0), 1.0)
+    # N = 1 and N = 2
+    with P.PcoaEngine(1) as eng:
+        eng.accumulate_callsets([[0]])
+        comps, lam, nz = eng.compute(1)
+    assert comps.shape == (1, 1) and abs(abs(comps[0, 0]) - 1) < 1e-15 and abs(lam[0]) < 1e-290 and nz == 1
+    with P.PcoaEngine(2) as eng:
+        eng.accumulate_callsets([[0], [0, 1], [0]])
+        comps, lam, _ = eng.compute(2)
+    ref = O.compute_pca(np.array([[3, 1], [1, 1]]), 2)
+    assert np.allclose(lam, ref["eigenvalues"], atol=1e-12)
+    assert np.abs(align_sign(comps, ref["components"])[:, 0] - ref["components"][:, 0]).max() < 1e-12
+
+
+# ------------------------------------------------------------------------------------------ multi-GPU plumbing
+def test_native_rccl_allreduce_single_rank(P, O):
+    rng = np.random.default_rng(4)
+    x = (rng.random((100, 50)) < 0.3).astype(np.float32)
+    want = O.similarity_from_dense(x, 50)
+    with P.PcoaEngine(50) as eng:
+        eng.accumulate_dense(x)
+        comm = eng.comm_init(eng.comm_unique_id(), 0, 1)
+        eng.allreduce_rccl(comm)
+        assert np.array_equal(eng.gram(), want)
+        eng.accumulate_dense(x)                     # keeps accumulating after the reduce
+        assert np.array_equal(eng.gram(), 2 * want)
+        eng.comm_destroy(comm)
+
+
+def test_torch_distributed_rccl_allreduce_single_rank(P, O):
+    import torch
+    import torch.distributed as td
+    dist = load_pkg("dist")
+    rng = np.random.default_rng(6)
+    x = (rng.random((80, 40)) < 0.3).astype(np.float32)
+    want = O.similarity_from_dense(x, 40)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    td.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        with P.PcoaEngine(40) as eng:
+            eng.accumulate_dense(x)
+            scratch = torch.empty((40, 40), dtype=torch.int64, device="cuda")
+            # world size 1 short-circuits; exercise the export -> all_reduce -> import path explicitly
+            eng.export_device(scratch.data_ptr())
+            eng.sync()
+            td.all_reduce(scratch)
+            torch.cuda.synchronize()
+            assert np.array_equal(scratch.cpu().numpy(), want)
+            eng.import_device(scratch.data_ptr())
+            assert np.array_equal(eng.gram(), want)
+            assert dist.allreduce_engine(eng) is None
+    finally:
+        td.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------ driver
+def test_driver_main_end_to_end(P, O, tmp_path, capsys):
+    vp = load_pkg("variants_pca")
+    g = load_golden("pops40")
+    ids = [str(s) for s in g["callset_ids"]]
+    names = ["NA%05d" % (40 - i) for i in range(40)]
+    path = str(tmp_path / "pops40_input.npz")
+    np.savez(path, callset_ids=np.array(ids), callset_names=np.array(names), sample_idx=g["sample_idx"],
+             row_offsets=g["row_offsets"])
+    rc = vp.main(["--input-path", path, "--output-path", str(tmp_path / "res"), "--spark-master", "local[4]"])
+    assert rc == 0
+    out = capsys.readouterr().out.splitlines()
+    assert out[0] == "Matrix size: 40."
+    assert out[1] == "Non zero rows in matrix: 40 / 40."
+    rows = [l.split("\t") for l in out[2:]]
+    assert len(rows) == 40 and [r[0] for r in rows] == sorted(names)
+    ref = O.compute_pca(g["similarity"], 2)
+    by_name = dict((r[0], r) for r in rows)
+    got = np.array([[float(by_name[names[i]][2]), float(by_name[names[i]][3])] for i in range(40)])
+    assert np.abs(align_sign(got, ref["components"]) - ref["components"]).max() < EIG_TOL
+    assert by_name[names[0]][1] == ids[0].split("-")[0]
+    saved = open(str(tmp_path / "res") + "-pca.tsv").read().splitlines()
+    assert len(saved) == 40 and saved[0].split("\t")[0] == sorted(names)[0]

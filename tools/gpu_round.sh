@@ -1,0 +1,44 @@
+#!/bin/bash
+# One gpurun call = smoke + GPU parity tests + bench + rocprofv3 kernel trace.  Every step has its own
+# timeout and log under gpurun_out/ so that one failure does not hide the others.
+# usage: tools/gpu_round.sh <tag> [steps...]   steps default: smoke tests bench prof
+set +e
+TAG=${1:-r01}; shift
+STEPS=${@:-smoke tests bench prof}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+echo "== $(date) on $(hostname); steps: $STEPS" | tee $OUT/summary.txt
+rocm-smi --showproductname 2>/dev/null | head -8 >> $OUT/summary.txt
+nproc >> $OUT/summary.txt
+for s in $STEPS; do
+  case $s in
+    smoke)
+      timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
+      echo "smoke exit $?" | tee -a $OUT/summary.txt; tail -3 $OUT/smoke.log | tee -a $OUT/summary.txt ;;
+    tests)
+      timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 600 -rA > $OUT/tests.log 2>&1
+      echo "tests exit $?" | tee -a $OUT/summary.txt; grep -E "passed|failed|error" $OUT/tests.log | tail -3 | tee -a $OUT/summary.txt
+      grep -E "^(FAILED|ERROR)|PCoA wall" $OUT/tests.log | head -40 | tee -a $OUT/summary.txt ;;
+    bench)
+      timeout 900 python bench.py --gpus 1 --steps 5 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
+      echo "bench exit $?" | tee -a $OUT/summary.txt; cat $OUT/bench.json | tee -a $OUT/summary.txt; tail -5 $OUT/bench.err ;;
+    prof)
+      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o trace -- python $OLDPWD/bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline > $OLDPWD/$OUT/prof_bench.json 2> $OLDPWD/$OUT/prof.err )
+      echo "prof exit $?" | tee -a $OUT/summary.txt
+      find $OUT/prof -name "*kernel_stats*" | head -3 | while read f; do echo "--- $f"; head -25 "$f"; done | tee -a $OUT/summary.txt
+      # keep the merge-back small: drop the raw per-dispatch trace if it is large
+      find $OUT/prof -name "*kernel_trace*" -size +8M -delete ;;
+    pmc)
+      ( cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE -d $OLDPWD/$OUT/pmc_fetch -o pmc -- python $OLDPWD/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --pcoa-reps 1 > /dev/null 2> $OLDPWD/$OUT/pmc_fetch.err )
+      echo "pmc fetch exit $?" | tee -a $OUT/summary.txt
+      ( cd /tmp && timeout 900 rocprofv3 --pmc WRITE_SIZE -d $OLDPWD/$OUT/pmc_write -o pmc -- python $OLDPWD/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --pcoa-reps 1 > /dev/null 2> $OLDPWD/$OUT/pmc_write.err )
+      echo "pmc write exit $?" | tee -a $OUT/summary.txt
+      ( cd /tmp && timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT -d $OLDPWD/$OUT/pmc_sq -o pmc -- python $OLDPWD/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --pcoa-reps 1 > /dev/null 2> $OLDPWD/$OUT/pmc_sq.err )
+      echo "pmc sq exit $?" | tee -a $OUT/summary.txt
+      python tools/pmc_summary.py $OUT | tee -a $OUT/summary.txt
+      find $OUT -name "*counter_collection*" -size +4M -delete ;;
+  esac
+done
+echo "== done $(date)" | tee -a $OUT/summary.txt
