@@ -252,7 +252,7 @@ int ensure_workspace(pcoa_ctx* c, int32_t k) {
     HIP_TRY(c, hipMalloc((void**)&c->ws.q, sizeof(double) * (size_t)n));
     HIP_TRY(c, hipMalloc((void**)&c->ws.w, sizeof(double) * (size_t)(2 * n)));
     HIP_TRY(c, hipMalloc((void**)&c->ws.scratch, sizeof(double) * (size_t)(6 * n)));
-    HIP_TRY(c, hipMalloc((void**)&c->ws.iscratch, sizeof(int32_t) * (size_t)std::max<int64_t>(n, 64)));
+    HIP_TRY(c, hipMalloc((void**)&c->ws.iscratch, sizeof(int32_t) * (size_t)(2 * n + 64)));
     HIP_TRY(c, hipMalloc((void**)&c->ws.status, sizeof(int32_t) * 4));
     HIP_TRY(c, hipMalloc((void**)&c->row_sums, sizeof(double) * (size_t)n));
     HIP_TRY(c, hipMalloc((void**)&c->stats, sizeof(double) * (size_t)(2 + n)));
