@@ -310,7 +310,9 @@ def test_compute_from_loaded_matrix_entries_and_degenerate_inputs(P, O):
         eng.accumulate_callsets([[0], [0, 1], [0]])
         comps, lam, _ = eng.compute(2)
     ref = O.compute_pca(np.array([[3, 1], [1, 1]]), 2)
-    assert np.allclose(lam, ref["eigenvalues"], atol=1e-12)
+    # the oracle recovers |lambda| as sqrt(s * (N-1)) from the SVD of Cov, which amplifies the
+    # rounding of the zero eigenvalue to ~1e-9; compare it loosely and the non-zero one tightly
+    assert abs(lam[0] - ref["eigenvalues"][0]) < 1e-12 and abs(lam[1]) < 1e-7
     assert np.abs(align_sign(comps, ref["components"])[:, 0] - ref["components"][:, 0]).max() < 1e-12
 
 
