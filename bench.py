@@ -28,6 +28,8 @@ sys.path.insert(0, ROOT)
 
 METRIC = "variants/sec into N×N Gram + PCoA wall-clock, 2504 samples, 1/2/4/8 GPU"
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 flop/clk/CU
+PEAK_I8_MFMA_TOPS = 5000.0      # MI355X_MICROARCH.md: i8 MFMA ~2x the bf16 rate (~2.5 PF dense) => ~5 POP/s dense
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 N_SAMPLES = 2504
 SEED = 1002                     # seed of configs[1]
 
@@ -42,8 +44,9 @@ def cpu_baseline(x_dev, n, budget_s=12.0):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     oracle = importlib.import_module("variants_pca_oracle")
     cores = oracle.num_threads()
-    probe = min(2048, x_dev.shape[0])
+    probe = min(8192, x_dev.shape[0])
     xs = x_dev[:probe].cpu().numpy()
+    oracle.similarity_from_dense(xs[:512], n)  # thread pool + page warm-up
     t0 = time.perf_counter()
     oracle.similarity_from_dense(xs, n)
     dt = max(time.perf_counter() - t0, 1e-4)
@@ -72,6 +75,8 @@ def main():
     ap.add_argument("--samples", type=int, default=N_SAMPLES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pcoa-reps", type=int, default=3)
+    ap.add_argument("--gram-kernel", choices=["i8", "f32"], default="i8",
+                    help="i8: pack fp32->int8 + v_mfma_i32_32x32x32_i8 (default); f32: v_mfma_f32_32x32x2_f32")
     args = ap.parse_args()
 
     import torch
@@ -93,7 +98,7 @@ def main():
     dist = pkg("dist")
     synth = pkg("synth")
     n, v = args.samples, args.variants
-    eng = P.PcoaEngine(n, device=local_rank)
+    eng = P.PcoaEngine(n, device=local_rank, gram_kernel=args.gram_kernel)
     dev_name, cus = eng.device_info()
 
     # ---- resident input: this rank's shard of the cohort, generated on device --------------------------
@@ -147,13 +152,41 @@ def main():
         kern_s = tim["gram_kernel_seconds"] / launches           # average Gram-kernel launch duration (HIP events)
         flops_per_launch = 2.0 * (tim["gram_variants"] / launches) * n * n   # algorithmic 2*V*N^2
         achieved = flops_per_launch / kern_s / 1e12 if kern_s > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "gram_pmc_latest.json")
-        if os.path.exists(pmc):
+        pmc = {}
+        pmc_path = os.path.join(ROOT, "profiles", "gram_pmc_latest.json")
+        if os.path.exists(pmc_path):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                pmc = json.load(open(pmc_path)).get(args.gram_kernel, {})
             except Exception:
-                traffic = None
+                pmc = {}
+        if args.gram_kernel == "i8":
+            tile, peak, kname = 256, PEAK_I8_MFMA_TOPS, "gram_i8_kernel"
+            kdesc = "pack fp32->k-blocked int8 (HBM-bound) + i8 MFMA v_mfma_i32_32x32x32_i8, upper-triangular 256x256 tiles, split-K, int32 accumulators"
+        else:
+            tile, peak, kname = 128, PEAK_FP32_MFMA_TFLOPS, "gram_f32_kernel"
+            kdesc = "fp32 MFMA v_mfma_f32_32x32x2_f32, upper-triangular 128x128 tiles, split-K"
+        frac_syrk = syrk_fraction(n, tile)
+        roof_gram = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                     "frac": achieved / peak, "traffic": pmc.get("gram_hbm_bytes_per_launch"),
+                     "kernel": kname, "avg_launch_ms": 1e3 * kern_s, "launches": launches,
+                     "flops_convention": "algorithmic 2*V*N^2 per launch (integer MACs count 2 ops); the kernel "
+                                         "issues the SYRK half (upper-triangular tiles only: %.3f of the MFMA work)"
+                                         % frac_syrk,
+                     "issued_tflops": achieved * frac_syrk, "issued_frac": achieved * frac_syrk / peak}
+        roof_pack = None
+        if args.gram_kernel == "i8" and tim["pack_launches"] > 0:
+            pl = int(tim["pack_launches"])
+            pack_s = tim["pack_seconds"] / pl
+            pack_gbs = tim["pack_bytes"] / pl / pack_s / 1e9 if pack_s > 0 else 0.0
+            roof_pack = {"bound": "hbm", "achieved": pack_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": pack_gbs / PEAK_HBM_GBS, "traffic": pmc.get("pack_hbm_bytes_per_launch"),
+                         "kernel": "pack_f32_i8_kernel", "avg_launch_ms": 1e3 * pack_s, "launches": pl,
+                         "bytes_convention": "algorithmic 4*V*N read + V*Npad written per launch"}
+        # the dominant kernel (larger share of the step) goes into `roofline`, the other into `roofline_other`
+        if roof_pack is not None and tim["pack_seconds"] > tim["gram_kernel_seconds"]:
+            roofline, roofline_other = roof_pack, roof_gram
+        else:
+            roofline, roofline_other = roof_gram, roof_pack
         # PCoA wall-clock on rank 0 (S of the last step is in place)
         pcoa = []
         for _ in range(max(args.pcoa_reps, 1)):
@@ -164,18 +197,15 @@ def main():
         out = {
             "metric": METRIC, "value": value, "unit": "variants/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "i8->i32" if args.gram_kernel == "i8" else "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: synthetic %d samples x %d variants fp32 per GPU, resident in HBM "
                                    "(Gram + eig on rank 0)" % (n, v),
                        "n_samples": n, "variants_per_gpu": v, "seed": SEED, "parallelism": "variant-sharded x%d" % world,
-                       "gram_kernel": "fp32 MFMA v_mfma_f32_32x32x2_f32, upper-triangular 128x128 tiles, split-K"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                         "kernel": "gram_f32_kernel", "avg_launch_ms": 1e3 * kern_s,
-                         "flops_convention": "algorithmic 2*V*N^2 per launch; the kernel issues the SYRK half "
-                                             "(upper-triangular tiles only: %.3f of the MFMA work)" %
-                                             (syrk_fraction(n)),
-                         "issued_tflops": achieved * syrk_fraction(n)},
+                       "gram_kernel": kdesc},
+            "roofline": roofline, "roofline_other": roofline_other,
+            "gram_ms_per_step": 1e3 * tim["gram_kernel_seconds"] / steps,
+            "pack_ms_per_step": 1e3 * tim["pack_seconds"] / steps,
+            "finalize_ms_per_step": 1e3 * tim["finalize_seconds"] / steps,
             "pcoa_wall_ms": float(np.median(pcoa)), "pcoa_wall_ms_all": pcoa,
             "pcoa_breakdown_ms": {k: 1e3 * tim2[k] / max(args.pcoa_reps, 1) for k in
                                   ("center_seconds", "tridiag_seconds", "eig_seconds", "backtransform_seconds")},
@@ -199,7 +229,7 @@ def main():
     return 0
 
 
-def syrk_fraction(n, bm=128):
+def syrk_fraction(n, bm):
     t = (n + bm - 1) // bm
     return (t * (t + 1) / 2.0) / float(t * t)
 

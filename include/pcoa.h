@@ -47,9 +47,9 @@ typedef enum pcoa_status {
 } pcoa_status;
 
 /* flags for pcoa_create */
-#define PCOA_FLAG_DEFAULT        0u
-#define PCOA_FLAG_GRAM_F32_MFMA  0x1u  /* force the fp32-MFMA Gram kernel (v_mfma_f32_32x32x2_f32)      */
-#define PCOA_FLAG_GRAM_I8_MFMA   0x2u  /* force the i8-MFMA Gram kernel (v_mfma_i32_32x32x32_i8)        */
+#define PCOA_FLAG_DEFAULT        0u     /* i8-MFMA Gram: tile values must be integers in [0, 127]         */
+#define PCOA_FLAG_GRAM_F32_MFMA  0x1u  /* fp32-MFMA Gram kernel (v_mfma_f32_32x32x2_f32): any small ints */
+#define PCOA_FLAG_GRAM_I8_MFMA   0x2u  /* i8-MFMA Gram kernel (v_mfma_i32_32x32x32_i8), the default      */
 #define PCOA_FLAG_NO_SIGN_NORM   0x10u /* keep the eigensolver's native sign instead of sign-normalising */
 
 /* Per-stage timings, filled by pcoa_get_timings(); times in seconds, measured with HIP events on
@@ -70,6 +70,9 @@ typedef struct pcoa_timings {
   double compute_total_seconds; /* wall of the last pcoa_compute (centring..D2H)                      */
   int32_t gram_kernel_kind;     /* 1 = fp32 MFMA, 2 = i8 MFMA                                        */
   int32_t reserved;
+  double pack_seconds;          /* fp32 -> k-blocked int8 pre-pass of the i8 path (sum of launches)   */
+  int64_t pack_launches;
+  double pack_bytes;            /* algorithmic bytes of the pre-pass: 4*V*N read + V*Npad written     */
 } pcoa_timings;
 
 /* Synthetic genotype model (bench / tests only; not part of the reference).  Sample i belongs to

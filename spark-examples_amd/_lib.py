@@ -42,6 +42,9 @@ class PcoaTimings(ctypes.Structure):
         ("compute_total_seconds", ctypes.c_double),
         ("gram_kernel_kind", ctypes.c_int32),
         ("reserved", ctypes.c_int32),
+        ("pack_seconds", ctypes.c_double),
+        ("pack_launches", ctypes.c_int64),
+        ("pack_bytes", ctypes.c_double),
     ]
 
 

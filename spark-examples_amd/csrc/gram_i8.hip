@@ -1,0 +1,290 @@
+// gram_i8.hip -- S += X^T X on the int8 matrix cores of gfx950 (v_mfma_i32_32x32x32_i8), exact.
+//
+// Same contraction as gram_f32.hip (reference VariantsPca.scala:184-190), computed in the reference's
+// own arithmetic: int32 counts (`DenseMatrix.zeros[Int]`, :185).  Genotype indicators are 0/1 (carrier
+// multiplicities <= 127 are accepted), so int8 operands lose nothing and the int32 accumulators are
+// exact to 2^31 -- but the i8 MFMA runs at 32x the rate of the fp32 MFMA (~5 POP/s dense vs 157 TF/s).
+//
+// Two kernels:
+//
+//  pack_f32_i8_kernel   X fp32 [V][ld]  ->  P int8 [V/16][Npad][16]            (HBM-bound, once per variant)
+//      "k-blocked" layout: the 16 bytes at P[kb][i] are sample i's indicators for variants
+//      16*kb .. 16*kb+15.  That is exactly one lane's operand slice of v_mfma_i32_32x32x32_i8, for the
+//      A operand (row i) and for the B operand (column j) alike -- X^T X uses the same k-slot mapping
+//      on both sides, so any consistent order of the 16 k's inside a block gives the same sum.
+//      Reads 4 B and writes 1 B per genotype: 12.5 GB per 10^6 variants at N = 2504.
+//
+//  gram_i8_kernel       P -> S32 (upper-triangular 256x256 tiles, split-K, integer atomics)
+//      512 threads = 8 waves as 2(M) x 4(N), each wave a 128x64 block = 4x2 MFMA tiles
+//      (128 int32 accumulators per lane).  One stage = 64 variants = 4 k-blocks x 2 panels x 256
+//      samples x 16 B = 32 KiB, brought in by 32 global_load_lds_dwordx4 (1 KiB each, the LDS image IS
+//      the global image), 3-stage ring (96 KiB), ONE raw s_barrier per stage, counted vmcnt (two
+//      stages stay in flight).  Operand reads are ds_read_b128 of 32 consecutive 16-B slots per
+//      half-wave: conflict-free.  MFMA-bound: per stage a wave issues 16 MFMAs (512 cycles) against
+//      12 ds_read_b128 and 4 DMA instructions.
+//
+// Roofline: i8 MFMA, peak ~5 POP/s dense (2x the bf16 rate, MI355X_MICROARCH.md); algorithmic
+// intensity of the packed operands N/0.5 = 5008 op/B, so HBM is irrelevant once packed.
+#include "pcoa_internal.h"
+
+namespace pcoa {
+namespace {
+
+constexpr int TM = 256;        // tile edge in samples
+constexpr int KB = 16;         // variants per k-block (one lane's operand slice)
+constexpr int SKB = 4;         // k-blocks per stage -> 64 variants
+constexpr int NT = 512;        // threads per workgroup (8 waves)
+constexpr int NSTAGE = 3;
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wg_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------------------------- pack
+// One thread: 16 variants x 4 samples.  A wave covers 256 consecutive samples of one k-block, so
+// every load instruction reads 1 KiB contiguous and the wave writes 4 KiB contiguous.
+// flag bit 2 is raised for a value that is not an integer in [0, 127].
+template <int VEC>
+__global__ __launch_bounds__(256) void pack_f32_i8_kernel(const float* __restrict__ x, int64_t ld, int64_t nv,
+                                                          int n, int npad, int64_t nkb_pad,
+                                                          int8_t* __restrict__ p, int32_t* __restrict__ flag) {
+  const int groups = npad >> 2;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t kb = gid / groups;
+  const int g = (int)(gid - kb * groups);
+  if (kb >= nkb_pad) return;
+  const int i0 = g * 4;
+  float v[16][4];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int64_t row = kb * KB + t;
+    if (row < nv) {
+      const float* src = x + row * ld + i0;
+      if (VEC == 4 && i0 + 3 < ld) {
+        const float4 f = *reinterpret_cast<const float4*>(src);
+        v[t][0] = f.x; v[t][1] = f.y; v[t][2] = f.z; v[t][3] = f.w;
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[t][s] = (i0 + s < ld) ? src[s] : 0.0f;
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) v[t][s] = 0.0f;
+    }
+  }
+  bool bad = false;
+  uint32_t w[4][4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const bool live = (i0 + s) < n;  // padding columns [n, ld) may hold anything: forced to zero
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint32_t word = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const float f = live ? v[q * 4 + b][s] : 0.0f;
+        const int iv = (int)f;
+        bad |= !((float)iv == f && iv >= 0 && iv <= 127);
+        word |= ((uint32_t)iv & 0xffu) << (8 * b);
+      }
+      w[s][q] = word;
+    }
+  }
+  uint4* dst = reinterpret_cast<uint4*>(p + ((size_t)kb * npad + i0) * KB);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) dst[s] = make_uint4(w[s][0], w[s][1], w[s][2], w[s][3]);
+  if (bad) atomicOr(flag, 4);
+}
+
+// ---------------------------------------------------------------------------------------------- gemm
+struct StageI8 {
+  int8_t p[2][SKB][TM][KB];  // [panel][k-block][sample][16 B] = 32 KiB
+};
+
+// 32 DMA instructions per stage, 4 per wave.
+__device__ __forceinline__ void issue_stage_i8(StageI8* st, const int8_t* __restrict__ p, int npad, int64_t kb0,
+                                               int col_i, int col_j, int wave, int lane) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int id = wave * 4 + q;       // 0..31
+    const int pnl = id >> 4;
+    const int kb = (id >> 2) & 3;
+    const int sq = id & 3;             // which 64-sample quarter of the panel
+    const int c0 = (pnl == 0 ? col_i : col_j) + sq * 64;
+    const int8_t* src = p + ((size_t)(kb0 + kb) * npad + c0 + lane) * KB;
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)&st->p[pnl][kb][sq * 64][0], 16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void compute_stage_i8(const StageI8* st, int wm, int wn, int lane, i32x16 (&acc)[4][2]) {
+  const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int k2 = 0; k2 < SKB / 2; ++k2) {
+    i32x4 a[4], b[2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+      a[mi] = *reinterpret_cast<const i32x4*>(&st->p[0][2 * k2 + hi][wm * 128 + mi * 32 + l31][0]);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+      b[ni] = *reinterpret_cast<const i32x4*>(&st->p[1][2 * k2 + hi][wn * 64 + ni * 32 + l31][0]);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+  }
+}
+
+template <int BUF>
+__device__ __forceinline__ void ring_step(StageI8* lds, const int8_t* __restrict__ p, int npad, int64_t kb_begin,
+                                          int s, int ns, int col_i, int col_j, int wave, int lane, int wm, int wn,
+                                          i32x16 (&acc)[4][2]) {
+  // stage s (buffer BUF) must have landed; stage s+1 may stay in flight
+  if (s + 1 < ns) wait_vmcnt<4>(); else wait_vmcnt<0>();
+  wg_barrier();  // all waves' stage-s DMA landed, and all waves are done reading buffer (BUF+2)%3
+  if (s + 2 < ns)
+    issue_stage_i8(&lds[(BUF + 2) % NSTAGE], p, npad, kb_begin + (int64_t)(s + 2) * SKB, col_i, col_j, wave, lane);
+  compute_stage_i8(&lds[BUF], wm, wn, lane, acc);
+}
+
+__global__ __launch_bounds__(NT) void gram_i8_kernel(const int8_t* __restrict__ p, int npad, int64_t nstages,
+                                                     int n, int ntile, int ntri, int splitk, int64_t stages_per,
+                                                     int32_t* __restrict__ s32, int xcd_map) {
+  __shared__ __attribute__((aligned(16))) StageI8 lds[NSTAGE];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  int tile, ks;
+  const int b = blockIdx.x;
+  if (xcd_map) {
+    const int q = b >> 3;
+    ks = (b & 7) + kNumXcd * (q / ntri);
+    tile = q % ntri;
+  } else {
+    tile = b % ntri;
+    ks = b / ntri;
+  }
+  int ti = 0, rem = tile;
+  while (rem >= ntile - ti) {
+    rem -= ntile - ti;
+    ++ti;
+  }
+  const int tj = ti + rem;
+
+  const int64_t st_begin = (int64_t)ks * stages_per;
+  const int64_t st_end = (st_begin + stages_per < nstages) ? (st_begin + stages_per) : nstages;
+  if (st_begin >= st_end) return;
+  const int ns = (int)(st_end - st_begin);
+  const int64_t kb_begin = st_begin * SKB;
+  const int col_i = ti * TM, col_j = tj * TM;
+
+  i32x16 acc[4][2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0;
+
+  issue_stage_i8(&lds[0], p, npad, kb_begin, col_i, col_j, wave, lane);
+  if (ns > 1) issue_stage_i8(&lds[1], p, npad, kb_begin + SKB, col_i, col_j, wave, lane);
+
+  int s = 0;
+  for (; s + 2 < ns; s += 3) {
+    ring_step<0>(lds, p, npad, kb_begin, s, ns, col_i, col_j, wave, lane, wm, wn, acc);
+    ring_step<1>(lds, p, npad, kb_begin, s + 1, ns, col_i, col_j, wave, lane, wm, wn, acc);
+    ring_step<2>(lds, p, npad, kb_begin, s + 2, ns, col_i, col_j, wave, lane, wm, wn, acc);
+  }
+  if (s < ns) {
+    ring_step<0>(lds, p, npad, kb_begin, s, ns, col_i, col_j, wave, lane, wm, wn, acc);
+    if (s + 1 < ns) ring_step<1>(lds, p, npad, kb_begin, s + 1, ns, col_i, col_j, wave, lane, wm, wn, acc);
+  }
+
+  // epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int j = col_j + wn * 64 + ni * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = col_i + wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int v = acc[mi][ni][r];
+        if (i < n && j < n && v != 0) atomicAdd(&s32[(int64_t)i * n + j], v);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int64_t gram_i8_npad(int32_t n) { return ((int64_t)n + TM - 1) / TM * TM; }
+int64_t gram_i8_kb_pad(int64_t nv) {
+  const int64_t nkb = (nv + KB - 1) / KB;
+  return (nkb + SKB - 1) / SKB * SKB;
+}
+size_t gram_i8_workspace_bytes(int32_t n, int64_t nv) {
+  return (size_t)gram_i8_kb_pad(nv) * (size_t)gram_i8_npad(n) * KB;
+}
+
+hipError_t launch_pack_f32_i8(const float* x, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
+                              hipStream_t stream) {
+  if (nv <= 0) return hipSuccess;
+  const int npad = (int)gram_i8_npad(n);
+  const int64_t nkb_pad = gram_i8_kb_pad(nv);
+  const int64_t threads = nkb_pad * (npad >> 2);
+  const int64_t blocks = (threads + 255) / 256;
+  if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+  const bool vec4 = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  if (vec4)
+    hipLaunchKernelGGL(pack_f32_i8_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, stream, x, ld, nv, n, npad,
+                       nkb_pad, p, flag);
+  else
+    hipLaunchKernelGGL(pack_f32_i8_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, x, ld, nv, n, npad,
+                       nkb_pad, p, flag);
+  return hipGetLastError();
+}
+
+hipError_t launch_gram_i8_packed(const int8_t* p, int64_t nv, int32_t n, int32_t* s32, int num_cu,
+                                 hipStream_t stream, int* splitk_out) {
+  if (nv <= 0) return hipSuccess;
+  const int npad = (int)gram_i8_npad(n);
+  const int ntile = npad / TM;
+  const int64_t ntri64 = (int64_t)ntile * (ntile + 1) / 2;
+  if (ntri64 > (1 << 28)) return hipErrorInvalidValue;
+  const int ntri = (int)ntri64;
+  const int64_t nstages = gram_i8_kb_pad(nv) / SKB;
+  // one 512-thread workgroup per CU is resident; aim at ~7 work units per CU, >= 16 stages each
+  const int64_t target = (int64_t)(num_cu > 0 ? num_cu : 256) * 7;
+  int64_t splitk = (target + ntri - 1) / ntri;
+  const int64_t max_by_work = nstages / 16;
+  if (splitk > max_by_work) splitk = max_by_work;
+  if (splitk < 1) splitk = 1;
+  int xcd_map = 0;
+  if (splitk >= kNumXcd) {
+    splitk = (splitk / kNumXcd) * kNumXcd;
+    xcd_map = 1;
+  }
+  const int64_t stages_per = (nstages + splitk - 1) / splitk;
+  const int64_t nblocks = (int64_t)ntri * splitk;
+  if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
+  if (splitk_out) *splitk_out = (int)splitk;
+  hipLaunchKernelGGL(gram_i8_kernel, dim3((unsigned)nblocks), dim3(NT), 0, stream, p, npad, nstages, n, ntile,
+                     ntri, (int)splitk, stages_per, s32, xcd_map);
+  return hipGetLastError();
+}
+
+}  // namespace pcoa

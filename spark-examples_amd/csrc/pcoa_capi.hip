@@ -21,7 +21,7 @@ namespace {
 
 thread_local std::string g_create_error;
 
-enum TimeCat { T_GRAM = 0, T_DENSIFY, T_SYNTH, T_FINALIZE, T_CENTER, T_TRIDIAG, T_EIG, T_BACK, T_NCAT };
+enum TimeCat { T_GRAM = 0, T_DENSIFY, T_SYNTH, T_FINALIZE, T_CENTER, T_TRIDIAG, T_EIG, T_BACK, T_PACK, T_NCAT };
 
 struct EventPair {
   hipEvent_t a, b;
@@ -60,6 +60,12 @@ struct pcoa_ctx {
   int64_t thr_cap = 0;
   int32_t* sample_pop = nullptr;   // [n]
   int64_t* xfer = nullptr;         // [n][n] int64 exchange buffer (lazy)
+  int8_t* pack_buf = nullptr;      // k-blocked int8 workspace of the i8 path (lazy)
+  int64_t pack_cap = 0;            // bytes
+  bool use_i8 = true;              // i8-MFMA Gram (default) or fp32-MFMA Gram
+  int64_t pack_chunk = (int64_t)1 << 19;  // variants packed + contracted per launch pair
+  int64_t pack_launches = 0;
+  double pack_bytes = 0;
 
   // computePca workspace (lazy)
   bool ws_ready = false;
@@ -209,23 +215,41 @@ int fold_now(pcoa_ctx* c) {
 // X tile already resident on the device: split into launches that keep fp32/int32 exact.
 int gram_device(pcoa_ctx* c, const float* x_dev, int64_t nv, int64_t ld) {
   int64_t done = 0;
+  const int64_t max_cur = c->use_i8 ? std::min(c->max_launch, c->pack_chunk) : c->max_launch;
   while (done < nv) {
-    const int64_t cur = std::min(nv - done, c->max_launch);
+    const int64_t cur = std::min(nv - done, max_cur);
     if (c->variants_in_s32 + cur > c->fold_threshold) {
       ScopedTimer t(c, T_FINALIZE);
       int rc = fold_now(c);
       if (rc != PCOA_OK) return rc;
     }
-    GramLaunch g;
-    g.x = x_dev + done * ld;
-    g.ld = ld;
-    g.nv = cur;
-    g.n = c->n;
-    g.s32 = c->s32;
-    g.zeros = c->zeros;
-    g.num_cu = c->num_cu;
-    g.stream = c->stream;
-    {
+    if (c->use_i8) {
+      // fp32 tile -> k-blocked int8 (HBM-bound pre-pass), then the i8-MFMA contraction
+      const int64_t need = (int64_t)gram_i8_workspace_bytes(c->n, cur);
+      int rc = ensure(c, &c->pack_buf, &c->pack_cap, need);
+      if (rc != PCOA_OK) return rc;
+      {
+        ScopedTimer t(c, T_PACK);
+        hipError_t e = launch_pack_f32_i8(x_dev + done * ld, ld, cur, c->n, c->pack_buf, c->err_flag, c->stream);
+        if (e != hipSuccess) return hip_fail(c, e, "pack kernel launch");
+      }
+      c->pack_launches += 1;
+      c->pack_bytes += 4.0 * (double)cur * (double)c->n + (double)need;
+      {
+        ScopedTimer t(c, T_GRAM);
+        hipError_t e = launch_gram_i8_packed(c->pack_buf, cur, c->n, c->s32, c->num_cu, c->stream, nullptr);
+        if (e != hipSuccess) return hip_fail(c, e, "gram i8 kernel launch");
+      }
+    } else {
+      GramLaunch g;
+      g.x = x_dev + done * ld;
+      g.ld = ld;
+      g.nv = cur;
+      g.n = c->n;
+      g.s32 = c->s32;
+      g.zeros = c->zeros;
+      g.num_cu = c->num_cu;
+      g.stream = c->stream;
       ScopedTimer t(c, T_GRAM);
       hipError_t e = launch_gram_f32(g, nullptr);
       if (e != hipSuccess) return hip_fail(c, e, "gram kernel launch");
@@ -239,6 +263,19 @@ int gram_device(pcoa_ctx* c, const float* x_dev, int64_t nv, int64_t ld) {
     c->have_data = true;
     done += cur;
   }
+  return PCOA_OK;
+}
+
+// Device-side input checks are asynchronous; they surface at the next synchronising call.
+int check_device_flags(pcoa_ctx* c) {
+  int32_t flag = 0;
+  HIP_TRY(c, hipMemcpyAsync(&flag, c->err_flag, sizeof(flag), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (flag & 1) return fail(c, PCOA_ERR_INDEX_RANGE, "a callset index outside [0, N) reached the device");
+  if (flag & 4)
+    return fail(c, PCOA_ERR_INVALID_ARG,
+                "a genotype tile holds a value that is not an integer in [0, 127] (carrier multiplicity); S is "
+                "invalid, call pcoa_reset; use PCOA_FLAG_GRAM_F32_MFMA for larger integer multiplicities");
   return PCOA_OK;
 }
 
@@ -332,6 +369,13 @@ int pcoa_create(pcoa_ctx** out, int32_t n_samples, int32_t device_ordinal, uint3
   c->n = n_samples;
   c->device = device_ordinal;
   c->flags = flags;
+  c->use_i8 = !(flags & PCOA_FLAG_GRAM_F32_MFMA);
+  if (const char* kk = std::getenv("PCOA_GRAM_KERNEL")) {
+    if (!std::strcmp(kk, "f32")) c->use_i8 = false;
+    if (!std::strcmp(kk, "i8")) c->use_i8 = true;
+  }
+  c->gram_kind = c->use_i8 ? 2 : 1;
+  c->pack_chunk = env_limit("PCOA_DEBUG_PACK_CHUNK", (int64_t)1 << 19);
   c->max_launch = env_limit("PCOA_DEBUG_MAX_LAUNCH", kMaxLaunchVariants);
   c->fold_threshold = env_limit("PCOA_DEBUG_FOLD_THRESHOLD", kFoldThreshold);
   auto bail = [&](hipError_t err, const char* what) {
@@ -367,7 +411,7 @@ void pcoa_destroy(pcoa_ctx* c) {
   for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto& ev : c->pool) (void)hipEventDestroy(ev);
   void* bufs[] = {c->s32, c->s64, c->zeros, c->err_flag, c->tile, c->csr_idx, c->csr_offs, c->thr_dev,
-                  c->sample_pop, c->xfer, c->ws.a, c->ws.d, c->ws.e, c->ws.tau, c->ws.q, c->ws.w, c->ws.lam,
+                  c->sample_pop, c->xfer, c->pack_buf, c->ws.a, c->ws.d, c->ws.e, c->ws.tau, c->ws.q, c->ws.w, c->ws.lam,
                   c->ws.z, c->ws.scratch, c->ws.iscratch, c->ws.status, c->row_sums, c->stats, c->nz,
                   c->out_dev};
   for (void* b : bufs)
@@ -526,7 +570,9 @@ int pcoa_accumulate_synthetic(pcoa_ctx* c, const pcoa_synth_params* p, int64_t f
 
 int pcoa_gram_finalize(pcoa_ctx* c) {
   CHECK_CTX(c);
-  return finalize_impl(c);
+  int rc = finalize_impl(c);
+  if (rc != PCOA_OK) return rc;
+  return check_device_flags(c);
 }
 
 int pcoa_gram_export_device_i64(pcoa_ctx* c, int64_t* dst_dev) {
@@ -559,11 +605,7 @@ int pcoa_gram_read_i64(pcoa_ctx* c, int64_t* out_nxn) {
   int rc = pcoa_gram_export_device_i64(c, c->xfer);
   if (rc != PCOA_OK) return rc;
   HIP_TRY(c, hipMemcpyAsync(out_nxn, c->xfer, sizeof(int64_t) * nn, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  int32_t flag = 0;
-  HIP_TRY(c, hipMemcpy(&flag, c->err_flag, sizeof(flag), hipMemcpyDeviceToHost));
-  if (flag) return fail(c, PCOA_ERR_INDEX_RANGE, "a callset index outside [0, N) reached the device");
-  return PCOA_OK;
+  return check_device_flags(c);
 }
 
 int pcoa_gram_load_i64(pcoa_ctx* c, const int64_t* in_nxn) {
@@ -657,6 +699,8 @@ int pcoa_compute(pcoa_ctx* c, int32_t num_pc, double* out_components, double* ou
   if (!out_components) return fail(c, PCOA_ERR_INVALID_ARG, "out_components is NULL");
   int rc = finalize_impl(c);
   if (rc != PCOA_OK) return rc;
+  rc = check_device_flags(c);
+  if (rc != PCOA_OK) return rc;
   rc = ensure_workspace(c, num_pc);
   if (rc != PCOA_OK) return rc;
 
@@ -748,6 +792,9 @@ int pcoa_get_timings(pcoa_ctx* c, pcoa_timings* out) {
   out->backtransform_seconds = c->tsec[T_BACK];
   out->compute_total_seconds = c->compute_total;
   out->gram_kernel_kind = c->gram_kind;
+  out->pack_seconds = c->tsec[T_PACK];
+  out->pack_launches = c->pack_launches;
+  out->pack_bytes = c->pack_bytes;
   return PCOA_OK;
 }
 
@@ -759,6 +806,8 @@ int pcoa_reset_timings(pcoa_ctx* c) {
   c->gram_variants = 0;
   c->gram_flops = c->gram_bytes = 0;
   c->compute_total = 0;
+  c->pack_launches = 0;
+  c->pack_bytes = 0;
   return PCOA_OK;
 }
 

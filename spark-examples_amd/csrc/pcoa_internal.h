@@ -29,7 +29,14 @@ struct GramLaunch {
 };
 // Returns hipSuccess or the launch error.  *splitk_out (optional) receives the split-K factor used.
 hipError_t launch_gram_f32(const GramLaunch& g, int* splitk_out);
-hipError_t launch_gram_i8(const GramLaunch& g, int* splitk_out);
+// i8 path (gram_i8.hip): pack fp32 -> k-blocked int8 workspace, then the i8-MFMA contraction.
+int64_t gram_i8_npad(int32_t n);
+int64_t gram_i8_kb_pad(int64_t nv);
+size_t gram_i8_workspace_bytes(int32_t n, int64_t nv);
+hipError_t launch_pack_f32_i8(const float* x, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
+                              hipStream_t stream);
+hipError_t launch_gram_i8_packed(const int8_t* p, int64_t nv, int32_t n, int32_t* s32, int num_cu,
+                                 hipStream_t stream, int* splitk_out);
 
 // ---- auxiliary Gram kernels (gram_aux.hip) ----------------------------------------------------
 hipError_t launch_densify_csr(const int32_t* idx_dev, const int64_t* offs_dev, int64_t v0, int64_t nv,

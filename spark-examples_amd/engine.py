@@ -26,7 +26,12 @@ def _ptr(a):
 
 
 class PcoaEngine(object):
-    def __init__(self, n_samples, device=0, flags=L.PCOA_FLAG_DEFAULT):
+    def __init__(self, n_samples, device=0, flags=L.PCOA_FLAG_DEFAULT, gram_kernel=None):
+        """gram_kernel: None/"i8" (default: exact i8-MFMA path) or "f32" (fp32-MFMA path)."""
+        if gram_kernel == "f32":
+            flags |= L.PCOA_FLAG_GRAM_F32_MFMA
+        elif gram_kernel not in (None, "i8"):
+            raise ValueError("gram_kernel must be 'i8' or 'f32'")
         self._lib = L.load()
         self._ctx = ctypes.c_void_p()
         rc = self._lib.pcoa_create(ctypes.byref(self._ctx), int(n_samples), int(device), int(flags))

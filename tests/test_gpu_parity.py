@@ -33,12 +33,16 @@ def callsets_of(x):
     return [list(np.nonzero(r)[0]) for r in x]
 
 
+KERNELS = ["i8", "f32"]  # both Gram kernels must give the reference's integers
+
+
 # ------------------------------------------------------------------------------------------ Gram
+@pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("name", golden_cases())
-def test_gram_and_centering_match_reference_python_goldens(P, name):
+def test_gram_and_centering_match_reference_python_goldens(P, name, kernel):
     g = load_golden(name)
     n = int(g["n_samples"])
-    with P.PcoaEngine(n) as eng:
+    with P.PcoaEngine(n, gram_kernel=kernel) as eng:
         eng.accumulate_calls(g["sample_idx"], g["row_offsets"])
         eng.finalize()
         assert np.array_equal(eng.gram(), g["similarity"])
@@ -63,12 +67,14 @@ def test_known_answer_survey_8c(P):
 
 
 @pytest.mark.parametrize("n,v", [(1, 1), (2, 3), (3, 17), (5, 16), (63, 100), (64, 15), (65, 33), (127, 1),
-                                 (128, 64), (129, 257), (200, 1000), (257, 129), (384, 2048), (777, 300)])
-def test_gram_dense_csr_oracle_agree_on_ragged_shapes(P, O, n, v):
+                                 (128, 64), (129, 257), (200, 1000), (257, 129), (384, 2048), (777, 300),
+                                 (255, 63), (256, 64), (513, 65), (1030, 200)])
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_gram_dense_csr_oracle_agree_on_ragged_shapes(P, O, n, v, kernel):
     rng = np.random.default_rng(1000 * n + v)
     x = (rng.random((v, n)) < rng.uniform(0.05, 0.5)).astype(np.float32)
     want = O.similarity_from_dense(x, n)
-    with P.PcoaEngine(n) as eng:
+    with P.PcoaEngine(n, gram_kernel=kernel) as eng:
         eng.accumulate_dense(x)               # host tile; ld = n (vec4 path iff n % 4 == 0 after staging)
         got_dense = eng.gram()
         eng.reset()
@@ -78,7 +84,8 @@ def test_gram_dense_csr_oracle_agree_on_ragged_shapes(P, O, n, v):
     assert np.array_equal(got_csr, want)
 
 
-def test_gram_device_pointer_paths_and_padding_is_ignored(P, O):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_gram_device_pointer_paths_and_padding_is_ignored(P, O, kernel):
     import torch
     rng = np.random.default_rng(3)
     n, v = 300, 500
@@ -87,24 +94,51 @@ def test_gram_device_pointer_paths_and_padding_is_ignored(P, O):
     for ld in (300, 301, 303, 304, 320):  # ld % 4 != 0 -> 4-byte DMA kernel; padding holds NaN
         buf = torch.full((v, ld), float("nan"), dtype=torch.float32, device="cuda")
         buf[:, :n] = torch.from_numpy(x).cuda()
-        with P.PcoaEngine(n) as eng:
+        with P.PcoaEngine(n, gram_kernel=kernel) as eng:
             eng.accumulate_dense(buf)
             assert np.array_equal(eng.gram(), want), "ld=%d" % ld
     # misaligned base pointer (4-byte aligned only)
     flat = torch.zeros(v * 304 + 1, dtype=torch.float32, device="cuda")
     view = flat[1:].view(v, 304)
     view[:, :n] = torch.from_numpy(x).cuda()
-    with P.PcoaEngine(n) as eng:
+    with P.PcoaEngine(n, gram_kernel=kernel) as eng:
         eng.accumulate_dense(view)
         assert np.array_equal(eng.gram(), want)
 
 
-def test_repeated_indices_count_with_multiplicity_like_the_reference_double_loop(P, O):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_repeated_indices_count_with_multiplicity_like_the_reference_double_loop(P, O, kernel):
     callsets = [[0, 0, 1], [2], [1, 2, 2, 2]]
     want = O.similarity_matrix_python_loops(callsets, 4)
     assert want[0, 0] == 4 and want[2, 2] == 10
-    with P.PcoaEngine(4) as eng:
+    with P.PcoaEngine(4, gram_kernel=kernel) as eng:
         eng.accumulate_callsets(callsets)
+        assert np.array_equal(eng.gram(), want)
+
+
+def test_i8_path_rejects_non_integer_or_large_values_and_f32_path_accepts_integers(P, O):
+    x = np.zeros((40, 12), dtype=np.float32)
+    x[3, 4] = 1.0
+    for bad in (0.5, -1.0, 128.0, float("nan")):
+        xb = x.copy()
+        xb[7, 2] = bad
+        with P.PcoaEngine(12) as eng:
+            eng.accumulate_dense(xb)
+            with pytest.raises(P.PcoaError) as ei:
+                eng.gram()
+            assert "integer in [0, 127]" in str(ei.value)
+    xb = x.copy()
+    xb[7, 2] = 127.0
+    xb[9, 2] = 3.0
+    want = (xb.T.astype(np.int64) @ xb.astype(np.int64))
+    for kernel in KERNELS:
+        with P.PcoaEngine(12, gram_kernel=kernel) as eng:
+            eng.accumulate_dense(xb)
+            assert np.array_equal(eng.gram(), want)
+    xb[7, 2] = 300.0  # beyond int8: only the fp32-MFMA kernel takes it
+    want = (xb.T.astype(np.int64) @ xb.astype(np.int64))
+    with P.PcoaEngine(12, gram_kernel="f32") as eng:
+        eng.accumulate_dense(xb)
         assert np.array_equal(eng.gram(), want)
 
 
@@ -164,11 +198,12 @@ def test_multi_launch_and_int64_fold_paths(P, O):
     import tempfile
     with tempfile.TemporaryDirectory() as td:
         np.save(os.path.join(td, "x.npy"), x)
-        env = dict(os.environ, PCOA_DEBUG_MAX_LAUNCH="64", PCOA_DEBUG_FOLD_THRESHOLD="200")
-        subprocess.check_call([sys.executable, "-c", code, os.path.join(td, "x.npy"), os.path.join(td, "s.npy")],
-                              env=env)
-        got = np.load(os.path.join(td, "s.npy"))
-    assert np.array_equal(got, want + O.similarity_from_dense(x[:50], n))
+        for extra in ({"PCOA_GRAM_KERNEL": "f32"}, {"PCOA_GRAM_KERNEL": "i8", "PCOA_DEBUG_PACK_CHUNK": "48"}):
+            env = dict(os.environ, PCOA_DEBUG_MAX_LAUNCH="64", PCOA_DEBUG_FOLD_THRESHOLD="200", **extra)
+            subprocess.check_call([sys.executable, "-c", code, os.path.join(td, "x.npy"),
+                                   os.path.join(td, "s.npy")], env=env)
+            got = np.load(os.path.join(td, "s.npy"))
+            assert np.array_equal(got, want + O.similarity_from_dense(x[:50], n)), extra
 
 
 def test_synthetic_device_generator_is_bit_identical_to_host_twin(P, O):
@@ -199,10 +234,11 @@ def test_config2_shape_against_faithful_pair_loop(P, O):
     thr = synth.thresholds(seed, 0, v)
     x = synth.genotypes(seed, 0, thr, offs)
     want = O.similarity_from_dense(x, n)
-    with P.PcoaEngine(n) as eng:
-        eng.accumulate_synthetic(seed, offs, thr, 0)
-        got = eng.gram()
-    assert np.array_equal(got, want)
+    for kernel in KERNELS:
+        with P.PcoaEngine(n, gram_kernel=kernel) as eng:
+            eng.accumulate_synthetic(seed, offs, thr, 0)
+            got = eng.gram()
+        assert np.array_equal(got, want), kernel
 
 
 def test_full_config2_size_properties(P):
@@ -230,6 +266,9 @@ def test_full_config2_size_properties(P):
         eng.reset()
         eng.accumulate_dense(x[:400001])
         eng.accumulate_dense(x[400001:])
+        assert np.array_equal(eng.gram(), s)
+    with P.PcoaEngine(n, gram_kernel="f32") as eng:   # the fp32-MFMA kernel gives the same integers
+        eng.accumulate_dense(x)
         assert np.array_equal(eng.gram(), s)
 
 

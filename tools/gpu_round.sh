@@ -24,18 +24,21 @@ for s in $STEPS; do
     bench)
       timeout 900 python bench.py --gpus 1 --steps 5 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
       echo "bench exit $?" | tee -a $OUT/summary.txt; cat $OUT/bench.json | tee -a $OUT/summary.txt; tail -5 $OUT/bench.err ;;
+    benchf32)
+      timeout 900 python bench.py --gpus 1 --steps 5 --warmup 2 --gram-kernel f32 --no-cpu-baseline > $OUT/bench_f32.json 2> $OUT/bench_f32.err
+      echo "bench f32 exit $?" | tee -a $OUT/summary.txt; cat $OUT/bench_f32.json | tee -a $OUT/summary.txt; tail -5 $OUT/bench_f32.err ;;
     prof)
-      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o trace -- python $OLDPWD/bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline > $OLDPWD/$OUT/prof_bench.json 2> $OLDPWD/$OUT/prof.err )
+      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o trace -- python $OLDPWD/bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline > $OLDPWD/$OUT/prof_bench.json 2> $OLDPWD/$OUT/prof.err )
       echo "prof exit $?" | tee -a $OUT/summary.txt
-      find $OUT/prof -name "*kernel_stats*" | head -3 | while read f; do echo "--- $f"; head -25 "$f"; done | tee -a $OUT/summary.txt
+      find $OUT/prof -name "*kernel_stats*" | head -3 | while read f; do echo "--- $f"; head -25 "$f" | cut -c1-220; done | tee -a $OUT/summary.txt
       # keep the merge-back small: drop the raw per-dispatch trace if it is large
       find $OUT/prof -name "*kernel_trace*" -size +8M -delete ;;
     pmc)
-      ( cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE -d $OLDPWD/$OUT/pmc_fetch -o pmc -- python $OLDPWD/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --pcoa-reps 1 > /dev/null 2> $OLDPWD/$OUT/pmc_fetch.err )
+      ( cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OLDPWD/$OUT/pmc_fetch -o pmc -- python $OLDPWD/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --pcoa-reps 1 > /dev/null 2> $OLDPWD/$OUT/pmc_fetch.err )
       echo "pmc fetch exit $?" | tee -a $OUT/summary.txt
-      ( cd /tmp && timeout 900 rocprofv3 --pmc WRITE_SIZE -d $OLDPWD/$OUT/pmc_write -o pmc -- python $OLDPWD/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --pcoa-reps 1 > /dev/null 2> $OLDPWD/$OUT/pmc_write.err )
+      ( cd /tmp && timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OLDPWD/$OUT/pmc_write -o pmc -- python $OLDPWD/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --pcoa-reps 1 > /dev/null 2> $OLDPWD/$OUT/pmc_write.err )
       echo "pmc write exit $?" | tee -a $OUT/summary.txt
-      ( cd /tmp && timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT -d $OLDPWD/$OUT/pmc_sq -o pmc -- python $OLDPWD/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --pcoa-reps 1 > /dev/null 2> $OLDPWD/$OUT/pmc_sq.err )
+      ( cd /tmp && timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $OLDPWD/$OUT/pmc_sq -o pmc -- python $OLDPWD/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --pcoa-reps 1 > /dev/null 2> $OLDPWD/$OUT/pmc_sq.err )
       echo "pmc sq exit $?" | tee -a $OUT/summary.txt
       python tools/pmc_summary.py $OUT | tee -a $OUT/summary.txt
       find $OUT -name "*counter_collection*" -size +4M -delete ;;
