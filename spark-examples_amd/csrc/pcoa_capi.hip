@@ -60,13 +60,10 @@ struct pcoa_ctx {
   int64_t thr_cap = 0;
   int32_t* sample_pop = nullptr;   // [n]
   int64_t* xfer = nullptr;         // [n][n] int64 exchange buffer (lazy)
-  int8_t* pack_buf[2] = {nullptr, nullptr};  // k-blocked int8 workspaces of the i8 path (lazy, ping-pong)
-  int64_t pack_cap[2] = {0, 0};    // bytes
-  hipStream_t pack_stream = nullptr;          // the HBM-bound pre-pass runs here, beside the MFMA-bound contraction
-  hipEvent_t ev_entry = nullptr, ev_pack[2] = {nullptr, nullptr}, ev_gram[2] = {nullptr, nullptr};
-  bool gram_recorded[2] = {false, false};
+  int8_t* pack_buf = nullptr;      // k-blocked int8 workspace of the i8 path (lazy)
+  int64_t pack_cap = 0;            // bytes
   bool use_i8 = true;              // i8-MFMA Gram (default) or fp32-MFMA Gram
-  int64_t pack_chunk = (int64_t)1 << 18;  // variants packed + contracted per launch pair
+  int64_t pack_chunk = (int64_t)1 << 20;  // variants packed + contracted per launch pair
   int64_t pack_launches = 0;
   double pack_bytes = 0;
 
@@ -131,10 +128,7 @@ hipEvent_t get_event(pcoa_ctx* c) {
 
 // resolves finished (or, if wait, all) event pairs into the per-category sums
 void drain_events(pcoa_ctx* c, bool wait) {
-  if (wait) {
-    (void)hipStreamSynchronize(c->stream);
-    if (c->pack_stream) (void)hipStreamSynchronize(c->pack_stream);
-  }
+  if (wait) (void)hipStreamSynchronize(c->stream);
   size_t keep = 0;
   for (size_t i = 0; i < c->pending.size(); ++i) {
     EventPair& p = c->pending[i];
@@ -159,16 +153,14 @@ struct ScopedTimer {
   pcoa_ctx* c;
   EventPair p;
   bool on;
-  hipStream_t st;
-  ScopedTimer(pcoa_ctx* ctx, int cat, hipStream_t stream = nullptr) : c(ctx), on(false) {
-    st = stream ? stream : c->stream;
+  ScopedTimer(pcoa_ctx* ctx, int cat) : c(ctx), on(false) {
     p.a = get_event(c);
     p.b = get_event(c);
     p.cat = cat;
-    if (p.a && p.b && hipEventRecord(p.a, st) == hipSuccess) on = true;
+    if (p.a && p.b && hipEventRecord(p.a, c->stream) == hipSuccess) on = true;
   }
   ~ScopedTimer() {
-    if (on && hipEventRecord(p.b, st) == hipSuccess) {
+    if (on && hipEventRecord(p.b, c->stream) == hipSuccess) {
       c->pending.push_back(p);
       if (c->pending.size() > 2048) drain_events(c, true);
     } else {
@@ -183,7 +175,6 @@ int ensure(pcoa_ctx* c, T** buf, int64_t* cap, int64_t need) {
   if (need <= *cap) return PCOA_OK;
   // the old buffer may still be read by queued kernels
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (c->pack_stream) HIP_TRY(c, hipStreamSynchronize(c->pack_stream));
   if (*buf) (void)hipFree(*buf);
   *buf = nullptr;
   *cap = 0;
@@ -224,13 +215,7 @@ int fold_now(pcoa_ctx* c) {
 // X tile already resident on the device: split into launches that keep fp32/int32 exact.
 int gram_device(pcoa_ctx* c, const float* x_dev, int64_t nv, int64_t ld) {
   int64_t done = 0;
-  int64_t chunk_index = 0;
   const int64_t max_cur = c->use_i8 ? std::min(c->max_launch, c->pack_chunk) : c->max_launch;
-  if (c->use_i8) {
-    // whatever produced x on the main stream (synthetic fill, densify, H2D) must precede the pre-pass
-    HIP_TRY(c, hipEventRecord(c->ev_entry, c->stream));
-    HIP_TRY(c, hipStreamWaitEvent(c->pack_stream, c->ev_entry, 0));
-  }
   while (done < nv) {
     const int64_t cur = std::min(nv - done, max_cur);
     if (c->variants_in_s32 + cur > c->fold_threshold) {
@@ -239,32 +224,25 @@ int gram_device(pcoa_ctx* c, const float* x_dev, int64_t nv, int64_t ld) {
       if (rc != PCOA_OK) return rc;
     }
     if (c->use_i8) {
-      // fp32 tile -> k-blocked int8 (HBM-bound pre-pass on pack_stream), then the i8-MFMA contraction
-      // on the main stream.  Two workspaces ping-pong, so chunk c+1 is packed while chunk c is
-      // contracted: the two kernels bound on different resources (HBM vs matrix cores) overlap.
-      const int slot = (int)(chunk_index & 1);
+      // fp32 tile -> k-blocked int8 (HBM-bound pre-pass), then the i8-MFMA contraction, back to back on
+      // one stream.  (Running the pre-pass on a second stream beside the contraction was measured
+      // SLOWER, 5.45 vs 5.09 ms per 10^6 variants: both kernels want all 256 CUs and the resident
+      // pre-pass waves block placement of the 96 KiB-LDS contraction workgroups.)
       const int64_t need = (int64_t)gram_i8_workspace_bytes(c->n, cur);
-      int rc = ensure(c, &c->pack_buf[slot], &c->pack_cap[slot], need);
+      int rc = ensure(c, &c->pack_buf, &c->pack_cap, need);
       if (rc != PCOA_OK) return rc;
-      if (c->gram_recorded[slot]) HIP_TRY(c, hipStreamWaitEvent(c->pack_stream, c->ev_gram[slot], 0));
       {
-        ScopedTimer t(c, T_PACK, c->pack_stream);
-        hipError_t e = launch_pack_f32_i8(x_dev + done * ld, ld, cur, c->n, c->pack_buf[slot], c->err_flag,
-                                          c->pack_stream);
+        ScopedTimer t(c, T_PACK);
+        hipError_t e = launch_pack_f32_i8(x_dev + done * ld, ld, cur, c->n, c->pack_buf, c->err_flag, c->stream);
         if (e != hipSuccess) return hip_fail(c, e, "pack kernel launch");
       }
-      HIP_TRY(c, hipEventRecord(c->ev_pack[slot], c->pack_stream));
-      HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_pack[slot], 0));
       c->pack_launches += 1;
       c->pack_bytes += 4.0 * (double)cur * (double)c->n + (double)need;
       {
         ScopedTimer t(c, T_GRAM);
-        hipError_t e = launch_gram_i8_packed(c->pack_buf[slot], cur, c->n, c->s32, c->num_cu, c->stream, nullptr);
+        hipError_t e = launch_gram_i8_packed(c->pack_buf, cur, c->n, c->s32, c->num_cu, c->stream, nullptr);
         if (e != hipSuccess) return hip_fail(c, e, "gram i8 kernel launch");
       }
-      HIP_TRY(c, hipEventRecord(c->ev_gram[slot], c->stream));
-      c->gram_recorded[slot] = true;
-      ++chunk_index;
     } else {
       GramLaunch g;
       g.x = x_dev + done * ld;
@@ -400,7 +378,6 @@ int pcoa_create(pcoa_ctx** out, int32_t n_samples, int32_t device_ordinal, uint3
     if (!std::strcmp(kk, "i8")) c->use_i8 = true;
   }
   c->gram_kind = c->use_i8 ? 2 : 1;
-  c->pack_chunk = (int64_t)1 << 18;
   if (const char* pc = std::getenv("PCOA_DEBUG_PACK_CHUNK")) {
     const long long x = std::atoll(pc);
     if (x > 0 && x <= ((long long)1 << 24)) c->pack_chunk = (int64_t)x;
@@ -421,13 +398,6 @@ int pcoa_create(pcoa_ctx** out, int32_t n_samples, int32_t device_ordinal, uint3
   if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess)
     return bail(e, "hipStreamCreate");
   c->stream = c->own_stream;
-  if ((e = hipStreamCreateWithFlags(&c->pack_stream, hipStreamNonBlocking)) != hipSuccess)
-    return bail(e, "hipStreamCreate(pack)");
-  {
-    hipEvent_t* evs[] = {&c->ev_entry, &c->ev_pack[0], &c->ev_pack[1], &c->ev_gram[0], &c->ev_gram[1]};
-    for (hipEvent_t* ev : evs)
-      if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
-  }
   const size_t nn = (size_t)n_samples * (size_t)n_samples;
   if ((e = hipMalloc((void**)&c->s32, sizeof(int32_t) * nn)) != hipSuccess) return bail(e, "hipMalloc(S)");
   if ((e = hipMemsetAsync(c->s32, 0, sizeof(int32_t) * nn, c->stream)) != hipSuccess) return bail(e, "memset(S)");
@@ -444,19 +414,15 @@ void pcoa_destroy(pcoa_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  if (c->pack_stream) (void)hipStreamSynchronize(c->pack_stream);
-  for (hipEvent_t ev : {c->ev_entry, c->ev_pack[0], c->ev_pack[1], c->ev_gram[0], c->ev_gram[1]})
-    if (ev) (void)hipEventDestroy(ev);
   for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto& ev : c->pool) (void)hipEventDestroy(ev);
   void* bufs[] = {c->s32, c->s64, c->zeros, c->err_flag, c->tile, c->csr_idx, c->csr_offs, c->thr_dev,
-                  c->sample_pop, c->xfer, c->pack_buf[0], c->pack_buf[1], c->ws.a, c->ws.d, c->ws.e, c->ws.tau, c->ws.q, c->ws.w, c->ws.lam,
+                  c->sample_pop, c->xfer, c->pack_buf, c->ws.a, c->ws.d, c->ws.e, c->ws.tau, c->ws.q, c->ws.w, c->ws.lam,
                   c->ws.z, c->ws.scratch, c->ws.iscratch, c->ws.status, c->row_sums, c->stats, c->nz,
                   c->out_dev};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
-  if (c->pack_stream) (void)hipStreamDestroy(c->pack_stream);
   delete c;
 }
 
@@ -468,7 +434,6 @@ int pcoa_set_stream(pcoa_ctx* c, void* hip_stream) {
   CHECK_CTX(c);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   drain_events(c, true);
-  c->gram_recorded[0] = c->gram_recorded[1] = false;
   c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
   return PCOA_OK;
 }
@@ -476,7 +441,6 @@ int pcoa_set_stream(pcoa_ctx* c, void* hip_stream) {
 int pcoa_sync(pcoa_ctx* c) {
   CHECK_CTX(c);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->pack_stream));
   return PCOA_OK;
 }
 
