@@ -194,6 +194,17 @@ def main():
             comps, lam, nz = eng.compute(2)
             pcoa.append(1e3 * (time.perf_counter() - t1))
         tim2 = eng.timings()
+        # the dense (gap-independent) eigensolver on the same S, for reference
+        pcoa_hh = []
+        with P.PcoaEngine(n, device=local_rank, eig="householder") as eng_hh:
+            eng_hh.load_gram(eng.gram())
+            for _ in range(2):
+                t1 = time.perf_counter()
+                comps_hh, lam_hh, _ = eng_hh.compute(2)
+                pcoa_hh.append(1e3 * (time.perf_counter() - t1))
+            tim_hh = eng_hh.timings()
+        agree = float(max(np.linalg.norm(comps[:, c] - comps_hh[:, c] * np.sign(np.dot(comps[:, c], comps_hh[:, c])))
+                          for c in range(2)))
         out = {
             "metric": METRIC, "value": value, "unit": "variants/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
@@ -208,7 +219,15 @@ def main():
             "finalize_ms_per_step": 1e3 * tim["finalize_seconds"] / steps,
             "pcoa_wall_ms": float(np.median(pcoa)), "pcoa_wall_ms_all": pcoa,
             "pcoa_breakdown_ms": {k: 1e3 * tim2[k] / max(args.pcoa_reps, 1) for k in
-                                  ("center_seconds", "tridiag_seconds", "eig_seconds", "backtransform_seconds")},
+                                  ("center_seconds", "lanczos_seconds", "tridiag_seconds", "eig_seconds",
+                                   "backtransform_seconds")},
+            "pcoa_method": {1: "lanczos (verified residual)", 2: "householder"}.get(tim2["eig_method"], "?"),
+            "lanczos_steps": tim2["lanczos_steps"],
+            "pcoa_wall_ms_householder": float(min(pcoa_hh)),
+            "pcoa_householder_breakdown_ms": {k: 1e3 * tim_hh[k] / 2 for k in
+                                              ("center_seconds", "tridiag_seconds", "eig_seconds",
+                                               "backtransform_seconds")},
+            "pcoa_paths_max_vector_diff": agree,
             "eigenvalues": [float(t) for t in lam], "nonzero_rows": int(nz),
             "device": dev_name, "cu_count": cus,
         }

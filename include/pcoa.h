@@ -51,6 +51,8 @@ typedef enum pcoa_status {
 #define PCOA_FLAG_GRAM_F32_MFMA  0x1u  /* fp32-MFMA Gram kernel (v_mfma_f32_32x32x2_f32): any small ints */
 #define PCOA_FLAG_GRAM_I8_MFMA   0x2u  /* i8-MFMA Gram kernel (v_mfma_i32_32x32x32_i8), the default      */
 #define PCOA_FLAG_NO_SIGN_NORM   0x10u /* keep the eigensolver's native sign instead of sign-normalising */
+#define PCOA_FLAG_EIG_HOUSEHOLDER 0x20u /* always use the dense Householder + bisection eigensolver        */
+#define PCOA_FLAG_EIG_LANCZOS    0x40u /* Lanczos only: PCOA_ERR_NOT_CONVERGED instead of falling back      */
 
 /* Per-stage timings, filled by pcoa_get_timings(); times in seconds, measured with HIP events on
  * the ctx stream.  Counters are cumulative since pcoa_create / pcoa_reset_timings. */
@@ -73,6 +75,9 @@ typedef struct pcoa_timings {
   double pack_seconds;          /* fp32 -> k-blocked int8 pre-pass of the i8 path (sum of launches)   */
   int64_t pack_launches;
   double pack_bytes;            /* algorithmic bytes of the pre-pass: 4*V*N read + V*Npad written     */
+  double lanczos_seconds;       /* Lanczos fast path of the eigensolver (sum over computes)           */
+  int32_t eig_method;           /* of the last pcoa_compute: 1 = Lanczos (verified), 2 = Householder  */
+  int32_t lanczos_steps;        /* Krylov dimension reached by the last pcoa_compute                  */
 } pcoa_timings;
 
 /* Synthetic genotype model (bench / tests only; not part of the reference).  Sample i belongs to

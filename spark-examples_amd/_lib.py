@@ -23,6 +23,8 @@ PCOA_FLAG_DEFAULT = 0
 PCOA_FLAG_GRAM_F32_MFMA = 0x1
 PCOA_FLAG_GRAM_I8_MFMA = 0x2
 PCOA_FLAG_NO_SIGN_NORM = 0x10
+PCOA_FLAG_EIG_HOUSEHOLDER = 0x20
+PCOA_FLAG_EIG_LANCZOS = 0x40
 
 
 class PcoaTimings(ctypes.Structure):
@@ -45,6 +47,9 @@ class PcoaTimings(ctypes.Structure):
         ("pack_seconds", ctypes.c_double),
         ("pack_launches", ctypes.c_int64),
         ("pack_bytes", ctypes.c_double),
+        ("lanczos_seconds", ctypes.c_double),
+        ("eig_method", ctypes.c_int32),
+        ("lanczos_steps", ctypes.c_int32),
     ]
 
 

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(HW_T) void tridiag_hw_kernel(double* __restrict__ a
                                                           double* __restrict__ w) {
   __shared__ double red[24];
   const int tid = threadIdx.x;
+  const int nt = blockDim.x;  // 256 for short rows (cheaper barriers), 1024 for long ones
   double* rowk = a + (int64_t)k * n;
   const bool pending = k > 0;
   const double* vprev = a + (int64_t)(pending ? k - 1 : 0) * n;
@@ -92,10 +93,10 @@ __global__ __launch_bounds__(HW_T) void tridiag_hw_kernel(double* __restrict__ a
   if (pending) {
     const double tp = tau[k - 1];
     double part = 0.0;
-    for (int j = k + tid; j < n; j += HW_T) part += q[j] * vprev[j];
+    for (int j = k + tid; j < n; j += nt) part += q[j] * vprev[j];
     const double dot = block_reduce<0>(part, red);
     const double c = 0.5 * tp * tp * dot;
-    for (int j = k + tid; j < n; j += HW_T) {
+    for (int j = k + tid; j < n; j += nt) {
       const double wj = tp * q[j] - c * vprev[j];
       w[j] = wj;
       if (j == k) red[20] = wj;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(HW_T) void tridiag_hw_kernel(double* __restrict__ a
   if (k >= n - 1) return;  // n == 1
 
   double part = 0.0;
-  for (int j = k + tid; j < n; j += HW_T) {
+  for (int j = k + tid; j < n; j += nt) {
     if (j == k) continue;
     double xj = rowk[j];
     if (pending) xj -= vpk * w[j] + wk * vprev[j];
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(HW_T) void tridiag_hw_kernel(double* __restrict__ a
     t = (beta - alpha) / beta;
     scale = 1.0 / (alpha - beta);
   }
-  for (int j = k + tid; j < n; j += HW_T) {
+  for (int j = k + tid; j < n; j += nt) {
     if (j == k) continue;
     rowk[j] = (j == k + 1) ? 1.0 : rowk[j] * scale;
   }
@@ -160,24 +161,46 @@ __global__ __launch_bounds__(256) void tridiag_update_kernel(double* __restrict_
     vpi = vprev[i];
     wpi = w[i];
   }
-  double acc = 0.0;
-  const int j0 = (k + 1) & ~63;
+  double acc = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+  int j = ((k + 1) & ~63) + lane;  // 512-B aligned start; the first chunk is masked at j <= k
   if (pending) {
-#pragma unroll 4
-    for (int j = j0 + lane; j < n; j += 64) {
-      if (j > k) {
-        const double aij = row[j] - (vpi * w[j] + wpi * vprev[j]);
-        row[j] = aij;
-        acc += aij * vk[j];
-      }
+    if (j > k && j < n) {
+      const double aij = row[j] - (vpi * w[j] + wpi * vprev[j]);
+      row[j] = aij;
+      acc += aij * vk[j];
+    }
+    j += 64;
+    // four independent 512-B row segments in flight per wave (memory-level parallelism: the pass is
+    // bandwidth/latency-bound, ~10 waves per CU)
+    for (; j + 192 < n; j += 256) {
+      const double r0 = row[j], r1 = row[j + 64], r2 = row[j + 128], r3 = row[j + 192];
+      const double a0 = r0 - (vpi * w[j] + wpi * vprev[j]);
+      const double a1 = r1 - (vpi * w[j + 64] + wpi * vprev[j + 64]);
+      const double a2 = r2 - (vpi * w[j + 128] + wpi * vprev[j + 128]);
+      const double a3 = r3 - (vpi * w[j + 192] + wpi * vprev[j + 192]);
+      row[j] = a0; row[j + 64] = a1; row[j + 128] = a2; row[j + 192] = a3;
+      acc += a0 * vk[j];
+      acc1 += a1 * vk[j + 64];
+      acc2 += a2 * vk[j + 128];
+      acc3 += a3 * vk[j + 192];
+    }
+    for (; j < n; j += 64) {
+      const double aij = row[j] - (vpi * w[j] + wpi * vprev[j]);
+      row[j] = aij;
+      acc += aij * vk[j];
     }
   } else {
-#pragma unroll 4
-    for (int j = j0 + lane; j < n; j += 64) {
-      if (j > k) acc += row[j] * vk[j];
+    if (j > k && j < n) acc += row[j] * vk[j];
+    j += 64;
+    for (; j + 192 < n; j += 256) {
+      acc += row[j] * vk[j];
+      acc1 += row[j + 64] * vk[j + 64];
+      acc2 += row[j + 128] * vk[j + 128];
+      acc3 += row[j + 192] * vk[j + 192];
     }
+    for (; j < n; j += 64) acc += row[j] * vk[j];
   }
-  acc = wave_sum(acc);
+  acc = wave_sum((acc + acc1) + (acc2 + acc3));
   if (lane == 0) q[i] = acc;
 }
 
@@ -329,7 +352,7 @@ __global__ __launch_bounds__(64) void invit_kernel(const double* __restrict__ d,
       }
     }
     __syncthreads();
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < 3; ++it) {
       if (lane == 0) {
         // y = U^-1 L^-1 P z  (dgtts2, no transpose)
         for (int i = 0; i < n; ++i) y[i] = zc[i];
@@ -385,12 +408,12 @@ __global__ __launch_bounds__(64) void invit_kernel(const double* __restrict__ d,
 __global__ __launch_bounds__(HW_T) void backtransform_kernel(const double* __restrict__ a, int n,
                                                              const double* __restrict__ tau,
                                                              double* __restrict__ z, int sign_normalize,
-                                                             double* __restrict__ out) {
+                                                             int apply_reflectors, double* __restrict__ out) {
   __shared__ double red[24];
   __shared__ int redi[24];
   const int tid = threadIdx.x;
   double* zc = z + (int64_t)blockIdx.x * n;
-  for (int s = n - 3; s >= 0; --s) {
+  for (int s = apply_reflectors ? n - 3 : -1; s >= 0; --s) {
     const double t = tau[s];
     if (t == 0.0) continue;  // uniform
     const double* vs = a + (int64_t)s * n;
@@ -448,8 +471,9 @@ hipError_t launch_tridiagonalize(const EigWorkspace& ws, int32_t n, hipStream_t 
     return hipGetLastError();
   }
   for (int k = 0; k <= n - 2; ++k) {
-    hipLaunchKernelGGL(tridiag_hw_kernel, dim3(1), dim3(HW_T), 0, stream, ws.a, n, k, ws.d, ws.e, ws.tau, ws.q,
-                       ws.w);
+    const int hw_threads = (n - k > 4096) ? HW_T : 256;
+    hipLaunchKernelGGL(tridiag_hw_kernel, dim3(1), dim3(hw_threads), 0, stream, ws.a, n, k, ws.d, ws.e, ws.tau,
+                       ws.q, ws.w);
     if (k <= n - 3) {
       const int rows = n - k - 1;
       hipLaunchKernelGGL(tridiag_update_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, ws.a, n,
@@ -483,9 +507,9 @@ hipError_t launch_inverse_iteration(const EigWorkspace& ws, int32_t n, const dou
 }
 
 hipError_t launch_backtransform(const EigWorkspace& ws, int32_t n, int32_t k, int sign_normalize,
-                                double* out_dev, hipStream_t stream) {
+                                int apply_reflectors, double* out_dev, hipStream_t stream) {
   hipLaunchKernelGGL(backtransform_kernel, dim3((unsigned)k), dim3(HW_T), 0, stream, ws.a, n, ws.tau, ws.z,
-                     sign_normalize, out_dev);
+                     sign_normalize, apply_reflectors, out_dev);
   return hipGetLastError();
 }
 

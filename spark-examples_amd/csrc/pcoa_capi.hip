@@ -21,7 +21,7 @@ namespace {
 
 thread_local std::string g_create_error;
 
-enum TimeCat { T_GRAM = 0, T_DENSIFY, T_SYNTH, T_FINALIZE, T_CENTER, T_TRIDIAG, T_EIG, T_BACK, T_PACK, T_NCAT };
+enum TimeCat { T_GRAM = 0, T_DENSIFY, T_SYNTH, T_FINALIZE, T_CENTER, T_TRIDIAG, T_EIG, T_BACK, T_PACK, T_LANCZOS, T_NCAT };
 
 struct EventPair {
   hipEvent_t a, b;
@@ -75,6 +75,10 @@ struct pcoa_ctx {
   int32_t* nz = nullptr;           // [1]
   double* out_dev = nullptr;       // [kmax][n]
   int32_t kmax = 0;
+  double* lanczos_ws = nullptr;    // Krylov basis + scalars of the Lanczos fast path (lazy)
+  int64_t lanczos_cap = 0;         // doubles
+  int32_t eig_method = 0;          // of the last pcoa_compute: 1 = Lanczos, 2 = Householder
+  int32_t lanczos_steps = 0;
 
   // timings
   std::vector<EventPair> pending;
@@ -307,7 +311,7 @@ int ensure_workspace(pcoa_ctx* c, int32_t k) {
     if (c->ws.z) (void)hipFree(c->ws.z);
     if (c->out_dev) (void)hipFree(c->out_dev);
     c->ws.lam = nullptr; c->ws.z = nullptr; c->out_dev = nullptr; c->kmax = 0;
-    HIP_TRY(c, hipMalloc((void**)&c->ws.lam, sizeof(double) * (size_t)(2 * k + 2)));
+    HIP_TRY(c, hipMalloc((void**)&c->ws.lam, sizeof(double) * (size_t)(2 * k + 8)));
     HIP_TRY(c, hipMalloc((void**)&c->ws.z, sizeof(double) * (size_t)((int64_t)k * n)));
     HIP_TRY(c, hipMalloc((void**)&c->out_dev, sizeof(double) * (size_t)((int64_t)k * n)));
     c->kmax = k;
@@ -417,7 +421,7 @@ void pcoa_destroy(pcoa_ctx* c) {
   for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto& ev : c->pool) (void)hipEventDestroy(ev);
   void* bufs[] = {c->s32, c->s64, c->zeros, c->err_flag, c->tile, c->csr_idx, c->csr_offs, c->thr_dev,
-                  c->sample_pop, c->xfer, c->pack_buf, c->ws.a, c->ws.d, c->ws.e, c->ws.tau, c->ws.q, c->ws.w, c->ws.lam,
+                  c->sample_pop, c->xfer, c->pack_buf, c->lanczos_ws, c->ws.a, c->ws.d, c->ws.e, c->ws.tau, c->ws.q, c->ws.w, c->ws.lam,
                   c->ws.z, c->ws.scratch, c->ws.iscratch, c->ws.status, c->row_sums, c->stats, c->nz,
                   c->out_dev};
   for (void* b : bufs)
@@ -717,44 +721,72 @@ int pcoa_compute(pcoa_ctx* c, int32_t num_pc, double* out_components, double* ou
     ScopedTimer t(c, T_CENTER);
     HIP_TRY(c, launch_center(c->s32, c->s64, n, c->row_sums, c->stats, c->nz, c->ws.a, c->stream));
   }
-  {
-    ScopedTimer t(c, T_TRIDIAG);
-    HIP_TRY(c, launch_tridiagonalize(c->ws, n, c->stream));
-  }
-  // candidates: the k algebraically largest and the k smallest eigenvalues of T; MLlib ranks by the
-  // singular values of Cov, i.e. by |lambda| (B = J S J is PSD up to rounding, so normally the largest)
-  std::vector<int32_t> idx;
-  for (int32_t t = 0; t < num_pc; ++t) idx.push_back(n - 1 - t);
-  for (int32_t t = 0; t < num_pc; ++t)
-    if (t < n - num_pc) idx.push_back(t);
-  std::vector<double> cand(idx.size());
-  {
-    ScopedTimer t(c, T_EIG);
-    HIP_TRY(c, launch_bisect(c->ws, n, idx.data(), (int32_t)idx.size(), c->ws.lam, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(cand.data(), c->ws.lam, sizeof(double) * cand.size(), hipMemcpyDeviceToHost,
-                              c->stream));
-  }
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  std::vector<int> order(cand.size());
-  for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-    const double fa = std::fabs(cand[a]), fb = std::fabs(cand[b]);
-    if (fa != fb) return fa > fb;
-    return cand[a] > cand[b];
-  });
   std::vector<double> sel((size_t)num_pc);
-  for (int32_t t = 0; t < num_pc; ++t) {
-    if (!std::isfinite(cand[order[t]])) return fail(c, PCOA_ERR_NOT_CONVERGED, "non-finite eigenvalue");
-    sel[(size_t)t] = cand[order[t]];
+  bool have_vectors = false;
+  c->eig_method = 0;
+  c->lanczos_steps = 0;
+  const bool force_householder = (c->flags & PCOA_FLAG_EIG_HOUSEHOLDER) != 0;
+  const bool force_lanczos = (c->flags & PCOA_FLAG_EIG_LANCZOS) != 0;
+  if (!force_householder && n >= 32) {
+    // fast path: Lanczos on B for the k wanted pairs, accepted only with a verified residual
+    const int32_t mmax = std::min<int32_t>(n, 512);
+    const int64_t need = (int64_t)lanczos_workspace_doubles(n, num_pc, mmax);
+    rc = ensure(c, &c->lanczos_ws, &c->lanczos_cap, need);
+    if (rc != PCOA_OK) return rc;
+    int conv = 0, steps = 0;
+    {
+      ScopedTimer t(c, T_LANCZOS);
+      HIP_TRY(c, lanczos_topk(c->ws, c->lanczos_ws, n, num_pc, mmax, 1e-11, sel.data(), &conv, &steps, c->stream));
+    }
+    c->lanczos_steps = steps;
+    if (conv) {
+      have_vectors = true;
+      c->eig_method = 1;
+    } else if (force_lanczos) {
+      return fail(c, PCOA_ERR_NOT_CONVERGED, "Lanczos did not reach a verified residual (PCOA_FLAG_EIG_LANCZOS set)");
+    }
   }
-  {
-    ScopedTimer t(c, T_EIG);
-    HIP_TRY(c, launch_inverse_iteration(c->ws, n, sel.data(), num_pc, c->stream));
+  if (!have_vectors) {
+    // exact, gap-independent path: Householder tridiagonalisation + bisection + inverse iteration
+    c->eig_method = 2;
+    {
+      ScopedTimer t(c, T_TRIDIAG);
+      HIP_TRY(c, launch_tridiagonalize(c->ws, n, c->stream));
+    }
+    // candidates: the k algebraically largest and the k smallest eigenvalues of T; MLlib ranks by the
+    // singular values of Cov, i.e. by |lambda| (B = J S J is PSD up to rounding, so normally the largest)
+    std::vector<int32_t> idx;
+    for (int32_t t = 0; t < num_pc; ++t) idx.push_back(n - 1 - t);
+    for (int32_t t = 0; t < num_pc; ++t)
+      if (t < n - num_pc) idx.push_back(t);
+    std::vector<double> cand(idx.size());
+    {
+      ScopedTimer t(c, T_EIG);
+      HIP_TRY(c, launch_bisect(c->ws, n, idx.data(), (int32_t)idx.size(), c->ws.lam, c->stream));
+      HIP_TRY(c, hipMemcpyAsync(cand.data(), c->ws.lam, sizeof(double) * cand.size(), hipMemcpyDeviceToHost,
+                                c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::vector<int> order(cand.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+      const double fa = std::fabs(cand[a]), fb = std::fabs(cand[b]);
+      if (fa != fb) return fa > fb;
+      return cand[a] > cand[b];
+    });
+    for (int32_t t = 0; t < num_pc; ++t) {
+      if (!std::isfinite(cand[order[t]])) return fail(c, PCOA_ERR_NOT_CONVERGED, "non-finite eigenvalue");
+      sel[(size_t)t] = cand[order[t]];
+    }
+    {
+      ScopedTimer t(c, T_EIG);
+      HIP_TRY(c, launch_inverse_iteration(c->ws, n, sel.data(), num_pc, c->stream));
+    }
   }
   {
     ScopedTimer t(c, T_BACK);
-    HIP_TRY(c, launch_backtransform(c->ws, n, num_pc, (c->flags & PCOA_FLAG_NO_SIGN_NORM) ? 0 : 1, c->out_dev,
-                                    c->stream));
+    HIP_TRY(c, launch_backtransform(c->ws, n, num_pc, (c->flags & PCOA_FLAG_NO_SIGN_NORM) ? 0 : 1,
+                                    have_vectors ? 0 : 1, c->out_dev, c->stream));
   }
   HIP_TRY(c, hipMemcpyAsync(out_components, c->out_dev, sizeof(double) * (size_t)num_pc * (size_t)n,
                             hipMemcpyDeviceToHost, c->stream));
@@ -798,6 +830,9 @@ int pcoa_get_timings(pcoa_ctx* c, pcoa_timings* out) {
   out->backtransform_seconds = c->tsec[T_BACK];
   out->compute_total_seconds = c->compute_total;
   out->gram_kernel_kind = c->gram_kind;
+  out->lanczos_seconds = c->tsec[T_LANCZOS];
+  out->eig_method = c->eig_method;
+  out->lanczos_steps = c->lanczos_steps;
   out->pack_seconds = c->tsec[T_PACK];
   out->pack_launches = c->pack_launches;
   out->pack_bytes = c->pack_bytes;

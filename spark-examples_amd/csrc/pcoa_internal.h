@@ -77,9 +77,14 @@ hipError_t launch_bisect(const EigWorkspace& ws, int32_t n, const int32_t* idx_h
 // eigenvectors of T for lam_sel[0..k) (host values) -> ws.z
 hipError_t launch_inverse_iteration(const EigWorkspace& ws, int32_t n, const double* lam_sel_host, int32_t k,
                                     hipStream_t stream);
-// ws.z <- Q * ws.z, normalise, sign-normalise (optional); out_dev[c*n + i] column-major
+// ws.z <- Q * ws.z (if apply_reflectors), normalise, sign-normalise (optional); out_dev[c*n + i] column-major
 hipError_t launch_backtransform(const EigWorkspace& ws, int32_t n, int32_t k, int sign_normalize,
-                                double* out_dev, hipStream_t stream);
+                                int apply_reflectors, double* out_dev, hipStream_t stream);
+
+// ---- Lanczos fast path (eig_lanczos.hip) ------------------------------------------------------
+size_t lanczos_workspace_doubles(int32_t n, int32_t k, int32_t mmax);
+hipError_t lanczos_topk(const EigWorkspace& ws, double* lz, int32_t n, int32_t k, int32_t mmax, double tol,
+                        double* lam_sel_host, int* converged, int* steps_out, hipStream_t stream);
 
 }  // namespace pcoa
 

@@ -26,8 +26,15 @@ def _ptr(a):
 
 
 class PcoaEngine(object):
-    def __init__(self, n_samples, device=0, flags=L.PCOA_FLAG_DEFAULT, gram_kernel=None):
-        """gram_kernel: None/"i8" (default: exact i8-MFMA path) or "f32" (fp32-MFMA path)."""
+    def __init__(self, n_samples, device=0, flags=L.PCOA_FLAG_DEFAULT, gram_kernel=None, eig=None):
+        """gram_kernel: None/"i8" (default: exact i8-MFMA path) or "f32" (fp32-MFMA path).
+        eig: None/"auto" (Lanczos with verified residual, Householder fallback), "householder", "lanczos"."""
+        if eig == "householder":
+            flags |= L.PCOA_FLAG_EIG_HOUSEHOLDER
+        elif eig == "lanczos":
+            flags |= L.PCOA_FLAG_EIG_LANCZOS
+        elif eig not in (None, "auto"):
+            raise ValueError("eig must be 'auto', 'householder' or 'lanczos'")
         if gram_kernel == "f32":
             flags |= L.PCOA_FLAG_GRAM_F32_MFMA
         elif gram_kernel not in (None, "i8"):

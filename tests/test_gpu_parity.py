@@ -285,15 +285,21 @@ def check_eigenpairs(comps, lam, ref_comps, ref_lam, b):
     assert np.abs(c.T @ c - np.eye(c.shape[1])).max() < 1e-10
 
 
+EIGS = ["auto", "householder"]  # Lanczos fast path (verified residual, fallback) and the dense solver
+
+
+@pytest.mark.parametrize("eig", EIGS)
 @pytest.mark.parametrize("n,v,k", [(6, 40, 2), (40, 300, 2), (64, 500, 3), (129, 800, 2), (500, 3000, 4)])
-def test_compute_pca_matches_oracle(P, O, n, v, k):
+def test_compute_pca_matches_oracle(P, O, n, v, k, eig):
     rng = np.random.default_rng(n * 31 + v)
     x = planted_callsets(rng, n, v, k=max(3, k + 1))
     s = O.similarity_from_dense(x, n)
     ref = O.compute_pca(s, k)
-    with P.PcoaEngine(n) as eng:
+    with P.PcoaEngine(n, eig=eig) as eng:
         eng.accumulate_dense(x)
         comps, lam, nz = eng.compute(k)
+        t = eng.timings()
+    assert t["eig_method"] == (2 if (eig == "householder" or n < 32) else 1)
     assert nz == ref["nonzero_rows"]
     check_eigenpairs(comps, lam, ref["components"], ref["eigenvalues"], ref["B"])
     # library output is sign-normalised exactly like the oracle's convention
@@ -302,27 +308,53 @@ def test_compute_pca_matches_oracle(P, O, n, v, k):
         assert comps[i, c] > 0
 
 
-def test_compute_pca_config2_sample_count(P, O):
-    """N = 2504 with planted 5-population structure: eigenpairs vs the MLlib-path oracle (dgesdd)."""
+@pytest.fixture(scope="module")
+def config2_reference(O):
     synth = load_pkg("synth")
     n, v, seed = 2504, 30000, 1002
     offs = synth.pop_offsets(n)
     thr = synth.thresholds(seed, 0, v)
     x = synth.genotypes(seed, 0, thr, offs)
     s = O.similarity_from_dense_blas(x)
-    ref = O.compute_pca(s, 2)
-    with P.PcoaEngine(n) as eng:
+    return n, seed, offs, thr, s, O.compute_pca(s, 2)
+
+
+@pytest.mark.parametrize("eig", EIGS + ["lanczos"])
+def test_compute_pca_config2_sample_count(P, O, config2_reference, eig):
+    """N = 2504 with planted 5-population structure: eigenpairs vs the MLlib-path oracle (dgesdd)."""
+    n, seed, offs, thr, s, ref = config2_reference
+    with P.PcoaEngine(n, eig=eig) as eng:
         eng.accumulate_synthetic(seed, offs, thr, 0)
         assert np.array_equal(eng.gram(), s)
         b, _, _, _ = eng.center()
         assert np.array_equal(b, ref["B"])
         comps, lam, nz = eng.compute(2)
+        comps, lam, nz = eng.compute(2)  # second call: workspaces warm
         t = eng.timings()
     check_eigenpairs(comps, lam, ref["components"], ref["eigenvalues"], ref["B"])
     assert nz == ref["nonzero_rows"]
-    print("PCoA wall %.1f ms (tridiag %.1f, eig %.1f, back %.1f)" %
-          (1e3 * t["compute_total_seconds"], 1e3 * t["tridiag_seconds"], 1e3 * t["eig_seconds"],
-           1e3 * t["backtransform_seconds"]))
+    print("PCoA wall [%s] %.2f ms (method %d, lanczos steps %d; lanczos %.2f, tridiag %.2f, eig %.2f, back %.2f per call)" %
+          (eig, 1e3 * t["compute_total_seconds"], t["eig_method"], t["lanczos_steps"], 0.5e3 * t["lanczos_seconds"],
+           0.5e3 * t["tridiag_seconds"], 0.5e3 * t["eig_seconds"], 0.5e3 * t["backtransform_seconds"]))
+
+
+def test_tiny_spectral_gap_falls_back_or_converges_correctly(P, O):
+    """Unstructured random genotypes: the top eigenvalues of B sit within a fraction of a percent of each
+    other.  Whatever path the engine takes (Lanczos if it verifies, else Householder), the result must be
+    a correct eigenpair: residual and eigenvalue are checked (eigenvectors are ill-conditioned here)."""
+    rng = np.random.default_rng(77)
+    n, v = 200, 5000
+    x = (rng.random((v, n)) < 0.3).astype(np.float32)
+    s = O.similarity_from_dense(x, n)
+    b = O.center_matrix(s)[0]
+    lam_ref = np.sort(np.linalg.eigvalsh(b))[::-1]
+    for eig in EIGS:
+        with P.PcoaEngine(n, eig=eig) as eng:
+            eng.accumulate_dense(x)
+            comps, lam, _ = eng.compute(2)
+        assert np.allclose(lam, lam_ref[:2], rtol=1e-9)
+        for c in range(2):
+            assert np.linalg.norm(b @ comps[:, c] - lam[c] * comps[:, c]) <= 1e-8 * abs(lam[c])
 
 
 def test_compute_from_loaded_matrix_entries_and_degenerate_inputs(P, O):
