@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--samples", type=int, default=N_SAMPLES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pcoa-reps", type=int, default=3)
+    ap.add_argument("--allreduce", choices=["native", "torch"], default="native",
+                    help="N>1: native = RCCL communicator inside libpcoa_hip (in-place int32), torch = "
+                         "export -> torch.distributed.all_reduce -> import")
     ap.add_argument("--gram-kernel", choices=["i8", "f32"], default="i8",
                     help="i8: pack fp32->int8 + v_mfma_i32_32x32x32_i8 (default); f32: v_mfma_f32_32x32x2_f32")
     args = ap.parse_args()
@@ -112,13 +115,35 @@ def main():
     eng.sync()
 
     scratch = None
+    native = None
+    allreduce_mode = "none"
+    if world > 1:
+        allreduce_mode = args.allreduce
+        if allreduce_mode == "native":
+            # every rank must end up on the same path: agree on success before using it
+            ok = 1
+            try:
+                native = dist.NativeComm(eng)
+            except Exception as exc:  # noqa: BLE001
+                sys.stderr.write("rank %d: native RCCL communicator failed (%s); using torch.distributed\n" % (rank, exc))
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            td.all_reduce(flag, op=td.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if native is not None:
+                    native.close()
+                native = None
+                allreduce_mode = "torch"
 
     def one_step():
         nonlocal scratch
         eng.reset()
         eng.accumulate_dense(x)
         if world > 1:
-            scratch = dist.allreduce_engine(eng, scratch=scratch)
+            if native is not None:
+                native.allreduce()
+            else:
+                scratch = dist.allreduce_engine(eng, scratch=scratch)
         else:
             eng.finalize()
 
@@ -212,6 +237,7 @@ def main():
             "config": {"workload": "configs[1]: synthetic %d samples x %d variants fp32 per GPU, resident in HBM "
                                    "(Gram + eig on rank 0)" % (n, v),
                        "n_samples": n, "variants_per_gpu": v, "seed": SEED, "parallelism": "variant-sharded x%d" % world,
+                       "allreduce": allreduce_mode,
                        "gram_kernel": kdesc},
             "roofline": roofline, "roofline_other": roofline_other,
             "gram_ms_per_step": 1e3 * tim["gram_kernel_seconds"] / steps,
@@ -241,6 +267,8 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
+    if native is not None:
+        native.close()
     if world > 1:
         td.barrier()
         td.destroy_process_group()

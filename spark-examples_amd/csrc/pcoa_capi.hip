@@ -60,6 +60,7 @@ struct pcoa_ctx {
   int64_t thr_cap = 0;
   int32_t* sample_pop = nullptr;   // [n]
   int64_t* xfer = nullptr;         // [n][n] int64 exchange buffer (lazy)
+  int64_t* coll = nullptr;         // 2 int64: {variants in S32, has-S64 flag} agreed across ranks
   int8_t* pack_buf = nullptr;      // k-blocked int8 workspace of the i8 path (lazy)
   int64_t pack_cap = 0;            // bytes
   bool use_i8 = true;              // i8-MFMA Gram (default) or fp32-MFMA Gram
@@ -421,7 +422,7 @@ void pcoa_destroy(pcoa_ctx* c) {
   for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto& ev : c->pool) (void)hipEventDestroy(ev);
   void* bufs[] = {c->s32, c->s64, c->zeros, c->err_flag, c->tile, c->csr_idx, c->csr_offs, c->thr_dev,
-                  c->sample_pop, c->xfer, c->pack_buf, c->lanczos_ws, c->ws.a, c->ws.d, c->ws.e, c->ws.tau, c->ws.q, c->ws.w, c->ws.lam,
+                  c->sample_pop, c->xfer, c->coll, c->pack_buf, c->lanczos_ws, c->ws.a, c->ws.d, c->ws.e, c->ws.tau, c->ws.q, c->ws.w, c->ws.lam,
                   c->ws.z, c->ws.scratch, c->ws.iscratch, c->ws.status, c->row_sums, c->stats, c->nz,
                   c->out_dev};
   for (void* b : bufs)
@@ -662,11 +663,31 @@ int pcoa_comm_destroy(void* nccl_comm) {
 int pcoa_gram_allreduce_rccl(pcoa_ctx* c, void* nccl_comm) {
   CHECK_CTX(c);
   if (!nccl_comm) return fail(c, PCOA_ERR_INVALID_ARG, "nccl_comm is NULL");
+  ncclComm_t comm = (ncclComm_t)nccl_comm;
   const size_t nn = (size_t)c->n * (size_t)c->n;
-  if (!c->xfer) HIP_TRY(c, hipMalloc((void**)&c->xfer, sizeof(int64_t) * nn));
-  int rc = pcoa_gram_export_device_i64(c, c->xfer);
+  int rc = finalize_impl(c);
   if (rc != PCOA_OK) return rc;
-  ncclResult_t r = ncclAllReduce(c->xfer, c->xfer, nn, ncclInt64, ncclSum, (ncclComm_t)nccl_comm, c->stream);
+  // All ranks must take the same branch: agree on {total variants held in int32 partials, anyone folded}.
+  if (!c->coll) HIP_TRY(c, hipMalloc((void**)&c->coll, 64));
+  int64_t mine[2] = {c->variants_in_s32, c->s64 ? 1 : 0};
+  int64_t all[2] = {0, 0};
+  HIP_TRY(c, hipMemcpyAsync(c->coll, mine, sizeof(mine), hipMemcpyHostToDevice, c->stream));
+  ncclResult_t r = ncclAllReduce(c->coll, c->coll, 2, ncclInt64, ncclSum, comm, c->stream);
+  if (r != ncclSuccess) return fail(c, PCOA_ERR_RCCL, std::string("ncclAllReduce(meta): ") + ncclGetErrorString(r));
+  HIP_TRY(c, hipMemcpyAsync(all, c->coll, sizeof(all), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (all[1] == 0 && all[0] < (((int64_t)1 << 31) - 1)) {
+    // fast path: every count fits int32 even after the sum -> reduce the 4*N^2-byte partial in place
+    r = ncclAllReduce(c->s32, c->s32, nn, ncclInt32, ncclSum, comm, c->stream);
+    if (r != ncclSuccess) return fail(c, PCOA_ERR_RCCL, std::string("ncclAllReduce(int32): ") + ncclGetErrorString(r));
+    c->variants_in_s32 = all[0];
+    c->have_data = true;
+    return PCOA_OK;
+  }
+  if (!c->xfer) HIP_TRY(c, hipMalloc((void**)&c->xfer, sizeof(int64_t) * nn));
+  rc = pcoa_gram_export_device_i64(c, c->xfer);
+  if (rc != PCOA_OK) return rc;
+  r = ncclAllReduce(c->xfer, c->xfer, nn, ncclInt64, ncclSum, comm, c->stream);
   if (r != ncclSuccess) return fail(c, PCOA_ERR_RCCL, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
   return pcoa_gram_import_device_i64(c, c->xfer);
 }

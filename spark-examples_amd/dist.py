@@ -49,6 +49,34 @@ def allreduce_engine(engine, group=None, scratch=None):
     return scratch
 
 
+class NativeComm(object):
+    """RCCL communicator owned by the C ABI (pcoa_comm_init): the all-reduce then runs on the engine's
+    own stream, in place on the int32 partial (25 MB at N = 2504) whenever the summed counts fit int32,
+    with no export/import copies.  The 128-byte unique id travels over torch.distributed once."""
+
+    def __init__(self, engine, group=None):
+        import torch
+        import torch.distributed as dist
+        self.engine = engine
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        dev = torch.device("cuda", engine.device)
+        if self.rank == 0:
+            uid = torch.tensor(list(engine.comm_unique_id()), dtype=torch.uint8, device=dev)
+        else:
+            uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        dist.broadcast(uid, src=0, group=group)
+        self.comm = engine.comm_init(bytes(uid.cpu().tolist()), self.rank, self.world)
+
+    def allreduce(self):
+        self.engine.allreduce_rccl(self.comm)
+
+    def close(self):
+        if self.comm is not None:
+            self.engine.comm_destroy(self.comm)
+            self.comm = None
+
+
 def allreduce_gram_numpy(s_local, group=None):
     """CPU twin used by the gloo tests: numpy int64 partial -> summed numpy int64."""
     import torch

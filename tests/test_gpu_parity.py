@@ -425,6 +425,12 @@ def test_torch_distributed_rccl_allreduce_single_rank(P, O):
             eng.import_device(scratch.data_ptr())
             assert np.array_equal(eng.gram(), want)
             assert dist.allreduce_engine(eng) is None
+            # the native communicator bootstrapped over torch.distributed (bench.py's N>1 path)
+            native = dist.NativeComm(eng)
+            eng.accumulate_dense(x)
+            native.allreduce()
+            assert np.array_equal(eng.gram(), 2 * want)
+            native.close()
     finally:
         td.destroy_process_group()
 
