@@ -127,23 +127,35 @@ __device__ __forceinline__ void issue_stage_i8(StageI8* st, const int8_t* __rest
   }
 }
 
-__device__ __forceinline__ void compute_stage_i8(const StageI8* st, int wm, int wn, int lane, i32x16 (&acc)[4][2]) {
+// Fragment registers of one stage: 2 k32-steps x (4 A + 2 B) x 16 B = 48 VGPRs.
+struct FragsI8 {
+  i32x4 a[SKB / 2][4];
+  i32x4 b[SKB / 2][2];
+};
+
+// All 12 ds_read_b128 of the stage are issued back to back (consumption order = issue order, so the
+// compiler's counted lgkmcnt lets the first MFMAs start while later fragments are still in flight).
+__device__ __forceinline__ void load_frags_i8(const StageI8* st, int wm, int wn, int lane, FragsI8& f) {
   const int l31 = lane & 31, hi = lane >> 5;
 #pragma unroll
   for (int k2 = 0; k2 < SKB / 2; ++k2) {
-    i32x4 a[4], b[2];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
-      a[mi] = *reinterpret_cast<const i32x4*>(&st->p[0][2 * k2 + hi][wm * 128 + mi * 32 + l31][0]);
+      f.a[k2][mi] = *reinterpret_cast<const i32x4*>(&st->p[0][2 * k2 + hi][wm * 128 + mi * 32 + l31][0]);
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
-      b[ni] = *reinterpret_cast<const i32x4*>(&st->p[1][2 * k2 + hi][wn * 64 + ni * 32 + l31][0]);
+      f.b[k2][ni] = *reinterpret_cast<const i32x4*>(&st->p[1][2 * k2 + hi][wn * 64 + ni * 32 + l31][0]);
+  }
+}
+
+__device__ __forceinline__ void mfma_stage_i8(const FragsI8& f, i32x16 (&acc)[4][2]) {
+#pragma unroll
+  for (int k2 = 0; k2 < SKB / 2; ++k2)
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
-        acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-  }
+        acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[k2][mi], f.b[k2][ni], acc[mi][ni], 0, 0, 0);
 }
 
 template <int BUF>
@@ -153,9 +165,14 @@ __device__ __forceinline__ void ring_step(StageI8* lds, const int8_t* __restrict
   // stage s (buffer BUF) must have landed; stage s+1 may stay in flight
   if (s + 1 < ns) wait_vmcnt<4>(); else wait_vmcnt<0>();
   wg_barrier();  // all waves' stage-s DMA landed, and all waves are done reading buffer (BUF+2)%3
+  FragsI8 f;
+  load_frags_i8(&lds[BUF], wm, wn, lane, f);
+  __builtin_amdgcn_sched_barrier(0);
+  // the DMA of stage s+2 is issued under the LDS latency of the fragment reads
   if (s + 2 < ns)
     issue_stage_i8(&lds[(BUF + 2) % NSTAGE], p, npad, kb_begin + (int64_t)(s + 2) * SKB, col_i, col_j, wave, lane);
-  compute_stage_i8(&lds[BUF], wm, wn, lane, acc);
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_stage_i8(f, acc);
 }
 
 __global__ __launch_bounds__(NT) void gram_i8_kernel(const int8_t* __restrict__ p, int npad, int64_t nstages,
