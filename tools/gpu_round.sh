@@ -41,7 +41,7 @@ for s in $STEPS; do
       ( cd /tmp && timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $OLDPWD/$OUT/pmc_sq -o pmc -- python $OLDPWD/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --pcoa-reps 1 > /dev/null 2> $OLDPWD/$OUT/pmc_sq.err )
       echo "pmc sq exit $?" | tee -a $OUT/summary.txt
       python tools/pmc_summary.py $OUT | tee -a $OUT/summary.txt
-      find $OUT -name "*counter_collection*" -size +4M -delete ;;
+      cp $OUT/pmc_summary.json $OUT/pmc_summary_full.json; find $OUT -name "*counter_collection*" -size +4M -delete ;;
   esac
 done
 echo "== done $(date)" | tee -a $OUT/summary.txt
