@@ -25,15 +25,16 @@
 //
 // Roofline: i8 MFMA, peak ~5 POP/s dense (2x the bf16 rate, MI355X_MICROARCH.md); algorithmic
 // intensity of the packed operands N/0.5 = 5008 op/B, so HBM is irrelevant once packed.
+#include <cstdlib>
+
 #include "pcoa_internal.h"
 
 namespace pcoa {
 namespace {
 
-constexpr int TM = 256;        // tile edge in samples
+constexpr int TM = 256;        // padding granule of the packed operand (samples)
 constexpr int KB = 16;         // variants per k-block (one lane's operand slice)
 constexpr int SKB = 4;         // k-blocks per stage -> 64 variants
-constexpr int NT = 512;        // threads per workgroup (8 waves)
 constexpr int NSTAGE = 3;
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -108,22 +109,38 @@ __global__ __launch_bounds__(256) void pack_f32_i8_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------- gemm
+// Templated on NWM = waves along M.  NWM = 2: 256x256 tile, 512 threads, 96 KiB LDS, one workgroup
+// per CU.  NWM = 1: 128x256 tile, 256 threads, 72 KiB LDS, TWO workgroups per CU -- the same 8 waves
+// per CU, but in two independently phased groups with half-size barriers, so one group's
+// barrier + LDS-read phase overlaps the other's MFMA phase.  The wave code is identical.
+constexpr int TJ = 256;  // tile width (panel J) in samples
+
+template <int NWM>
 struct StageI8 {
-  int8_t p[2][SKB][TM][KB];  // [panel][k-block][sample][16 B] = 32 KiB
+  int8_t pi[SKB][128 * NWM][KB];  // panel I: [k-block][sample][16 B]
+  int8_t pj[SKB][TJ][KB];         // panel J
 };
 
-// 32 DMA instructions per stage, 4 per wave.
-__device__ __forceinline__ void issue_stage_i8(StageI8* st, const int8_t* __restrict__ p, int npad, int64_t kb0,
-                                               int col_i, int col_j, int wave, int lane) {
+// DMA instructions per stage: SKB * (2*NWM + 4) of 1 KiB each, spread evenly over the 4*NWM waves.
+template <int NWM>
+__device__ __forceinline__ void issue_stage_i8(StageI8<NWM>* st, const int8_t* __restrict__ p, int npad,
+                                               int64_t kb0, int col_i, int col_j, int wave, int lane) {
+  constexpr int QI = 2 * NWM;              // 64-sample quarters in panel I
+  constexpr int PER_KB = QI + 4;           // instructions per k-block
+  constexpr int TOTAL = SKB * PER_KB;
+  constexpr int PER_WAVE = TOTAL / (4 * NWM);
+  static_assert(TOTAL % (4 * NWM) == 0, "DMA instructions must divide evenly over the waves");
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int id = wave * 4 + q;       // 0..31
-    const int pnl = id >> 4;
-    const int kb = (id >> 2) & 3;
-    const int sq = id & 3;             // which 64-sample quarter of the panel
-    const int c0 = (pnl == 0 ? col_i : col_j) + sq * 64;
+  for (int q = 0; q < PER_WAVE; ++q) {
+    const int id = wave * PER_WAVE + q;
+    const int kb = id / PER_KB;
+    const int r = id - kb * PER_KB;
+    const bool is_i = r < QI;
+    const int sq = is_i ? r : r - QI;
+    const int c0 = (is_i ? col_i : col_j) + sq * 64;
     const int8_t* src = p + ((size_t)(kb0 + kb) * npad + c0 + lane) * KB;
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)&st->p[pnl][kb][sq * 64][0], 16, 0, 0);
+    int8_t* dst = is_i ? &st->pi[kb][sq * 64][0] : &st->pj[kb][sq * 64][0];
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
   }
 }
 
@@ -133,18 +150,18 @@ struct FragsI8 {
   i32x4 b[SKB / 2][2];
 };
 
-// All 12 ds_read_b128 of the stage are issued back to back (consumption order = issue order, so the
-// compiler's counted lgkmcnt lets the first MFMAs start while later fragments are still in flight).
-__device__ __forceinline__ void load_frags_i8(const StageI8* st, int wm, int wn, int lane, FragsI8& f) {
+// All 12 ds_read_b128 of the stage are issued back to back (consumption order = issue order).
+template <int NWM>
+__device__ __forceinline__ void load_frags_i8(const StageI8<NWM>* st, int wm, int wn, int lane, FragsI8& f) {
   const int l31 = lane & 31, hi = lane >> 5;
 #pragma unroll
   for (int k2 = 0; k2 < SKB / 2; ++k2) {
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
-      f.a[k2][mi] = *reinterpret_cast<const i32x4*>(&st->p[0][2 * k2 + hi][wm * 128 + mi * 32 + l31][0]);
+      f.a[k2][mi] = *reinterpret_cast<const i32x4*>(&st->pi[2 * k2 + hi][wm * 128 + mi * 32 + l31][0]);
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
-      f.b[k2][ni] = *reinterpret_cast<const i32x4*>(&st->p[1][2 * k2 + hi][wn * 64 + ni * 32 + l31][0]);
+      f.b[k2][ni] = *reinterpret_cast<const i32x4*>(&st->pj[2 * k2 + hi][wn * 64 + ni * 32 + l31][0]);
   }
 }
 
@@ -158,27 +175,52 @@ __device__ __forceinline__ void mfma_stage_i8(const FragsI8& f, i32x16 (&acc)[4]
         acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[k2][mi], f.b[k2][ni], acc[mi][ni], 0, 0, 0);
 }
 
-template <int BUF>
-__device__ __forceinline__ void ring_step(StageI8* lds, const int8_t* __restrict__ p, int npad, int64_t kb_begin,
-                                          int s, int ns, int col_i, int col_j, int wave, int lane, int wm, int wn,
-                                          i32x16 (&acc)[4][2]) {
+template <int NWM, int BUF>
+__device__ __forceinline__ void ring_step(StageI8<NWM>* lds, const int8_t* __restrict__ p, int npad,
+                                          int64_t kb_begin, int s, int ns, int col_i, int col_j, int wave, int lane,
+                                          int wm, int wn, i32x16 (&acc)[4][2]) {
+  constexpr int PER_WAVE = SKB * (2 * NWM + 4) / (4 * NWM);
   // stage s (buffer BUF) must have landed; stage s+1 may stay in flight
-  if (s + 1 < ns) wait_vmcnt<4>(); else wait_vmcnt<0>();
+  if (s + 1 < ns) wait_vmcnt<PER_WAVE>(); else wait_vmcnt<0>();
   wg_barrier();  // all waves' stage-s DMA landed, and all waves are done reading buffer (BUF+2)%3
   FragsI8 f;
-  load_frags_i8(&lds[BUF], wm, wn, lane, f);
+  load_frags_i8<NWM>(&lds[BUF], wm, wn, lane, f);
   __builtin_amdgcn_sched_barrier(0);
   // the DMA of stage s+2 is issued under the LDS latency of the fragment reads
   if (s + 2 < ns)
-    issue_stage_i8(&lds[(BUF + 2) % NSTAGE], p, npad, kb_begin + (int64_t)(s + 2) * SKB, col_i, col_j, wave, lane);
+    issue_stage_i8<NWM>(&lds[(BUF + 2) % NSTAGE], p, npad, kb_begin + (int64_t)(s + 2) * SKB, col_i, col_j, wave,
+                        lane);
   __builtin_amdgcn_sched_barrier(0);
   mfma_stage_i8(f, acc);
 }
 
-__global__ __launch_bounds__(NT) void gram_i8_kernel(const int8_t* __restrict__ p, int npad, int64_t nstages,
-                                                     int n, int ntile, int ntri, int splitk, int64_t stages_per,
-                                                     int32_t* __restrict__ s32, int xcd_map) {
-  __shared__ __attribute__((aligned(16))) StageI8 lds[NSTAGE];
+// Tile enumeration over the upper triangle.  Row blocks are 128*NWM samples, column blocks 256.
+//   NWM = 2: (ti, tj) with ti <= tj, T(T+1)/2 tiles.
+//   NWM = 1: row block r in [0, 2T), column block c >= r/2: T(T+1) tiles (half the size each).
+template <int NWM>
+__device__ __forceinline__ void tile_coords(int tile, int ntile, int& row_blk, int& col_blk) {
+  int sup = 0, rem = tile;  // super-row = 256-sample row block
+  const int per = (NWM == 2) ? 1 : 2;
+  while (rem >= per * (ntile - sup)) {
+    rem -= per * (ntile - sup);
+    ++sup;
+  }
+  if (NWM == 2) {
+    row_blk = sup;
+    col_blk = sup + rem;
+  } else {
+    const int half = rem / (ntile - sup);
+    row_blk = 2 * sup + half;
+    col_blk = sup + (rem - half * (ntile - sup));
+  }
+}
+
+template <int NWM>
+__global__ __launch_bounds__(256 * NWM, 2) void gram_i8_kernel(const int8_t* __restrict__ p, int npad, int64_t nstages,
+                                                            int n, int ntile, int ntri, int splitk,
+                                                            int64_t stages_per, int32_t* __restrict__ s32,
+                                                            int xcd_map) {
+  __shared__ __attribute__((aligned(16))) StageI8<NWM> lds[NSTAGE];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -194,19 +236,15 @@ __global__ __launch_bounds__(NT) void gram_i8_kernel(const int8_t* __restrict__ 
     tile = b % ntri;
     ks = b / ntri;
   }
-  int ti = 0, rem = tile;
-  while (rem >= ntile - ti) {
-    rem -= ntile - ti;
-    ++ti;
-  }
-  const int tj = ti + rem;
+  int row_blk, col_blk;
+  tile_coords<NWM>(tile, ntile, row_blk, col_blk);
 
   const int64_t st_begin = (int64_t)ks * stages_per;
   const int64_t st_end = (st_begin + stages_per < nstages) ? (st_begin + stages_per) : nstages;
   if (st_begin >= st_end) return;
   const int ns = (int)(st_end - st_begin);
   const int64_t kb_begin = st_begin * SKB;
-  const int col_i = ti * TM, col_j = tj * TM;
+  const int col_i = row_blk * 128 * NWM, col_j = col_blk * TJ;
 
   i32x16 acc[4][2];
 #pragma unroll
@@ -216,21 +254,22 @@ __global__ __launch_bounds__(NT) void gram_i8_kernel(const int8_t* __restrict__ 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0;
 
-  issue_stage_i8(&lds[0], p, npad, kb_begin, col_i, col_j, wave, lane);
-  if (ns > 1) issue_stage_i8(&lds[1], p, npad, kb_begin + SKB, col_i, col_j, wave, lane);
+  issue_stage_i8<NWM>(&lds[0], p, npad, kb_begin, col_i, col_j, wave, lane);
+  if (ns > 1) issue_stage_i8<NWM>(&lds[1], p, npad, kb_begin + SKB, col_i, col_j, wave, lane);
 
   int s = 0;
   for (; s + 2 < ns; s += 3) {
-    ring_step<0>(lds, p, npad, kb_begin, s, ns, col_i, col_j, wave, lane, wm, wn, acc);
-    ring_step<1>(lds, p, npad, kb_begin, s + 1, ns, col_i, col_j, wave, lane, wm, wn, acc);
-    ring_step<2>(lds, p, npad, kb_begin, s + 2, ns, col_i, col_j, wave, lane, wm, wn, acc);
+    ring_step<NWM, 0>(lds, p, npad, kb_begin, s, ns, col_i, col_j, wave, lane, wm, wn, acc);
+    ring_step<NWM, 1>(lds, p, npad, kb_begin, s + 1, ns, col_i, col_j, wave, lane, wm, wn, acc);
+    ring_step<NWM, 2>(lds, p, npad, kb_begin, s + 2, ns, col_i, col_j, wave, lane, wm, wn, acc);
   }
   if (s < ns) {
-    ring_step<0>(lds, p, npad, kb_begin, s, ns, col_i, col_j, wave, lane, wm, wn, acc);
-    if (s + 1 < ns) ring_step<1>(lds, p, npad, kb_begin, s + 1, ns, col_i, col_j, wave, lane, wm, wn, acc);
+    ring_step<NWM, 0>(lds, p, npad, kb_begin, s, ns, col_i, col_j, wave, lane, wm, wn, acc);
+    if (s + 1 < ns) ring_step<NWM, 1>(lds, p, npad, kb_begin, s + 1, ns, col_i, col_j, wave, lane, wm, wn, acc);
   }
 
-  // epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  // epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+  // Only the upper triangle (j >= i) is authoritative; pcoa_gram_finalize mirrors it.
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
@@ -240,7 +279,7 @@ __global__ __launch_bounds__(NT) void gram_i8_kernel(const int8_t* __restrict__ 
       for (int r = 0; r < 16; ++r) {
         const int i = col_i + wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int v = acc[mi][ni][r];
-        if (i < n && j < n && v != 0) atomicAdd(&s32[(int64_t)i * n + j], v);
+        if (j >= i && j < n && v != 0) atomicAdd(&s32[(int64_t)i * n + j], v);
       }
     }
   }
@@ -278,14 +317,18 @@ hipError_t launch_pack_f32_i8(const float* x, int64_t ld, int64_t nv, int32_t n,
 hipError_t launch_gram_i8_packed(const int8_t* p, int64_t nv, int32_t n, int32_t* s32, int num_cu,
                                  hipStream_t stream, int* splitk_out) {
   if (nv <= 0) return hipSuccess;
+  static const int variant = [] {  // PCOA_GRAM_I8_TILE=256 selects the 256x256 / 512-thread variant
+    const char* v = std::getenv("PCOA_GRAM_I8_TILE");
+    return (v && std::atoi(v) == 256) ? 2 : 1;
+  }();
   const int npad = (int)gram_i8_npad(n);
-  const int ntile = npad / TM;
-  const int64_t ntri64 = (int64_t)ntile * (ntile + 1) / 2;
+  const int ntile = npad / TJ;
+  const int64_t ntri64 = (int64_t)ntile * (ntile + 1) / 2 * (variant == 2 ? 1 : 2);
   if (ntri64 > (1 << 28)) return hipErrorInvalidValue;
   const int ntri = (int)ntri64;
   const int64_t nstages = gram_i8_kb_pad(nv) / SKB;
-  // one 512-thread workgroup per CU is resident; aim at ~7 work units per CU, >= 16 stages each
-  const int64_t target = (int64_t)(num_cu > 0 ? num_cu : 256) * 7;
+  // resident workgroups per CU: 1 (256x256) or 2 (128x256); aim at ~7 rounds of work per slot, >= 16 stages each
+  const int64_t target = (int64_t)(num_cu > 0 ? num_cu : 256) * (variant == 2 ? 7 : 14);
   int64_t splitk = (target + ntri - 1) / ntri;
   const int64_t max_by_work = nstages / 16;
   if (splitk > max_by_work) splitk = max_by_work;
@@ -299,8 +342,12 @@ hipError_t launch_gram_i8_packed(const int8_t* p, int64_t nv, int32_t n, int32_t
   const int64_t nblocks = (int64_t)ntri * splitk;
   if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
   if (splitk_out) *splitk_out = (int)splitk;
-  hipLaunchKernelGGL(gram_i8_kernel, dim3((unsigned)nblocks), dim3(NT), 0, stream, p, npad, nstages, n, ntile,
-                     ntri, (int)splitk, stages_per, s32, xcd_map);
+  if (variant == 2)
+    hipLaunchKernelGGL(gram_i8_kernel<2>, dim3((unsigned)nblocks), dim3(512), 0, stream, p, npad, nstages, n, ntile,
+                       ntri, (int)splitk, stages_per, s32, xcd_map);
+  else
+    hipLaunchKernelGGL(gram_i8_kernel<1>, dim3((unsigned)nblocks), dim3(256), 0, stream, p, npad, nstages, n, ntile,
+                       ntri, (int)splitk, stages_per, s32, xcd_map);
   return hipGetLastError();
 }
 
