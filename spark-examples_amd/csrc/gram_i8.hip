@@ -122,14 +122,14 @@ struct StageI8 {
 };
 
 // DMA instructions per stage: SKB * (2*NWM + 4) of 1 KiB each, spread evenly over the 4*NWM waves.
-template <int NWM>
+template <int NWM, int NWAVES>
 __device__ __forceinline__ void issue_stage_i8(StageI8<NWM>* st, const int8_t* __restrict__ p, int npad,
                                                int64_t kb0, int col_i, int col_j, int wave, int lane) {
   constexpr int QI = 2 * NWM;              // 64-sample quarters in panel I
   constexpr int PER_KB = QI + 4;           // instructions per k-block
   constexpr int TOTAL = SKB * PER_KB;
-  constexpr int PER_WAVE = TOTAL / (4 * NWM);
-  static_assert(TOTAL % (4 * NWM) == 0, "DMA instructions must divide evenly over the waves");
+  constexpr int PER_WAVE = TOTAL / NWAVES;
+  static_assert(TOTAL % NWAVES == 0, "DMA instructions must divide evenly over the waves");
 #pragma unroll
   for (int q = 0; q < PER_WAVE; ++q) {
     const int id = wave * PER_WAVE + q;
@@ -144,15 +144,16 @@ __device__ __forceinline__ void issue_stage_i8(StageI8<NWM>* st, const int8_t* _
   }
 }
 
-// Fragment registers of one stage: 2 k32-steps x (4 A + 2 B) x 16 B = 48 VGPRs.
+// Fragment registers of one stage: 2 k32-steps x (4 A + NNI B) x 16 B (NNI = 2: 48 VGPRs, NNI = 4: 64).
+template <int NNI>
 struct FragsI8 {
   i32x4 a[SKB / 2][4];
-  i32x4 b[SKB / 2][2];
+  i32x4 b[SKB / 2][NNI];
 };
 
-// All 12 ds_read_b128 of the stage are issued back to back (consumption order = issue order).
-template <int NWM>
-__device__ __forceinline__ void load_frags_i8(const StageI8<NWM>* st, int wm, int wn, int lane, FragsI8& f) {
+// All ds_read_b128 of the stage are issued back to back (consumption order = issue order).
+template <int NWM, int NNI>
+__device__ __forceinline__ void load_frags_i8(const StageI8<NWM>* st, int wm, int wn, int lane, FragsI8<NNI>& f) {
   const int l31 = lane & 31, hi = lane >> 5;
 #pragma unroll
   for (int k2 = 0; k2 < SKB / 2; ++k2) {
@@ -160,38 +161,40 @@ __device__ __forceinline__ void load_frags_i8(const StageI8<NWM>* st, int wm, in
     for (int mi = 0; mi < 4; ++mi)
       f.a[k2][mi] = *reinterpret_cast<const i32x4*>(&st->pi[2 * k2 + hi][wm * 128 + mi * 32 + l31][0]);
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-      f.b[k2][ni] = *reinterpret_cast<const i32x4*>(&st->pj[2 * k2 + hi][wn * 64 + ni * 32 + l31][0]);
+    for (int ni = 0; ni < NNI; ++ni)
+      f.b[k2][ni] = *reinterpret_cast<const i32x4*>(&st->pj[2 * k2 + hi][wn * 32 * NNI + ni * 32 + l31][0]);
   }
 }
 
-__device__ __forceinline__ void mfma_stage_i8(const FragsI8& f, i32x16 (&acc)[4][2]) {
+template <int NNI>
+__device__ __forceinline__ void mfma_stage_i8(const FragsI8<NNI>& f, i32x16 (&acc)[4][NNI]) {
 #pragma unroll
   for (int k2 = 0; k2 < SKB / 2; ++k2)
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int ni = 0; ni < NNI; ++ni)
         acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[k2][mi], f.b[k2][ni], acc[mi][ni], 0, 0, 0);
 }
 
-template <int NWM, int BUF>
+template <int NWM, int NNI, int BUF>
 __device__ __forceinline__ void ring_step(StageI8<NWM>* lds, const int8_t* __restrict__ p, int npad,
                                           int64_t kb_begin, int s, int ns, int col_i, int col_j, int wave, int lane,
-                                          int wm, int wn, i32x16 (&acc)[4][2]) {
-  constexpr int PER_WAVE = SKB * (2 * NWM + 4) / (4 * NWM);
+                                          int wm, int wn, i32x16 (&acc)[4][NNI]) {
+  constexpr int NWAVES = NWM * (8 / NNI);
+  constexpr int PER_WAVE = SKB * (2 * NWM + 4) / NWAVES;
   // stage s (buffer BUF) must have landed; stage s+1 may stay in flight
   if (s + 1 < ns) wait_vmcnt<PER_WAVE>(); else wait_vmcnt<0>();
   wg_barrier();  // all waves' stage-s DMA landed, and all waves are done reading buffer (BUF+2)%3
-  FragsI8 f;
-  load_frags_i8<NWM>(&lds[BUF], wm, wn, lane, f);
+  FragsI8<NNI> f;
+  load_frags_i8<NWM, NNI>(&lds[BUF], wm, wn, lane, f);
   __builtin_amdgcn_sched_barrier(0);
   // the DMA of stage s+2 is issued under the LDS latency of the fragment reads
   if (s + 2 < ns)
-    issue_stage_i8<NWM>(&lds[(BUF + 2) % NSTAGE], p, npad, kb_begin + (int64_t)(s + 2) * SKB, col_i, col_j, wave,
-                        lane);
+    issue_stage_i8<NWM, NWAVES>(&lds[(BUF + 2) % NSTAGE], p, npad, kb_begin + (int64_t)(s + 2) * SKB, col_i, col_j,
+                                wave, lane);
   __builtin_amdgcn_sched_barrier(0);
-  mfma_stage_i8(f, acc);
+  mfma_stage_i8<NNI>(f, acc);
 }
 
 // Tile enumeration over the upper triangle.  Row blocks are 128*NWM samples, column blocks 256.
@@ -215,8 +218,11 @@ __device__ __forceinline__ void tile_coords(int tile, int ntile, int& row_blk, i
   }
 }
 
-template <int NWM>
-__global__ __launch_bounds__(256 * NWM, 2) void gram_i8_kernel(const int8_t* __restrict__ p, int npad, int64_t nstages,
+// NNI = 32-column MFMA tiles per wave along N: 2 -> wave tile 128x64, 4 waves along N, two waves per
+// SIMD; 4 -> wave tile 128x128 (256 accumulators), 2 waves along N, ONE wave per SIMD but only 0.5
+// instead of 0.75 fragment reads per MFMA (LDS bandwidth is the co-limiter of this kernel).
+template <int NWM, int NNI>
+__global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram_i8_kernel(const int8_t* __restrict__ p, int npad, int64_t nstages,
                                                             int n, int ntile, int ntri, int splitk,
                                                             int64_t stages_per, int32_t* __restrict__ s32,
                                                             int xcd_map) {
@@ -224,7 +230,9 @@ __global__ __launch_bounds__(256 * NWM, 2) void gram_i8_kernel(const int8_t* __r
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  constexpr int NWN = 8 / NNI;  // waves along N
+  constexpr int NWAVES = NWM * NWN;
+  const int wm = wave / NWN, wn = wave % NWN;
 
   int tile, ks;
   const int b = blockIdx.x;
@@ -246,26 +254,27 @@ __global__ __launch_bounds__(256 * NWM, 2) void gram_i8_kernel(const int8_t* __r
   const int64_t kb_begin = st_begin * SKB;
   const int col_i = row_blk * 128 * NWM, col_j = col_blk * TJ;
 
-  i32x16 acc[4][2];
+  i32x16 acc[4][NNI];
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+    for (int ni = 0; ni < NNI; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0;
 
-  issue_stage_i8<NWM>(&lds[0], p, npad, kb_begin, col_i, col_j, wave, lane);
-  if (ns > 1) issue_stage_i8<NWM>(&lds[1], p, npad, kb_begin + SKB, col_i, col_j, wave, lane);
+  issue_stage_i8<NWM, NWAVES>(&lds[0], p, npad, kb_begin, col_i, col_j, wave, lane);
+  if (ns > 1) issue_stage_i8<NWM, NWAVES>(&lds[1], p, npad, kb_begin + SKB, col_i, col_j, wave, lane);
 
   int s = 0;
   for (; s + 2 < ns; s += 3) {
-    ring_step<NWM, 0>(lds, p, npad, kb_begin, s, ns, col_i, col_j, wave, lane, wm, wn, acc);
-    ring_step<NWM, 1>(lds, p, npad, kb_begin, s + 1, ns, col_i, col_j, wave, lane, wm, wn, acc);
-    ring_step<NWM, 2>(lds, p, npad, kb_begin, s + 2, ns, col_i, col_j, wave, lane, wm, wn, acc);
+    ring_step<NWM, NNI, 0>(lds, p, npad, kb_begin, s, ns, col_i, col_j, wave, lane, wm, wn, acc);
+    ring_step<NWM, NNI, 1>(lds, p, npad, kb_begin, s + 1, ns, col_i, col_j, wave, lane, wm, wn, acc);
+    ring_step<NWM, NNI, 2>(lds, p, npad, kb_begin, s + 2, ns, col_i, col_j, wave, lane, wm, wn, acc);
   }
   if (s < ns) {
-    ring_step<NWM, 0>(lds, p, npad, kb_begin, s, ns, col_i, col_j, wave, lane, wm, wn, acc);
-    if (s + 1 < ns) ring_step<NWM, 1>(lds, p, npad, kb_begin, s + 1, ns, col_i, col_j, wave, lane, wm, wn, acc);
+    ring_step<NWM, NNI, 0>(lds, p, npad, kb_begin, s, ns, col_i, col_j, wave, lane, wm, wn, acc);
+    if (s + 1 < ns)
+      ring_step<NWM, NNI, 1>(lds, p, npad, kb_begin, s + 1, ns, col_i, col_j, wave, lane, wm, wn, acc);
   }
 
   // epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
@@ -273,8 +282,8 @@ __global__ __launch_bounds__(256 * NWM, 2) void gram_i8_kernel(const int8_t* __r
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int j = col_j + wn * 64 + ni * 32 + (lane & 31);
+    for (int ni = 0; ni < NNI; ++ni) {
+      const int j = col_j + wn * 32 * NNI + ni * 32 + (lane & 31);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = col_i + wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -317,18 +326,22 @@ hipError_t launch_pack_f32_i8(const float* x, int64_t ld, int64_t nv, int32_t n,
 hipError_t launch_gram_i8_packed(const int8_t* p, int64_t nv, int32_t n, int32_t* s32, int num_cu,
                                  hipStream_t stream, int* splitk_out) {
   if (nv <= 0) return hipSuccess;
-  static const int variant = [] {  // PCOA_GRAM_I8_TILE=256 selects the 256x256 / 512-thread variant
+  // variants: 2 = 256x256 tile, 8 waves, wave tile 128x64 (default; measured 2.41 ms per 10^6 variants);
+  //           1 = 128x256 tile, 4 waves, two workgroups per CU (measured 2.88 ms);
+  //           3 = 256x256 tile, 4 waves (one per SIMD), wave tile 128x128.
+  static const int variant = [] {
     const char* v = std::getenv("PCOA_GRAM_I8_TILE");
-    return (v && std::atoi(v) == 256) ? 2 : 1;
+    const int t = v ? std::atoi(v) : 256;
+    return t == 128 ? 1 : (t == 2561 ? 3 : 2);
   }();
   const int npad = (int)gram_i8_npad(n);
   const int ntile = npad / TJ;
-  const int64_t ntri64 = (int64_t)ntile * (ntile + 1) / 2 * (variant == 2 ? 1 : 2);
+  const int64_t ntri64 = (int64_t)ntile * (ntile + 1) / 2 * (variant == 1 ? 2 : 1);
   if (ntri64 > (1 << 28)) return hipErrorInvalidValue;
   const int ntri = (int)ntri64;
   const int64_t nstages = gram_i8_kb_pad(nv) / SKB;
   // resident workgroups per CU: 1 (256x256) or 2 (128x256); aim at ~7 rounds of work per slot, >= 16 stages each
-  const int64_t target = (int64_t)(num_cu > 0 ? num_cu : 256) * (variant == 2 ? 7 : 14);
+  const int64_t target = (int64_t)(num_cu > 0 ? num_cu : 256) * (variant == 1 ? 14 : 7);
   int64_t splitk = (target + ntri - 1) / ntri;
   const int64_t max_by_work = nstages / 16;
   if (splitk > max_by_work) splitk = max_by_work;
@@ -343,11 +356,14 @@ hipError_t launch_gram_i8_packed(const int8_t* p, int64_t nv, int32_t n, int32_t
   if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
   if (splitk_out) *splitk_out = (int)splitk;
   if (variant == 2)
-    hipLaunchKernelGGL(gram_i8_kernel<2>, dim3((unsigned)nblocks), dim3(512), 0, stream, p, npad, nstages, n, ntile,
-                       ntri, (int)splitk, stages_per, s32, xcd_map);
+    hipLaunchKernelGGL((gram_i8_kernel<2, 2>), dim3((unsigned)nblocks), dim3(512), 0, stream, p, npad, nstages, n,
+                       ntile, ntri, (int)splitk, stages_per, s32, xcd_map);
+  else if (variant == 3)
+    hipLaunchKernelGGL((gram_i8_kernel<2, 4>), dim3((unsigned)nblocks), dim3(256), 0, stream, p, npad, nstages, n,
+                       ntile, ntri, (int)splitk, stages_per, s32, xcd_map);
   else
-    hipLaunchKernelGGL(gram_i8_kernel<1>, dim3((unsigned)nblocks), dim3(256), 0, stream, p, npad, nstages, n, ntile,
-                       ntri, (int)splitk, stages_per, s32, xcd_map);
+    hipLaunchKernelGGL((gram_i8_kernel<1, 2>), dim3((unsigned)nblocks), dim3(256), 0, stream, p, npad, nstages, n,
+                       ntile, ntri, (int)splitk, stages_per, s32, xcd_map);
   return hipGetLastError();
 }
 

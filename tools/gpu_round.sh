@@ -25,7 +25,7 @@ for s in $STEPS; do
       timeout 900 python bench.py --gpus 1 --steps 5 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
       echo "bench exit $?" | tee -a $OUT/summary.txt; cat $OUT/bench.json | tee -a $OUT/summary.txt; tail -5 $OUT/bench.err ;;
     benchab)
-      for t in 128 256 128 256; do
+      for t in 256 2561 256 2561; do
         PCOA_GRAM_I8_TILE=$t timeout 600 python bench.py --gpus 1 --steps 8 --warmup 2 --no-cpu-baseline --pcoa-reps 1 > $OUT/bench_tile$t.json 2>> $OUT/bench_ab.err
         python -c "import json,sys; d=json.load(open('$OUT/bench_tile$t.json')); print('tile $t: value %.1f M/s, ms/step %.3f, gram %.3f ms, pack %.3f ms' % (d['value']/1e6, d['ms_per_step'], d['gram_ms_per_step'], d['pack_ms_per_step']))" | tee -a $OUT/summary.txt
       done ;;
