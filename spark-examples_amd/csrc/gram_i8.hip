@@ -34,8 +34,6 @@ namespace {
 
 constexpr int TM = 256;        // padding granule of the packed operand (samples)
 constexpr int KB = 16;         // variants per k-block (one lane's operand slice)
-constexpr int SKB = 4;         // k-blocks per stage -> 64 variants
-constexpr int NSTAGE = 3;
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
@@ -109,21 +107,24 @@ __global__ __launch_bounds__(256) void pack_f32_i8_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------- gemm
-// Templated on NWM = waves along M.  NWM = 2: 256x256 tile, 512 threads, 96 KiB LDS, one workgroup
-// per CU.  NWM = 1: 128x256 tile, 256 threads, 72 KiB LDS, TWO workgroups per CU -- the same 8 waves
-// per CU, but in two independently phased groups with half-size barriers, so one group's
-// barrier + LDS-read phase overlaps the other's MFMA phase.  The wave code is identical.
+// Template parameters
+//   NWM  waves along M (tile height 128*NWM); NNI 32-column MFMA tiles per wave along N (wave tile
+//        128 x 32*NNI, 8/NNI waves along N); SKB k-blocks (of 16 variants) per stage; NST ring length.
+// Measured at N = 2504, 10^6 variants per launch (MI355X):
+//   <2,2,4,3> 256x256, 8 waves, 64-variant stages, 3-ring          2.41 ms
+//   <1,2,4,3> 128x256, 4 waves, two workgroups per CU              2.88 ms  (more LDS-DMA bytes per MAC)
+//   <2,4,4,3> 256x256, 4 waves (one per SIMD), wave tile 128x128   2.61 ms  (LDS latency exposed)
 constexpr int TJ = 256;  // tile width (panel J) in samples
 
-template <int NWM>
+template <int NWM, int SKB>
 struct StageI8 {
   int8_t pi[SKB][128 * NWM][KB];  // panel I: [k-block][sample][16 B]
   int8_t pj[SKB][TJ][KB];         // panel J
 };
 
-// DMA instructions per stage: SKB * (2*NWM + 4) of 1 KiB each, spread evenly over the 4*NWM waves.
-template <int NWM, int NWAVES>
-__device__ __forceinline__ void issue_stage_i8(StageI8<NWM>* st, const int8_t* __restrict__ p, int npad,
+// DMA instructions per stage: SKB * (2*NWM + 4) of 1 KiB each, spread evenly over the waves.
+template <int NWM, int SKB, int NWAVES>
+__device__ __forceinline__ void issue_stage_i8(StageI8<NWM, SKB>* st, const int8_t* __restrict__ p, int npad,
                                                int64_t kb0, int col_i, int col_j, int wave, int lane) {
   constexpr int QI = 2 * NWM;              // 64-sample quarters in panel I
   constexpr int PER_KB = QI + 4;           // instructions per k-block
@@ -144,57 +145,63 @@ __device__ __forceinline__ void issue_stage_i8(StageI8<NWM>* st, const int8_t* _
   }
 }
 
-// Fragment registers of one stage: 2 k32-steps x (4 A + NNI B) x 16 B (NNI = 2: 48 VGPRs, NNI = 4: 64).
+// Fragment registers of one k32-step: (4 A + NNI B) x 16 B = 24 VGPRs at NNI = 2.
 template <int NNI>
 struct FragsI8 {
-  i32x4 a[SKB / 2][4];
-  i32x4 b[SKB / 2][NNI];
+  i32x4 a[4];
+  i32x4 b[NNI];
 };
 
-// All ds_read_b128 of the stage are issued back to back (consumption order = issue order).
-template <int NWM, int NNI>
-__device__ __forceinline__ void load_frags_i8(const StageI8<NWM>* st, int wm, int wn, int lane, FragsI8<NNI>& f) {
+template <int NWM, int NNI, int SKB>
+__device__ __forceinline__ void load_frags_i8(const StageI8<NWM, SKB>* st, int k2, int wm, int wn, int lane,
+                                              FragsI8<NNI>& f) {
   const int l31 = lane & 31, hi = lane >> 5;
 #pragma unroll
-  for (int k2 = 0; k2 < SKB / 2; ++k2) {
+  for (int mi = 0; mi < 4; ++mi)
+    f.a[mi] = *reinterpret_cast<const i32x4*>(&st->pi[2 * k2 + hi][wm * 128 + mi * 32 + l31][0]);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-      f.a[k2][mi] = *reinterpret_cast<const i32x4*>(&st->pi[2 * k2 + hi][wm * 128 + mi * 32 + l31][0]);
-#pragma unroll
-    for (int ni = 0; ni < NNI; ++ni)
-      f.b[k2][ni] = *reinterpret_cast<const i32x4*>(&st->pj[2 * k2 + hi][wn * 32 * NNI + ni * 32 + l31][0]);
-  }
+  for (int ni = 0; ni < NNI; ++ni)
+    f.b[ni] = *reinterpret_cast<const i32x4*>(&st->pj[2 * k2 + hi][wn * 32 * NNI + ni * 32 + l31][0]);
 }
 
 template <int NNI>
-__device__ __forceinline__ void mfma_stage_i8(const FragsI8<NNI>& f, i32x16 (&acc)[4][NNI]) {
+__device__ __forceinline__ void mfma_step_i8(const FragsI8<NNI>& f, i32x16 (&acc)[4][NNI]) {
 #pragma unroll
-  for (int k2 = 0; k2 < SKB / 2; ++k2)
+  for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NNI; ++ni)
-        acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[k2][mi], f.b[k2][ni], acc[mi][ni], 0, 0, 0);
+    for (int ni = 0; ni < NNI; ++ni)
+      acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[mi], f.b[ni], acc[mi][ni], 0, 0, 0);
 }
 
-template <int NWM, int NNI, int BUF>
-__device__ __forceinline__ void ring_step(StageI8<NWM>* lds, const int8_t* __restrict__ p, int npad,
+// One stage of the ring.  Prefetch distance D = NST - 1: when stage s is consumed, stages s+1 .. s+D-1
+// may still be in flight (counted vmcnt), and stage s+D is issued into the buffer stage s-1 used.
+// Inside the stage the fragment reads are software-pipelined one k32-step ahead of the MFMAs
+// (two register sets of 24 VGPRs), so the stage depth SKB does not cost registers.
+template <int NWM, int NNI, int SKB, int NST, int BUF>
+__device__ __forceinline__ void ring_step(StageI8<NWM, SKB>* lds, const int8_t* __restrict__ p, int npad,
                                           int64_t kb_begin, int s, int ns, int col_i, int col_j, int wave, int lane,
                                           int wm, int wn, i32x16 (&acc)[4][NNI]) {
   constexpr int NWAVES = NWM * (8 / NNI);
   constexpr int PER_WAVE = SKB * (2 * NWM + 4) / NWAVES;
-  // stage s (buffer BUF) must have landed; stage s+1 may stay in flight
-  if (s + 1 < ns) wait_vmcnt<PER_WAVE>(); else wait_vmcnt<0>();
-  wg_barrier();  // all waves' stage-s DMA landed, and all waves are done reading buffer (BUF+2)%3
-  FragsI8<NNI> f;
-  load_frags_i8<NWM, NNI>(&lds[BUF], wm, wn, lane, f);
+  constexpr int D = NST - 1;
+  static_assert(D == 1 || D == 2, "ring of 2 or 3 stages");
+  if (D >= 2 && s + 1 < ns) wait_vmcnt<(D >= 2 ? PER_WAVE : 0)>(); else wait_vmcnt<0>();
+  wg_barrier();  // all waves' stage-s DMA landed, and all waves are done reading the buffer of stage s-1
+  FragsI8<NNI> f0, f1;
+  load_frags_i8<NWM, NNI, SKB>(&lds[BUF], 0, wm, wn, lane, f0);
   __builtin_amdgcn_sched_barrier(0);
-  // the DMA of stage s+2 is issued under the LDS latency of the fragment reads
-  if (s + 2 < ns)
-    issue_stage_i8<NWM, NWAVES>(&lds[(BUF + 2) % NSTAGE], p, npad, kb_begin + (int64_t)(s + 2) * SKB, col_i, col_j,
-                                wave, lane);
+  // the DMA of stage s+D is issued under the LDS latency of the first fragment reads
+  if (s + D < ns)
+    issue_stage_i8<NWM, SKB, NWAVES>(&lds[(BUF + D) % NST], p, npad, kb_begin + (int64_t)(s + D) * SKB, col_i, col_j,
+                                     wave, lane);
   __builtin_amdgcn_sched_barrier(0);
-  mfma_stage_i8<NNI>(f, acc);
+#pragma unroll
+  for (int k2 = 0; k2 < SKB / 2; k2 += 2) {
+    if (k2 + 1 < SKB / 2) load_frags_i8<NWM, NNI, SKB>(&lds[BUF], k2 + 1, wm, wn, lane, f1);
+    mfma_step_i8<NNI>(f0, acc);
+    if (k2 + 2 < SKB / 2) load_frags_i8<NWM, NNI, SKB>(&lds[BUF], k2 + 2, wm, wn, lane, f0);
+    if (k2 + 1 < SKB / 2) mfma_step_i8<NNI>(f1, acc);
+  }
 }
 
 // Tile enumeration over the upper triangle.  Row blocks are 128*NWM samples, column blocks 256.
@@ -218,20 +225,17 @@ __device__ __forceinline__ void tile_coords(int tile, int ntile, int& row_blk, i
   }
 }
 
-// NNI = 32-column MFMA tiles per wave along N: 2 -> wave tile 128x64, 4 waves along N, two waves per
-// SIMD; 4 -> wave tile 128x128 (256 accumulators), 2 waves along N, ONE wave per SIMD but only 0.5
-// instead of 0.75 fragment reads per MFMA (LDS bandwidth is the co-limiter of this kernel).
-template <int NWM, int NNI>
-__global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram_i8_kernel(const int8_t* __restrict__ p, int npad, int64_t nstages,
-                                                            int n, int ntile, int ntri, int splitk,
-                                                            int64_t stages_per, int32_t* __restrict__ s32,
-                                                            int xcd_map) {
-  __shared__ __attribute__((aligned(16))) StageI8<NWM> lds[NSTAGE];
+template <int NWM, int NNI, int SKB, int NST>
+__global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram_i8_kernel(
+    const int8_t* __restrict__ p, int npad, int64_t nstages, int n, int ntile, int ntri, int splitk,
+    int64_t stages_per, int32_t* __restrict__ s32, int xcd_map) {
+  __shared__ __attribute__((aligned(16))) StageI8<NWM, SKB> lds[NST];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int NWN = 8 / NNI;  // waves along N
   constexpr int NWAVES = NWM * NWN;
+  constexpr int D = NST - 1;
   const int wm = wave / NWN, wn = wave % NWN;
 
   int tile, ks;
@@ -262,19 +266,27 @@ __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0;
 
-  issue_stage_i8<NWM, NWAVES>(&lds[0], p, npad, kb_begin, col_i, col_j, wave, lane);
-  if (ns > 1) issue_stage_i8<NWM, NWAVES>(&lds[1], p, npad, kb_begin + SKB, col_i, col_j, wave, lane);
+  issue_stage_i8<NWM, SKB, NWAVES>(&lds[0], p, npad, kb_begin, col_i, col_j, wave, lane);
+  if (D >= 2 && ns > 1) issue_stage_i8<NWM, SKB, NWAVES>(&lds[1], p, npad, kb_begin + SKB, col_i, col_j, wave, lane);
 
   int s = 0;
-  for (; s + 2 < ns; s += 3) {
-    ring_step<NWM, NNI, 0>(lds, p, npad, kb_begin, s, ns, col_i, col_j, wave, lane, wm, wn, acc);
-    ring_step<NWM, NNI, 1>(lds, p, npad, kb_begin, s + 1, ns, col_i, col_j, wave, lane, wm, wn, acc);
-    ring_step<NWM, NNI, 2>(lds, p, npad, kb_begin, s + 2, ns, col_i, col_j, wave, lane, wm, wn, acc);
-  }
-  if (s < ns) {
-    ring_step<NWM, NNI, 0>(lds, p, npad, kb_begin, s, ns, col_i, col_j, wave, lane, wm, wn, acc);
-    if (s + 1 < ns)
-      ring_step<NWM, NNI, 1>(lds, p, npad, kb_begin, s + 1, ns, col_i, col_j, wave, lane, wm, wn, acc);
+  if constexpr (NST == 3) {
+    for (; s + 2 < ns; s += 3) {
+      ring_step<NWM, NNI, SKB, NST, 0>(lds, p, npad, kb_begin, s, ns, col_i, col_j, wave, lane, wm, wn, acc);
+      ring_step<NWM, NNI, SKB, NST, 1>(lds, p, npad, kb_begin, s + 1, ns, col_i, col_j, wave, lane, wm, wn, acc);
+      ring_step<NWM, NNI, SKB, NST, 2>(lds, p, npad, kb_begin, s + 2, ns, col_i, col_j, wave, lane, wm, wn, acc);
+    }
+    if (s < ns) {
+      ring_step<NWM, NNI, SKB, NST, 0>(lds, p, npad, kb_begin, s, ns, col_i, col_j, wave, lane, wm, wn, acc);
+      if (s + 1 < ns)
+        ring_step<NWM, NNI, SKB, NST, 1>(lds, p, npad, kb_begin, s + 1, ns, col_i, col_j, wave, lane, wm, wn, acc);
+    }
+  } else {
+    for (; s + 1 < ns; s += 2) {
+      ring_step<NWM, NNI, SKB, NST, 0>(lds, p, npad, kb_begin, s, ns, col_i, col_j, wave, lane, wm, wn, acc);
+      ring_step<NWM, NNI, SKB, NST, 1>(lds, p, npad, kb_begin, s + 1, ns, col_i, col_j, wave, lane, wm, wn, acc);
+    }
+    if (s < ns) ring_step<NWM, NNI, SKB, NST, 0>(lds, p, npad, kb_begin, s, ns, col_i, col_j, wave, lane, wm, wn, acc);
   }
 
   // epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
@@ -297,9 +309,10 @@ __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram
 }  // namespace
 
 int64_t gram_i8_npad(int32_t n) { return ((int64_t)n + TM - 1) / TM * TM; }
+// k-blocks are padded to a multiple of 24 so that every stage depth (4, 6 or 8 k-blocks) divides it
 int64_t gram_i8_kb_pad(int64_t nv) {
   const int64_t nkb = (nv + KB - 1) / KB;
-  return (nkb + SKB - 1) / SKB * SKB;
+  return (nkb + 23) / 24 * 24;
 }
 size_t gram_i8_workspace_bytes(int32_t n, int64_t nv) {
   return (size_t)gram_i8_kb_pad(nv) * (size_t)gram_i8_npad(n) * KB;
@@ -326,24 +339,22 @@ hipError_t launch_pack_f32_i8(const float* x, int64_t ld, int64_t nv, int32_t n,
 hipError_t launch_gram_i8_packed(const int8_t* p, int64_t nv, int32_t n, int32_t* s32, int num_cu,
                                  hipStream_t stream, int* splitk_out) {
   if (nv <= 0) return hipSuccess;
-  // variants: 2 = 256x256 tile, 8 waves, wave tile 128x64 (default; measured 2.41 ms per 10^6 variants);
-  //           1 = 128x256 tile, 4 waves, two workgroups per CU (measured 2.88 ms);
-  //           3 = 256x256 tile, 4 waves (one per SIMD), wave tile 128x128.
-  static const int variant = [] {
-    const char* v = std::getenv("PCOA_GRAM_I8_TILE");
-    const int t = v ? std::atoi(v) : 256;
-    return t == 128 ? 1 : (t == 2561 ? 3 : 2);
+  // stage depth in k-blocks (PCOA_GRAM_I8_SKB = 4 | 6 | 8; 8 uses a 2-stage ring: 128 KiB of LDS)
+  static const int skb = [] {
+    const char* v = std::getenv("PCOA_GRAM_I8_SKB");
+    const int t = v ? std::atoi(v) : 4;
+    return (t == 6 || t == 8) ? t : 4;
   }();
   const int npad = (int)gram_i8_npad(n);
   const int ntile = npad / TJ;
-  const int64_t ntri64 = (int64_t)ntile * (ntile + 1) / 2 * (variant == 1 ? 2 : 1);
+  const int64_t ntri64 = (int64_t)ntile * (ntile + 1) / 2;
   if (ntri64 > (1 << 28)) return hipErrorInvalidValue;
   const int ntri = (int)ntri64;
-  const int64_t nstages = gram_i8_kb_pad(nv) / SKB;
-  // resident workgroups per CU: 1 (256x256) or 2 (128x256); aim at ~7 rounds of work per slot, >= 16 stages each
-  const int64_t target = (int64_t)(num_cu > 0 ? num_cu : 256) * (variant == 1 ? 14 : 7);
+  const int64_t nstages = gram_i8_kb_pad(nv) / skb;
+  // one 512-thread workgroup per CU is resident; aim at ~7 work units per CU, >= 1024 variants each
+  const int64_t target = (int64_t)(num_cu > 0 ? num_cu : 256) * 7;
   int64_t splitk = (target + ntri - 1) / ntri;
-  const int64_t max_by_work = nstages / 16;
+  const int64_t max_by_work = nstages * skb / 64;
   if (splitk > max_by_work) splitk = max_by_work;
   if (splitk < 1) splitk = 1;
   int xcd_map = 0;
@@ -355,15 +366,16 @@ hipError_t launch_gram_i8_packed(const int8_t* p, int64_t nv, int32_t n, int32_t
   const int64_t nblocks = (int64_t)ntri * splitk;
   if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
   if (splitk_out) *splitk_out = (int)splitk;
-  if (variant == 2)
-    hipLaunchKernelGGL((gram_i8_kernel<2, 2>), dim3((unsigned)nblocks), dim3(512), 0, stream, p, npad, nstages, n,
-                       ntile, ntri, (int)splitk, stages_per, s32, xcd_map);
-  else if (variant == 3)
-    hipLaunchKernelGGL((gram_i8_kernel<2, 4>), dim3((unsigned)nblocks), dim3(256), 0, stream, p, npad, nstages, n,
-                       ntile, ntri, (int)splitk, stages_per, s32, xcd_map);
+  const dim3 grid((unsigned)nblocks), block(512);
+  if (skb == 6)
+    hipLaunchKernelGGL((gram_i8_kernel<2, 2, 6, 3>), grid, block, 0, stream, p, npad, nstages, n, ntile, ntri,
+                       (int)splitk, stages_per, s32, xcd_map);
+  else if (skb == 8)
+    hipLaunchKernelGGL((gram_i8_kernel<2, 2, 8, 2>), grid, block, 0, stream, p, npad, nstages, n, ntile, ntri,
+                       (int)splitk, stages_per, s32, xcd_map);
   else
-    hipLaunchKernelGGL((gram_i8_kernel<1, 2>), dim3((unsigned)nblocks), dim3(256), 0, stream, p, npad, nstages, n,
-                       ntile, ntri, (int)splitk, stages_per, s32, xcd_map);
+    hipLaunchKernelGGL((gram_i8_kernel<2, 2, 4, 3>), grid, block, 0, stream, p, npad, nstages, n, ntile, ntri,
+                       (int)splitk, stages_per, s32, xcd_map);
   return hipGetLastError();
 }
 
