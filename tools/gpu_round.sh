@@ -25,9 +25,15 @@ for s in $STEPS; do
       timeout 900 python bench.py --gpus 1 --steps 5 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
       echo "bench exit $?" | tee -a $OUT/summary.txt; cat $OUT/bench.json | tee -a $OUT/summary.txt; tail -5 $OUT/bench.err ;;
     benchab)
-      for t in 256 2561 256 2561; do
-        PCOA_GRAM_I8_TILE=$t timeout 600 python bench.py --gpus 1 --steps 8 --warmup 2 --no-cpu-baseline --pcoa-reps 1 > $OUT/bench_tile$t.json 2>> $OUT/bench_ab.err
-        python -c "import json,sys; d=json.load(open('$OUT/bench_tile$t.json')); print('tile $t: value %.1f M/s, ms/step %.3f, gram %.3f ms, pack %.3f ms' % (d['value']/1e6, d['ms_per_step'], d['gram_ms_per_step'], d['pack_ms_per_step']))" | tee -a $OUT/summary.txt
+      # within-run A/B: AB_VAR=<env var> AB_VALUES="a b" (interleaved, two rounds)
+      for t in $AB_VALUES $AB_VALUES; do
+        env $AB_VAR=$t timeout 600 python bench.py --gpus 1 --steps 8 --warmup 2 --no-cpu-baseline --pcoa-reps 1 > $OUT/bench_ab_$t.json 2>> $OUT/bench_ab.err
+        python -c "import json,sys; d=json.load(open('$OUT/bench_ab_$t.json')); print('$AB_VAR=$t: value %.1f M/s, ms/step %.3f, gram %.3f ms, pack %.3f ms' % (d['value']/1e6, d['ms_per_step'], d['gram_ms_per_step'], d['pack_ms_per_step']))" | tee -a $OUT/summary.txt
+      done ;;
+    testsab)
+      for t in $AB_VALUES; do
+        env $AB_VAR=$t timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 600 -x -k "gram or config2 or full_config2 or multi_launch or synthetic" > $OUT/tests_$t.log 2>&1
+        echo "tests $AB_VAR=$t exit $?: $(tail -1 $OUT/tests_$t.log)" | tee -a $OUT/summary.txt
       done ;;
     benchf32)
       timeout 900 python bench.py --gpus 1 --steps 5 --warmup 2 --gram-kernel f32 --no-cpu-baseline > $OUT/bench_f32.json 2> $OUT/bench_f32.err
