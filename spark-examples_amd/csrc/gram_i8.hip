@@ -26,6 +26,7 @@
 // Roofline: i8 MFMA, peak ~5 POP/s dense (2x the bf16 rate, MI355X_MICROARCH.md); algorithmic
 // intensity of the packed operands N/0.5 = 5008 op/B, so HBM is irrelevant once packed.
 #include <cstdlib>
+#include <utility>
 
 #include "pcoa_internal.h"
 
@@ -184,8 +185,17 @@ __device__ __forceinline__ void ring_step(StageI8<NWM, SKB>* lds, const int8_t* 
   constexpr int NWAVES = NWM * (8 / NNI);
   constexpr int PER_WAVE = SKB * (2 * NWM + 4) / NWAVES;
   constexpr int D = NST - 1;
-  static_assert(D == 1 || D == 2, "ring of 2 or 3 stages");
-  if (D >= 2 && s + 1 < ns) wait_vmcnt<(D >= 2 ? PER_WAVE : 0)>(); else wait_vmcnt<0>();
+  static_assert(D >= 1 && D <= 5 && D * PER_WAVE < 64, "prefetch distance 1..5, vmcnt is a 6-bit counter");
+  {
+    // stages s+1 .. s+min(D-1, ns-1-s) may stay in flight
+    const int rem = ns - 1 - s;
+    const int keep = rem < D - 1 ? rem : D - 1;
+    if (keep >= 4) wait_vmcnt<(D >= 5 ? 4 * PER_WAVE : 0)>();
+    else if (keep == 3) wait_vmcnt<(D >= 4 ? 3 * PER_WAVE : 0)>();
+    else if (keep == 2) wait_vmcnt<(D >= 3 ? 2 * PER_WAVE : 0)>();
+    else if (keep == 1) wait_vmcnt<(D >= 2 ? PER_WAVE : 0)>();
+    else wait_vmcnt<0>();
+  }
   wg_barrier();  // all waves' stage-s DMA landed, and all waves are done reading the buffer of stage s-1
   FragsI8<NNI> f0, f1;
   load_frags_i8<NWM, NNI, SKB>(&lds[BUF], 0, wm, wn, lane, f0);
@@ -202,6 +212,28 @@ __device__ __forceinline__ void ring_step(StageI8<NWM, SKB>* lds, const int8_t* 
     if (k2 + 2 < SKB / 2) load_frags_i8<NWM, NNI, SKB>(&lds[BUF], k2 + 2, wm, wn, lane, f0);
     if (k2 + 1 < SKB / 2) mfma_step_i8<NNI>(f1, acc);
   }
+}
+
+template <int NWM, int SKB, int NST, int NWAVES, int... Is>
+__device__ __forceinline__ void ring_prologue(StageI8<NWM, SKB>* lds, const int8_t* __restrict__ p, int npad,
+                                              int64_t kb_begin, int ns, int col_i, int col_j, int wave, int lane,
+                                              std::integer_sequence<int, Is...>) {
+  ((Is < ns ? issue_stage_i8<NWM, SKB, NWAVES>(&lds[Is], p, npad, kb_begin + (int64_t)Is * SKB, col_i, col_j, wave,
+                                               lane)
+            : (void)0),
+   ...);
+}
+
+// `count` consecutive stages starting at s (s is a multiple of NST, so stage s+i lives in buffer i)
+template <int NWM, int NNI, int SKB, int NST, int... Is>
+__device__ __forceinline__ void ring_round(StageI8<NWM, SKB>* lds, const int8_t* __restrict__ p, int npad,
+                                           int64_t kb_begin, int s, int ns, int count, int col_i, int col_j,
+                                           int wave, int lane, int wm, int wn, i32x16 (&acc)[4][NNI],
+                                           std::integer_sequence<int, Is...>) {
+  ((Is < count ? ring_step<NWM, NNI, SKB, NST, Is>(lds, p, npad, kb_begin, s + Is, ns, col_i, col_j, wave, lane, wm,
+                                                    wn, acc)
+               : (void)0),
+   ...);
 }
 
 // Tile enumeration over the upper triangle.  Row blocks are 128*NWM samples, column blocks 256.
@@ -235,7 +267,6 @@ __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int NWN = 8 / NNI;  // waves along N
   constexpr int NWAVES = NWM * NWN;
-  constexpr int D = NST - 1;
   const int wm = wave / NWN, wn = wave % NWN;
 
   int tile, ks;
@@ -266,28 +297,16 @@ __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0;
 
-  issue_stage_i8<NWM, SKB, NWAVES>(&lds[0], p, npad, kb_begin, col_i, col_j, wave, lane);
-  if (D >= 2 && ns > 1) issue_stage_i8<NWM, SKB, NWAVES>(&lds[1], p, npad, kb_begin + SKB, col_i, col_j, wave, lane);
-
+  // prologue: stages 0 .. D-1 go in flight
+  ring_prologue<NWM, SKB, NST, NWAVES>(lds, p, npad, kb_begin, ns, col_i, col_j, wave, lane,
+                                      std::make_integer_sequence<int, NST - 1>{});
   int s = 0;
-  if constexpr (NST == 3) {
-    for (; s + 2 < ns; s += 3) {
-      ring_step<NWM, NNI, SKB, NST, 0>(lds, p, npad, kb_begin, s, ns, col_i, col_j, wave, lane, wm, wn, acc);
-      ring_step<NWM, NNI, SKB, NST, 1>(lds, p, npad, kb_begin, s + 1, ns, col_i, col_j, wave, lane, wm, wn, acc);
-      ring_step<NWM, NNI, SKB, NST, 2>(lds, p, npad, kb_begin, s + 2, ns, col_i, col_j, wave, lane, wm, wn, acc);
-    }
-    if (s < ns) {
-      ring_step<NWM, NNI, SKB, NST, 0>(lds, p, npad, kb_begin, s, ns, col_i, col_j, wave, lane, wm, wn, acc);
-      if (s + 1 < ns)
-        ring_step<NWM, NNI, SKB, NST, 1>(lds, p, npad, kb_begin, s + 1, ns, col_i, col_j, wave, lane, wm, wn, acc);
-    }
-  } else {
-    for (; s + 1 < ns; s += 2) {
-      ring_step<NWM, NNI, SKB, NST, 0>(lds, p, npad, kb_begin, s, ns, col_i, col_j, wave, lane, wm, wn, acc);
-      ring_step<NWM, NNI, SKB, NST, 1>(lds, p, npad, kb_begin, s + 1, ns, col_i, col_j, wave, lane, wm, wn, acc);
-    }
-    if (s < ns) ring_step<NWM, NNI, SKB, NST, 0>(lds, p, npad, kb_begin, s, ns, col_i, col_j, wave, lane, wm, wn, acc);
-  }
+  for (; s + NST - 1 < ns; s += NST)
+    ring_round<NWM, NNI, SKB, NST>(lds, p, npad, kb_begin, s, ns, NST, col_i, col_j, wave, lane, wm, wn, acc,
+                                   std::make_integer_sequence<int, NST>{});
+  if (s < ns)
+    ring_round<NWM, NNI, SKB, NST>(lds, p, npad, kb_begin, s, ns, ns - s, col_i, col_j, wave, lane, wm, wn, acc,
+                                   std::make_integer_sequence<int, NST - 1>{});
 
   // epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
   // Only the upper triangle (j >= i) is authoritative; pcoa_gram_finalize mirrors it.
@@ -339,12 +358,13 @@ hipError_t launch_pack_f32_i8(const float* x, int64_t ld, int64_t nv, int32_t n,
 hipError_t launch_gram_i8_packed(const int8_t* p, int64_t nv, int32_t n, int32_t* s32, int num_cu,
                                  hipStream_t stream, int* splitk_out) {
   if (nv <= 0) return hipSuccess;
-  // stage depth in k-blocks (PCOA_GRAM_I8_SKB = 4 | 6 | 8; 8 uses a 2-stage ring: 128 KiB of LDS)
-  static const int skb = [] {
-    const char* v = std::getenv("PCOA_GRAM_I8_SKB");
-    const int t = v ? std::atoi(v) : 4;
-    return (t == 6 || t == 8) ? t : 4;
+  // PCOA_GRAM_I8_CFG = <k-blocks per stage><ring length>: 43 (default), 44, 25, 26, 63, 82
+  static const int cfg = [] {
+    const char* v = std::getenv("PCOA_GRAM_I8_CFG");
+    const int t = v ? std::atoi(v) : 43;
+    return (t == 44 || t == 25 || t == 26 || t == 63 || t == 82) ? t : 43;
   }();
+  const int skb = cfg / 10;
   const int npad = (int)gram_i8_npad(n);
   const int ntile = npad / TJ;
   const int64_t ntri64 = (int64_t)ntile * (ntile + 1) / 2;
@@ -367,15 +387,18 @@ hipError_t launch_gram_i8_packed(const int8_t* p, int64_t nv, int32_t n, int32_t
   if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
   if (splitk_out) *splitk_out = (int)splitk;
   const dim3 grid((unsigned)nblocks), block(512);
-  if (skb == 6)
-    hipLaunchKernelGGL((gram_i8_kernel<2, 2, 6, 3>), grid, block, 0, stream, p, npad, nstages, n, ntile, ntri,
-                       (int)splitk, stages_per, s32, xcd_map);
-  else if (skb == 8)
-    hipLaunchKernelGGL((gram_i8_kernel<2, 2, 8, 2>), grid, block, 0, stream, p, npad, nstages, n, ntile, ntri,
-                       (int)splitk, stages_per, s32, xcd_map);
-  else
-    hipLaunchKernelGGL((gram_i8_kernel<2, 2, 4, 3>), grid, block, 0, stream, p, npad, nstages, n, ntile, ntri,
-                       (int)splitk, stages_per, s32, xcd_map);
+#define PCOA_LAUNCH_I8(SKB_, NST_)                                                                            \
+  hipLaunchKernelGGL((gram_i8_kernel<2, 2, SKB_, NST_>), grid, block, 0, stream, p, npad, nstages, n, ntile, ntri, \
+                     (int)splitk, stages_per, s32, xcd_map)
+  switch (cfg) {
+    case 44: PCOA_LAUNCH_I8(4, 4); break;
+    case 25: PCOA_LAUNCH_I8(2, 5); break;
+    case 26: PCOA_LAUNCH_I8(2, 6); break;
+    case 63: PCOA_LAUNCH_I8(6, 3); break;
+    case 82: PCOA_LAUNCH_I8(8, 2); break;
+    default: PCOA_LAUNCH_I8(4, 3); break;
+  }
+#undef PCOA_LAUNCH_I8
   return hipGetLastError();
 }
 
