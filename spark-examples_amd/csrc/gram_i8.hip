@@ -174,51 +174,43 @@ __device__ __forceinline__ void mfma_step_i8(const FragsI8<NNI>& f, i32x16 (&acc
       acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[mi], f.b[ni], acc[mi][ni], 0, 0, 0);
 }
 
-// Counted wait: at most `keep` whole stages (PER_WAVE DMA instructions each) stay in flight.
-template <int PER_WAVE, int MAXKEEP>
-__device__ __forceinline__ void wait_stages(int keep) {
-  static_assert(MAXKEEP * PER_WAVE < 64, "vmcnt is a 6-bit counter");
-  if (keep >= 5) wait_vmcnt<(MAXKEEP >= 5 ? 5 * PER_WAVE : 0)>();
-  else if (keep == 4) wait_vmcnt<(MAXKEEP >= 4 ? 4 * PER_WAVE : 0)>();
-  else if (keep == 3) wait_vmcnt<(MAXKEEP >= 3 ? 3 * PER_WAVE : 0)>();
-  else if (keep == 2) wait_vmcnt<(MAXKEEP >= 2 ? 2 * PER_WAVE : 0)>();
-  else if (keep == 1) wait_vmcnt<(MAXKEEP >= 1 ? PER_WAVE : 0)>();
-  else wait_vmcnt<0>();
-}
-
-// One stage of the software pipeline (stage s lives in buffer BUF = s % NST).
-//   entry : fa holds the fragments of (stage s, k32-step 0); stages s+1 .. s+NST-1 may be in flight.
-//   body  : every group of 8 MFMAs runs with the NEXT group's fragments already being read
-//           (two register sets, 24 VGPRs each).  The barrier that makes stage s+1 visible sits before
-//           the LAST MFMA group of stage s: behind it the wave refills the ring (stage s+NST goes into
-//           buffer BUF, whose last read has completed on every wave), starts reading stage s+1's
-//           first fragments, and only then issues its last 8 MFMAs -- so no MFMA group ever waits for a
-//           barrier + LDS round trip.
-//   exit  : fa holds (stage s+1, step 0).
+// One stage of the ring.  Prefetch distance D = NST - 1: when stage s is consumed, stages s+1 .. s+D-1
+// may still be in flight (counted vmcnt), and stage s+D is issued into the buffer stage s-1 used.
+// Inside the stage the fragment reads are software-pipelined one k32-step ahead of the MFMAs
+// (two register sets of 24 VGPRs), so the stage depth SKB does not cost registers.
 template <int NWM, int NNI, int SKB, int NST, int BUF>
 __device__ __forceinline__ void ring_step(StageI8<NWM, SKB>* lds, const int8_t* __restrict__ p, int npad,
                                           int64_t kb_begin, int s, int ns, int col_i, int col_j, int wave, int lane,
-                                          int wm, int wn, i32x16 (&acc)[4][NNI], FragsI8<NNI>& fa, FragsI8<NNI>& fb) {
+                                          int wm, int wn, i32x16 (&acc)[4][NNI]) {
   constexpr int NWAVES = NWM * (8 / NNI);
   constexpr int PER_WAVE = SKB * (2 * NWM + 4) / NWAVES;
-  constexpr int K2N = SKB / 2;
-  static_assert(K2N % 2 == 0, "the two fragment sets swap roles an even number of times per stage");
+  constexpr int D = NST - 1;
+  static_assert(D >= 1 && D <= 5 && D * PER_WAVE < 64, "prefetch distance 1..5, vmcnt is a 6-bit counter");
+  {
+    // stages s+1 .. s+min(D-1, ns-1-s) may stay in flight
+    const int rem = ns - 1 - s;
+    const int keep = rem < D - 1 ? rem : D - 1;
+    if (keep >= 4) wait_vmcnt<(D >= 5 ? 4 * PER_WAVE : 0)>();
+    else if (keep == 3) wait_vmcnt<(D >= 4 ? 3 * PER_WAVE : 0)>();
+    else if (keep == 2) wait_vmcnt<(D >= 3 ? 2 * PER_WAVE : 0)>();
+    else if (keep == 1) wait_vmcnt<(D >= 2 ? PER_WAVE : 0)>();
+    else wait_vmcnt<0>();
+  }
+  wg_barrier();  // all waves' stage-s DMA landed, and all waves are done reading the buffer of stage s-1
+  FragsI8<NNI> f0, f1;
+  load_frags_i8<NWM, NNI, SKB>(&lds[BUF], 0, wm, wn, lane, f0);
+  __builtin_amdgcn_sched_barrier(0);
+  // the DMA of stage s+D is issued under the LDS latency of the first fragment reads
+  if (s + D < ns)
+    issue_stage_i8<NWM, SKB, NWAVES>(&lds[(BUF + D) % NST], p, npad, kb_begin + (int64_t)(s + D) * SKB, col_i, col_j,
+                                     wave, lane);
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int k2 = 0; k2 < K2N; k2 += 2) {
-    load_frags_i8<NWM, NNI, SKB>(&lds[BUF], k2 + 1, wm, wn, lane, fb);
-    mfma_step_i8<NNI>(fa, acc);
-    if (k2 + 2 < K2N) {
-      load_frags_i8<NWM, NNI, SKB>(&lds[BUF], k2 + 2, wm, wn, lane, fa);
-    } else if (s + 1 < ns) {
-      const int rem = ns - 2 - s;  // stages after s+1
-      wait_stages<PER_WAVE, NST - 2>(rem < NST - 2 ? rem : NST - 2);
-      wg_barrier();  // stage s+1 landed for every wave; every wave's reads of buffer BUF are complete
-      if (s + NST < ns)
-        issue_stage_i8<NWM, SKB, NWAVES>(&lds[BUF], p, npad, kb_begin + (int64_t)(s + NST) * SKB, col_i, col_j, wave,
-                                         lane);
-      load_frags_i8<NWM, NNI, SKB>(&lds[(BUF + 1) % NST], 0, wm, wn, lane, fa);
-    }
-    mfma_step_i8<NNI>(fb, acc);
+  for (int k2 = 0; k2 < SKB / 2; k2 += 2) {
+    if (k2 + 1 < SKB / 2) load_frags_i8<NWM, NNI, SKB>(&lds[BUF], k2 + 1, wm, wn, lane, f1);
+    mfma_step_i8<NNI>(f0, acc);
+    if (k2 + 2 < SKB / 2) load_frags_i8<NWM, NNI, SKB>(&lds[BUF], k2 + 2, wm, wn, lane, f0);
+    if (k2 + 1 < SKB / 2) mfma_step_i8<NNI>(f1, acc);
   }
 }
 
@@ -237,9 +229,9 @@ template <int NWM, int NNI, int SKB, int NST, int... Is>
 __device__ __forceinline__ void ring_round(StageI8<NWM, SKB>* lds, const int8_t* __restrict__ p, int npad,
                                            int64_t kb_begin, int s, int ns, int count, int col_i, int col_j,
                                            int wave, int lane, int wm, int wn, i32x16 (&acc)[4][NNI],
-                                           FragsI8<NNI>& fa, FragsI8<NNI>& fb, std::integer_sequence<int, Is...>) {
+                                           std::integer_sequence<int, Is...>) {
   ((Is < count ? ring_step<NWM, NNI, SKB, NST, Is>(lds, p, npad, kb_begin, s + Is, ns, col_i, col_j, wave, lane, wm,
-                                                    wn, acc, fa, fb)
+                                                    wn, acc)
                : (void)0),
    ...);
 }
@@ -305,21 +297,16 @@ __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0;
 
-  // prologue: the whole ring (stages 0 .. NST-1) goes in flight; wait for stage 0 only
-  constexpr int PER_WAVE = SKB * (2 * NWM + 4) / NWAVES;
+  // prologue: stages 0 .. D-1 go in flight
   ring_prologue<NWM, SKB, NST, NWAVES>(lds, p, npad, kb_begin, ns, col_i, col_j, wave, lane,
-                                      std::make_integer_sequence<int, NST>{});
-  wait_stages<PER_WAVE, NST - 1>(ns - 1 < NST - 1 ? ns - 1 : NST - 1);
-  wg_barrier();
-  FragsI8<NNI> fa, fb;
-  load_frags_i8<NWM, NNI, SKB>(&lds[0], 0, wm, wn, lane, fa);
+                                      std::make_integer_sequence<int, NST - 1>{});
   int s = 0;
   for (; s + NST - 1 < ns; s += NST)
-    ring_round<NWM, NNI, SKB, NST>(lds, p, npad, kb_begin, s, ns, NST, col_i, col_j, wave, lane, wm, wn, acc, fa, fb,
+    ring_round<NWM, NNI, SKB, NST>(lds, p, npad, kb_begin, s, ns, NST, col_i, col_j, wave, lane, wm, wn, acc,
                                    std::make_integer_sequence<int, NST>{});
   if (s < ns)
-    ring_round<NWM, NNI, SKB, NST>(lds, p, npad, kb_begin, s, ns, ns - s, col_i, col_j, wave, lane, wm, wn, acc, fa,
-                                   fb, std::make_integer_sequence<int, NST - 1>{});
+    ring_round<NWM, NNI, SKB, NST>(lds, p, npad, kb_begin, s, ns, ns - s, col_i, col_j, wave, lane, wm, wn, acc,
+                                   std::make_integer_sequence<int, NST - 1>{});
 
   // epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
   // Only the upper triangle (j >= i) is authoritative; pcoa_gram_finalize mirrors it.
@@ -371,13 +358,13 @@ hipError_t launch_pack_f32_i8(const float* x, int64_t ld, int64_t nv, int32_t n,
 hipError_t launch_gram_i8_packed(const int8_t* p, int64_t nv, int32_t n, int32_t* s32, int num_cu,
                                  hipStream_t stream, int* splitk_out) {
   if (nv <= 0) return hipSuccess;
-  // PCOA_GRAM_I8_CFG = <k-blocks per stage><ring length>: 43 (default), 44, 82; 2843 = 4-wave variant
+  // PCOA_GRAM_I8_CFG = <k-blocks per stage><ring length>: 43 (default), 44, 25, 26, 63, 82
   static const int cfg = [] {
     const char* v = std::getenv("PCOA_GRAM_I8_CFG");
     const int t = v ? std::atoi(v) : 43;
-    return (t == 44 || t == 82 || t == 2843) ? t : 43;
+    return (t == 44 || t == 25 || t == 26 || t == 63 || t == 82) ? t : 43;
   }();
-  const int skb = (cfg % 100) / 10;
+  const int skb = cfg / 10;
   const int npad = (int)gram_i8_npad(n);
   const int ntile = npad / TJ;
   const int64_t ntri64 = (int64_t)ntile * (ntile + 1) / 2;
@@ -405,11 +392,10 @@ hipError_t launch_gram_i8_packed(const int8_t* p, int64_t nv, int32_t n, int32_t
                      (int)splitk, stages_per, s32, xcd_map)
   switch (cfg) {
     case 44: PCOA_LAUNCH_I8(4, 4); break;
+    case 25: PCOA_LAUNCH_I8(2, 5); break;
+    case 26: PCOA_LAUNCH_I8(2, 6); break;
+    case 63: PCOA_LAUNCH_I8(6, 3); break;
     case 82: PCOA_LAUNCH_I8(8, 2); break;
-    case 2843:  // 4 waves (one per SIMD), wave tile 128x128, 64-variant stages, 3-ring
-      hipLaunchKernelGGL((gram_i8_kernel<2, 4, 4, 3>), grid, dim3(256), 0, stream, p, npad, nstages, n, ntile, ntri,
-                         (int)splitk, stages_per, s32, xcd_map);
-      break;
     default: PCOA_LAUNCH_I8(4, 3); break;
   }
 #undef PCOA_LAUNCH_I8
