@@ -140,6 +140,11 @@ int pcoa_accumulate_calls(pcoa_ctx* ctx, const int32_t* sample_idx, const int64_
 int pcoa_accumulate_dense_f32(pcoa_ctx* ctx, const float* x, int64_t n_variants, int64_t ld,
                               int is_device_ptr);
 
+/* Same boundary with one byte per genotype (values 0..127): the production format -- the int8 matrix
+ * cores take it after a 4x cheaper re-layout pass than the fp32 tile (SURVEY.md 8f "bit-packed / int8
+ * Gram path").  Always runs the i8-MFMA kernel.  Host or device pointer as above. */
+int pcoa_accumulate_dense_u8(pcoa_ctx* ctx, const uint8_t* x, int64_t n_variants, int64_t ld, int is_device_ptr);
+
 /* Generates variants [first_variant, first_variant + n_variants) of the synthetic model directly
  * in HBM and accumulates them (no host tile).  params->thresholds covers exactly that range. */
 int pcoa_accumulate_synthetic(pcoa_ctx* ctx, const pcoa_synth_params* params, int64_t first_variant,

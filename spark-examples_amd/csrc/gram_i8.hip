@@ -107,6 +107,80 @@ __global__ __launch_bounds__(256) void pack_f32_i8_kernel(const float* __restric
   if (bad) atomicOr(flag, 4);
 }
 
+// uint8 twin of the pre-pass: X u8 [V][ld] -> P.  One thread = 16 variants x 4 samples (16 coalesced 4-B
+// loads, a 16x4 byte transpose with v_perm, 4 x 16-B stores).  2.5 + 2.56 GB per 10^6 variants.
+__global__ __launch_bounds__(256) void pack_u8_i8_kernel(const uint8_t* __restrict__ x, int64_t ld, int64_t nv,
+                                                         int n, int npad, int64_t nkb_pad, int8_t* __restrict__ p,
+                                                         int32_t* __restrict__ flag, int vec_ok) {
+  const int groups = npad >> 2;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t kb = gid / groups;
+  const int g = (int)(gid - kb * groups);
+  if (kb >= nkb_pad) return;
+  const int i0 = g * 4;
+  uint32_t v[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int64_t row = kb * KB + t;
+    uint32_t w = 0;
+    if (row < nv) {
+      const uint8_t* src = x + row * ld + i0;
+      if (vec_ok && i0 + 3 < ld) {
+        w = *reinterpret_cast<const uint32_t*>(src);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          if (i0 + s < ld) w |= (uint32_t)src[s] << (8 * s);
+      }
+    }
+    // padding columns [n, ld) may hold anything: forced to zero
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (i0 + s >= n) w &= ~(0xffu << (8 * s));
+    v[t] = w;
+  }
+  uint32_t any = 0;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) any |= v[t];
+  uint4* dst = reinterpret_cast<uint4*>(p + ((size_t)kb * npad + i0) * KB);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    uint32_t o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      o[q] = ((v[4 * q] >> (8 * s)) & 0xffu) | (((v[4 * q + 1] >> (8 * s)) & 0xffu) << 8) |
+             (((v[4 * q + 2] >> (8 * s)) & 0xffu) << 16) | (((v[4 * q + 3] >> (8 * s)) & 0xffu) << 24);
+    dst[s] = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+  if (any & 0x80808080u) atomicOr(flag, 4);  // a value above 127
+}
+
+// CSR carrier lists (RDD[Seq[Int]], VariantsPca.scala:153-168) straight into the k-blocked operand:
+// one wave per variant row, +1 into byte (v % 16) of P[v / 16][sample] through a 32-bit atomic on
+// the enclosing word (repeated indices count with multiplicity, as the reference's double loop does;
+// a byte that would pass 127 raises flag bit 2).  P must be zero-filled beforehand.
+__global__ __launch_bounds__(256) void densify_csr_i8_kernel(const int32_t* __restrict__ idx,
+                                                             const int64_t* __restrict__ offs, int64_t nv,
+                                                             int64_t offs_base, int8_t* __restrict__ p, int npad,
+                                                             int32_t n, int32_t* __restrict__ flag) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nv) return;
+  const int64_t b = offs[row] - offs_base, e = offs[row + 1] - offs_base;
+  const int64_t kb = row / KB;
+  const int t = (int)(row % KB);
+  for (int64_t q = b + lane; q < e; q += 64) {
+    const int32_t c = idx[q];
+    if (c < 0 || c >= n) {
+      atomicOr(flag, 1);
+      continue;
+    }
+    uint32_t* word = reinterpret_cast<uint32_t*>(p + ((size_t)kb * npad + c) * KB) + (t >> 2);
+    const uint32_t old = atomicAdd(word, 1u << (8 * (t & 3)));
+    if (((old >> (8 * (t & 3))) & 0xffu) >= 127u) atomicOr(flag, 4);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- gemm
 // Template parameters
 //   NWM  waves along M (tile height 128*NWM); NNI 32-column MFMA tiles per wave along N (wave tile
@@ -352,6 +426,30 @@ hipError_t launch_pack_f32_i8(const float* x, int64_t ld, int64_t nv, int32_t n,
   else
     hipLaunchKernelGGL(pack_f32_i8_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, x, ld, nv, n, npad,
                        nkb_pad, p, flag);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_u8_i8(const uint8_t* x, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
+                             hipStream_t stream) {
+  if (nv <= 0) return hipSuccess;
+  const int npad = (int)gram_i8_npad(n);
+  const int64_t nkb_pad = gram_i8_kb_pad(nv);
+  const int64_t threads = nkb_pad * (npad >> 2);
+  const int64_t blocks = (threads + 255) / 256;
+  if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+  const int vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 3) == 0);
+  hipLaunchKernelGGL(pack_u8_i8_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, ld, nv, n, npad, nkb_pad, p,
+                     flag, vec_ok);
+  return hipGetLastError();
+}
+
+hipError_t launch_densify_csr_i8(const int32_t* idx_dev, const int64_t* offs_dev, int64_t nv, int64_t offs_base,
+                                 int8_t* p, int32_t n, int32_t* flag, hipStream_t stream) {
+  if (nv <= 0) return hipSuccess;
+  hipError_t e = hipMemsetAsync(p, 0, gram_i8_workspace_bytes(n, nv), stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(densify_csr_i8_kernel, dim3((unsigned)((nv + 3) / 4)), dim3(256), 0, stream, idx_dev, offs_dev,
+                     nv, offs_base, p, (int)gram_i8_npad(n), n, flag);
   return hipGetLastError();
 }
 

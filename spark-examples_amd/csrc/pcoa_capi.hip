@@ -217,15 +217,62 @@ int fold_now(pcoa_ctx* c) {
   return PCOA_OK;
 }
 
+// bookkeeping shared by every Gram launch
+void account_gram(pcoa_ctx* c, int64_t cur) {
+  c->gram_launches += 1;
+  c->gram_variants += cur;
+  c->gram_flops += 2.0 * (double)cur * (double)c->n * (double)c->n;
+  c->gram_bytes += 4.0 * (double)cur * (double)c->n + 4.0 * (double)c->n * (double)c->n;
+  c->variants_in_s32 += cur;
+  c->dirty = true;
+  c->have_data = true;
+}
+
+int fold_if_needed(pcoa_ctx* c, int64_t cur) {
+  if (c->variants_in_s32 + cur > c->fold_threshold) {
+    ScopedTimer t(c, T_FINALIZE);
+    return fold_now(c);
+  }
+  return PCOA_OK;
+}
+
+// uint8 tile resident on the device -> k-blocked int8 -> i8 contraction (always the i8 path)
+int gram_device_u8(pcoa_ctx* c, const uint8_t* x_dev, int64_t nv, int64_t ld) {
+  int64_t done = 0;
+  const int64_t max_cur = std::min(c->max_launch, c->pack_chunk);
+  while (done < nv) {
+    const int64_t cur = std::min(nv - done, max_cur);
+    int rc = fold_if_needed(c, cur);
+    if (rc != PCOA_OK) return rc;
+    const int64_t need = (int64_t)gram_i8_workspace_bytes(c->n, cur);
+    rc = ensure(c, &c->pack_buf, &c->pack_cap, need);
+    if (rc != PCOA_OK) return rc;
+    {
+      ScopedTimer t(c, T_PACK);
+      hipError_t e = launch_pack_u8_i8(x_dev + done * ld, ld, cur, c->n, c->pack_buf, c->err_flag, c->stream);
+      if (e != hipSuccess) return hip_fail(c, e, "pack(u8) kernel launch");
+    }
+    c->pack_launches += 1;
+    c->pack_bytes += (double)cur * (double)c->n + (double)need;
+    {
+      ScopedTimer t(c, T_GRAM);
+      hipError_t e = launch_gram_i8_packed(c->pack_buf, cur, c->n, c->s32, c->num_cu, c->stream, nullptr);
+      if (e != hipSuccess) return hip_fail(c, e, "gram i8 kernel launch");
+    }
+    account_gram(c, cur);
+    done += cur;
+  }
+  return PCOA_OK;
+}
+
 // X tile already resident on the device: split into launches that keep fp32/int32 exact.
 int gram_device(pcoa_ctx* c, const float* x_dev, int64_t nv, int64_t ld) {
   int64_t done = 0;
   const int64_t max_cur = c->use_i8 ? std::min(c->max_launch, c->pack_chunk) : c->max_launch;
   while (done < nv) {
     const int64_t cur = std::min(nv - done, max_cur);
-    if (c->variants_in_s32 + cur > c->fold_threshold) {
-      ScopedTimer t(c, T_FINALIZE);
-      int rc = fold_now(c);
+    {
+      int rc = fold_if_needed(c, cur);
       if (rc != PCOA_OK) return rc;
     }
     if (c->use_i8) {
@@ -262,13 +309,7 @@ int gram_device(pcoa_ctx* c, const float* x_dev, int64_t nv, int64_t ld) {
       hipError_t e = launch_gram_f32(g, nullptr);
       if (e != hipSuccess) return hip_fail(c, e, "gram kernel launch");
     }
-    c->gram_launches += 1;
-    c->gram_variants += cur;
-    c->gram_flops += 2.0 * (double)cur * (double)c->n * (double)c->n;
-    c->gram_bytes += 4.0 * (double)cur * (double)c->n + 4.0 * (double)c->n * (double)c->n;
-    c->variants_in_s32 += cur;
-    c->dirty = true;
-    c->have_data = true;
+    account_gram(c, cur);
     done += cur;
   }
   return PCOA_OK;
@@ -485,6 +526,30 @@ int pcoa_accumulate_dense_f32(pcoa_ctx* c, const float* x, int64_t n_variants, i
   return PCOA_OK;
 }
 
+int pcoa_accumulate_dense_u8(pcoa_ctx* c, const uint8_t* x, int64_t n_variants, int64_t ld, int is_device_ptr) {
+  CHECK_CTX(c);
+  if (n_variants < 0 || (n_variants > 0 && !x)) return fail(c, PCOA_ERR_INVALID_ARG, "x is NULL or n_variants < 0");
+  if (ld < c->n) return fail(c, PCOA_ERR_INVALID_ARG, "ld must be >= n_samples");
+  if (n_variants == 0) return PCOA_OK;
+  if (is_device_ptr) return gram_device_u8(c, x, n_variants, ld);
+  // host tile: staged through the (byte-addressed) tile buffer in chunks of at most 256 MiB
+  const int64_t ld4 = round_up(c->n, 4);
+  const int64_t rows_cap = std::max<int64_t>(1, std::min<int64_t>(n_variants, ((int64_t)256 << 20) / ld4));
+  int rc = ensure(c, &c->tile, &c->tile_elems, (rows_cap * ld4 + 3) / 4);
+  if (rc != PCOA_OK) return rc;
+  uint8_t* stage = reinterpret_cast<uint8_t*>(c->tile);
+  for (int64_t v0 = 0; v0 < n_variants; v0 += rows_cap) {
+    const int64_t rows = std::min(rows_cap, n_variants - v0);
+    if (ld4 != c->n) HIP_TRY(c, hipMemsetAsync(stage, 0, (size_t)(rows * ld4), c->stream));
+    HIP_TRY(c, hipMemcpy2DAsync(stage, (size_t)ld4, x + v0 * ld, (size_t)ld, (size_t)c->n, (size_t)rows,
+                                hipMemcpyHostToDevice, c->stream));
+    rc = gram_device_u8(c, stage, rows, ld4);
+    if (rc != PCOA_OK) return rc;
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return PCOA_OK;
+}
+
 int pcoa_accumulate_calls(pcoa_ctx* c, const int32_t* sample_idx, const int64_t* row_offsets, int64_t n_variants) {
   CHECK_CTX(c);
   if (n_variants < 0 || !row_offsets) return fail(c, PCOA_ERR_INVALID_ARG, "row_offsets is NULL or n_variants < 0");
@@ -507,8 +572,11 @@ int pcoa_accumulate_calls(pcoa_ctx* c, const int32_t* sample_idx, const int64_t*
   }
   const int64_t ld4 = round_up(c->n, 4);
   const int64_t rows_cap = std::max<int64_t>(1, std::min<int64_t>(n_variants, ((int64_t)64 << 20) / ld4));
-  int rc = ensure(c, &c->tile, &c->tile_elems, rows_cap * ld4);
-  if (rc != PCOA_OK) return rc;
+  int rc = PCOA_OK;
+  if (!c->use_i8) {
+    rc = ensure(c, &c->tile, &c->tile_elems, rows_cap * ld4);
+    if (rc != PCOA_OK) return rc;
+  }
   rc = ensure(c, &c->csr_offs, &c->csr_offs_cap, rows_cap + 1);
   if (rc != PCOA_OK) return rc;
   for (int64_t v0 = 0; v0 < n_variants; v0 += rows_cap) {
@@ -522,6 +590,24 @@ int pcoa_accumulate_calls(pcoa_ctx* c, const int32_t* sample_idx, const int64_t*
                               c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->csr_offs, row_offsets + v0, sizeof(int64_t) * (size_t)(rows + 1),
                               hipMemcpyHostToDevice, c->stream));
+    if (c->use_i8) {
+      // carriers -> k-blocked int8 operand directly (no fp32 tile, no pre-pass), then the i8 contraction
+      rc = fold_if_needed(c, rows);
+      if (rc != PCOA_OK) return rc;
+      rc = ensure(c, &c->pack_buf, &c->pack_cap, (int64_t)gram_i8_workspace_bytes(c->n, rows));
+      if (rc != PCOA_OK) return rc;
+      {
+        ScopedTimer t(c, T_DENSIFY);
+        HIP_TRY(c, launch_densify_csr_i8(c->csr_idx, c->csr_offs, rows, b, c->pack_buf, c->n, c->err_flag,
+                                         c->stream));
+      }
+      {
+        ScopedTimer t(c, T_GRAM);
+        HIP_TRY(c, launch_gram_i8_packed(c->pack_buf, rows, c->n, c->s32, c->num_cu, c->stream, nullptr));
+      }
+      account_gram(c, rows);
+      continue;
+    }
     {
       ScopedTimer t(c, T_DENSIFY);
       HIP_TRY(c, hipMemsetAsync(c->tile, 0, sizeof(float) * (size_t)(rows * ld4), c->stream));

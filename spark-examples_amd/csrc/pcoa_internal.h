@@ -35,6 +35,10 @@ int64_t gram_i8_kb_pad(int64_t nv);
 size_t gram_i8_workspace_bytes(int32_t n, int64_t nv);
 hipError_t launch_pack_f32_i8(const float* x, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
                               hipStream_t stream);
+hipError_t launch_pack_u8_i8(const uint8_t* x, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
+                             hipStream_t stream);
+hipError_t launch_densify_csr_i8(const int32_t* idx_dev, const int64_t* offs_dev, int64_t nv, int64_t offs_base,
+                                 int8_t* p, int32_t n, int32_t* flag, hipStream_t stream);
 hipError_t launch_gram_i8_packed(const int8_t* p, int64_t nv, int32_t n, int32_t* s32, int num_cu,
                                  hipStream_t stream, int* splitk_out);
 

@@ -129,6 +129,24 @@ class PcoaEngine(object):
         ldv = a.shape[1] if ld is None else int(ld)
         self._check(self._lib.pcoa_accumulate_dense_f32(self._ctx, _ptr(a), nv, ldv, 0))
 
+    def accumulate_dense_u8(self, x, n_variants=None, ld=None):
+        """Dense variants x samples tile with one byte per genotype (0..127): numpy uint8 array (host) or a
+        torch uint8 CUDA tensor (read in place)."""
+        if hasattr(x, "data_ptr") and getattr(x, "is_cuda", False):
+            import torch  # plumbing only
+            assert x.dtype == torch.uint8 and x.dim() == 2 and x.stride(1) == 1
+            nv = int(x.shape[0]) if n_variants is None else int(n_variants)
+            ldv = int(x.stride(0)) if ld is None else int(ld)
+            self._keepalive.append(x)
+            self._check(self._lib.pcoa_accumulate_dense_u8(self._ctx, ctypes.c_void_p(x.data_ptr()), nv, ldv, 1))
+            return
+        a = np.ascontiguousarray(x, dtype=np.uint8)
+        if a.ndim != 2:
+            raise ValueError("x must be 2-D [variants][samples]")
+        nv = a.shape[0] if n_variants is None else int(n_variants)
+        ldv = a.shape[1] if ld is None else int(ld)
+        self._check(self._lib.pcoa_accumulate_dense_u8(self._ctx, _ptr(a), nv, ldv, 0))
+
     def accumulate_dense_device_ptr(self, ptr, n_variants, ld):
         self._check(self._lib.pcoa_accumulate_dense_f32(self._ctx, ctypes.c_void_p(int(ptr)), int(n_variants),
                                                         int(ld), 1))

@@ -116,6 +116,30 @@ def test_repeated_indices_count_with_multiplicity_like_the_reference_double_loop
         assert np.array_equal(eng.gram(), want)
 
 
+@pytest.mark.parametrize("n,v", [(5, 3), (64, 100), (300, 777), (1030, 200)])
+def test_u8_boundary_matches_oracle_host_and_device(P, O, n, v):
+    import torch
+    rng = np.random.default_rng(n + 7 * v)
+    x = (rng.random((v, n)) < 0.25).astype(np.uint8)
+    x[0, 0] = 3  # multiplicities up to 127 are legal
+    want = (x.T.astype(np.int64) @ x.astype(np.int64))
+    with P.PcoaEngine(n) as eng:
+        eng.accumulate_dense_u8(x)
+        assert np.array_equal(eng.gram(), want)
+        eng.reset()
+        for ld in (n, n + 1, ((n + 15) // 16) * 16 + 16):  # unaligned and padded strides, padding = 0xff
+            buf = torch.full((v, ld), 255, dtype=torch.uint8, device="cuda")
+            buf[:, :n] = torch.from_numpy(x).cuda()
+            eng.accumulate_dense_u8(buf)
+        assert np.array_equal(eng.gram(), 3 * want)
+    with P.PcoaEngine(n) as eng:
+        bad = x.copy()
+        bad[v // 2, n // 2] = 128
+        eng.accumulate_dense_u8(bad)
+        with pytest.raises(P.PcoaError):
+            eng.gram()
+
+
 def test_i8_path_rejects_non_integer_or_large_values_and_f32_path_accepts_integers(P, O):
     x = np.zeros((40, 12), dtype=np.float32)
     x[3, 4] = 1.0
