@@ -120,6 +120,8 @@ class PcoaEngine(object):
             nv = int(x.shape[0]) if n_variants is None else int(n_variants)
             ldv = int(x.stride(0)) if ld is None else int(ld)
             self._keepalive.append(x)
+            # the engine runs on its own stream: whatever torch queued to produce x must have finished
+            torch.cuda.current_stream(x.device).synchronize()
             self._check(self._lib.pcoa_accumulate_dense_f32(self._ctx, ctypes.c_void_p(x.data_ptr()), nv, ldv, 1))
             return
         a = np.ascontiguousarray(x, dtype=np.float32)
@@ -138,6 +140,7 @@ class PcoaEngine(object):
             nv = int(x.shape[0]) if n_variants is None else int(n_variants)
             ldv = int(x.stride(0)) if ld is None else int(ld)
             self._keepalive.append(x)
+            torch.cuda.current_stream(x.device).synchronize()  # see accumulate_dense
             self._check(self._lib.pcoa_accumulate_dense_u8(self._ctx, ctypes.c_void_p(x.data_ptr()), nv, ldv, 1))
             return
         a = np.ascontiguousarray(x, dtype=np.uint8)
