@@ -110,6 +110,14 @@ def load():
         raise ImportError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
             "`make -C spark-examples_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.  If libpcoa_hip.so pulls in
+    # /opt/rocm's copy first and torch is imported later, two runtimes tear down at exit ("double free or
+    # corruption").  Importing torch first makes the loader resolve our DT_NEEDED entry to the runtime
+    # that is already mapped.  (Plumbing only; skipped when torch is not installed.)
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover
+        pass
     lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
     for name, restype, argtypes in _SIGNATURES:
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch

@@ -96,6 +96,56 @@ def load_vcf(path, references=None):
     return indexes, dict(zip(ids, samples)), [("csr", idx, np.asarray(offs, dtype=np.int64))]
 
 
+def load_vcf_records(path, references=None):
+    """VCF -> variant records shaped like the reference's Variant case class (VariantsRDD.scala:46-54):
+    contig, start, end, referenceBases, alternateBases, info, calls[{callSetId, genotype}].
+    Returns (callset ids in file order, id -> name, [variant dict])."""
+    regions = parse_references(references)
+    opener = gzip.open if path.endswith(".gz") else open
+    set_id = os.path.basename(path).split(".")[0].replace("-", "_")
+    samples, ids, variants = None, [], []
+    with opener(path, "rt") as f:
+        for line in f:
+            if line.startswith("##"):
+                continue
+            if line.startswith("#CHROM"):
+                samples = line.rstrip("\n").split("\t")[9:]
+                ids = ["%s-%d" % (set_id, i) for i in range(len(samples))]
+                continue
+            if samples is None:
+                raise ValueError("VCF header line (#CHROM) missing")
+            rec = line.rstrip("\n").split("\t")
+            if len(rec) < 10:
+                continue
+            contig = normalize_contig(rec[0])
+            if contig is None:
+                continue
+            start = int(rec[1]) - 1
+            if regions and not any(c == contig and s <= start < e for (c, s, e) in regions):
+                continue
+            fmt = rec[8].split(":")
+            if "GT" not in fmt:
+                continue
+            gti = fmt.index("GT")
+            info = {}
+            for item in rec[7].split(";"):
+                if "=" in item:
+                    k, val = item.split("=", 1)
+                    info[k] = val.split(",")
+            calls = []
+            for i, cell in enumerate(rec[9:]):
+                parts = cell.split(":")
+                gt = parts[gti] if gti < len(parts) else "."
+                genotype = [(-1 if a in (".", "") else int(a)) for a in re.split(r"[/|]", gt)]
+                calls.append({"callSetId": ids[i], "genotype": genotype})
+            variants.append({"contig": contig, "start": start, "end": start + len(rec[3]), "referenceBases": rec[3],
+                             "alternateBases": [a for a in rec[4].split(",") if a != "."], "info": info,
+                             "calls": calls})
+    if samples is None:
+        raise ValueError("no #CHROM header in %s" % path)
+    return ids, dict(zip(ids, samples)), variants
+
+
 def synthetic_dataset(spec):
     """'V,N,seed' -> Balding-Nichols synthetic carriers as CSR (host generated; small V only)."""
     v, n, seed = [int(t) for t in spec.split(",")]

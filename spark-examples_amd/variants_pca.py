@@ -62,6 +62,93 @@ def prepare_call_data(py_rdd, py_id_to_index):
     return call_rdd
 
 
+# --------------------------------------------------------------------------------------------- join / merge
+_M64 = 0xFFFFFFFFFFFFFFFF
+
+
+def _rotl64(x, r):
+    return ((x << r) | (x >> (64 - r))) & _M64
+
+
+def _fmix64(k):
+    k ^= k >> 33
+    k = (k * 0xFF51AFD7ED558CCD) & _M64
+    k ^= k >> 33
+    k = (k * 0xC4CEB9FE1A85EC53) & _M64
+    k ^= k >> 33
+    return k
+
+
+def murmur3_128_hex(data, seed=0):
+    """Guava Hashing.murmur3_128(seed).hashBytes(data).toString(): MurmurHash3_x64_128, the two 64-bit
+    halves printed as little-endian bytes (the reference keys variants with it, VariantsPca.scala:69-77)."""
+    c1, c2 = 0x87C37B91114253D5, 0x4CF5AD432745937F
+    h1 = h2 = seed & _M64
+    n = len(data)
+    nblocks = n // 16
+    for i in range(nblocks):
+        k1 = int.from_bytes(data[16 * i:16 * i + 8], "little")
+        k2 = int.from_bytes(data[16 * i + 8:16 * i + 16], "little")
+        k1 = (k1 * c1) & _M64; k1 = _rotl64(k1, 31); k1 = (k1 * c2) & _M64; h1 ^= k1
+        h1 = _rotl64(h1, 27); h1 = (h1 + h2) & _M64; h1 = (h1 * 5 + 0x52DCE729) & _M64
+        k2 = (k2 * c2) & _M64; k2 = _rotl64(k2, 33); k2 = (k2 * c1) & _M64; h2 ^= k2
+        h2 = _rotl64(h2, 31); h2 = (h2 + h1) & _M64; h2 = (h2 * 5 + 0x38495AB5) & _M64
+    tail = data[16 * nblocks:]
+    k1 = k2 = 0
+    if len(tail) > 8:
+        k2 = int.from_bytes(tail[8:], "little")
+        k2 = (k2 * c2) & _M64; k2 = _rotl64(k2, 33); k2 = (k2 * c1) & _M64; h2 ^= k2
+    if len(tail) > 0:
+        k1 = int.from_bytes(tail[:8], "little")
+        k1 = (k1 * c1) & _M64; k1 = _rotl64(k1, 31); k1 = (k1 * c2) & _M64; h1 ^= k1
+    h1 ^= n; h2 ^= n
+    h1 = (h1 + h2) & _M64; h2 = (h2 + h1) & _M64
+    h1 = _fmix64(h1); h2 = _fmix64(h2)
+    h1 = (h1 + h2) & _M64; h2 = (h2 + h1) & _M64
+    return (h1.to_bytes(8, "little") + h2.to_bytes(8, "little")).hex()
+
+
+def get_variant_key(variant, debug=False):
+    """VariantsPcaDriver.getVariantKey (VariantsPca.scala:62-78): murmur3_128 over
+    contig, start, end, referenceBases, alternateBases.mkString("") as a Guava Hasher sees them
+    (putString = UTF-8 bytes, putLong = 8 little-endian bytes)."""
+    alternate = "".join(variant.get("alternateBases") or [])
+    reference = variant.get("referenceBases") or ""
+    if debug:
+        print("%s: (%d, %d) ref=%s alt=%s" % (variant["contig"], variant["start"], variant["end"], reference, alternate))
+    buf = (variant["contig"].encode("utf-8") + int(variant["start"]).to_bytes(8, "little", signed=True) +
+           int(variant["end"]).to_bytes(8, "little", signed=True) + reference.encode("utf-8") +
+           alternate.encode("utf-8"))
+    return murmur3_128_hex(buf)
+
+
+def join_datasets(datasets, indexes, debug=False):
+    """VariantsPcaDriver.joinDatasets (VariantsPca.scala:115-128): two-way INNER join on the variant
+    key; the joined record is calls1 ++ calls2 (cross product if a key repeats, as RDD.join does)."""
+    keyed = []
+    for data in datasets[:2]:
+        d = {}
+        for variant in data:
+            d.setdefault(get_variant_key(variant, debug), []).append(extract_call_info(variant, indexes))
+        keyed.append(d)
+    out = []
+    for key, calls1 in keyed[0].items():
+        for c1 in calls1:
+            for c2 in keyed[1].get(key, []):
+                out.append(c1 + c2)
+    return out
+
+
+def merge_datasets(datasets, variant_set_count, indexes):
+    """VariantsPcaDriver.mergeDatasets (VariantsPca.scala:136-148): union, group by variant key, keep
+    the groups with exactly variantSetCount members, concatenate their calls."""
+    groups = {}
+    for data in datasets:
+        for variant in data:
+            groups.setdefault(get_variant_key(variant), []).append(extract_call_info(variant, indexes))
+    return [[c for calls in g for c in calls] for g in groups.values() if len(g) == variant_set_count]
+
+
 # --------------------------------------------------------------------------------------------- a3
 def calculate_similarity_matrix(call_rdd, matrix_size, engine=None, device=0):
     """calculate_similarity_matrix (variants_pca.py:54-82) == getSimilarityMatrix
@@ -115,8 +202,10 @@ class PcaConf(object):
         p = argparse.ArgumentParser(prog="VariantsPcaDriver", description=self.__doc__)
         p.add_argument("--bases-per-partition", type=int, default=1000000)
         p.add_argument("--client-secrets", type=str, default=None)
-        p.add_argument("--input-path", type=str, default=None,
-                       help=".npz (callset_ids, [callset_names], sample_idx, row_offsets) or .vcf[.gz]")
+        p.add_argument("--input-path", type=str, nargs="*", default=None,
+                       help="one local dataset per variant set: .npz (callset_ids, [callset_names], sample_idx, "
+                            "row_offsets) or .vcf[.gz]; two files are joined, three or more merged "
+                            "(VariantsPca.scala:153-162)")
         p.add_argument("--num-reduce-partitions", type=int, default=10)
         p.add_argument("--output-path", type=str, default=None)
         p.add_argument("--references", type=str, nargs="*", default=["chr17:41196311:41277499"])
@@ -198,14 +287,26 @@ class VariantsPcaDriver(object):
                 out.append(variant)
         return out
 
-    # getCallsRdd, VariantsPca.scala:153-168 (single-dataset branch; join/merge are SURVEY 8f "next")
+    # getCallsRdd, VariantsPca.scala:153-168
     def getCallsRdd(self, data):
-        if len(data) != 1:
-            raise NotImplementedError("multi-dataset join/merge (VariantsPca.scala:115-148) is not on the hot path yet")
-        d = data[0]
-        if isinstance(d, tuple):
-            return (d[1], d[2])
-        return prepare_call_data(d, self.indexes)
+        variant_set_count = len(data)
+        if variant_set_count == 1:
+            d = data[0]
+            if isinstance(d, tuple):  # pre-extracted carriers (CSR): already filtered
+                return (d[1], d[2])
+            return prepare_call_data(d, self.indexes)
+        if any(isinstance(d, tuple) for d in data):
+            raise ValueError("joining datasets needs variant records (contig/start/end/ref/alt), not CSR carriers")
+        if variant_set_count == 2:
+            callsets = join_datasets(data, self.indexes, self.conf.debug_datasets)
+        else:
+            callsets = merge_datasets(data, variant_set_count, self.indexes)
+        out = []
+        for calls in callsets:  # :164-167
+            kept = [idx for (has_variation, idx) in calls if has_variation]
+            if len(kept) > 0:
+                out.append(kept)
+        return out
 
     # getSimilarityMatrix, VariantsPca.scala:182-191
     def getSimilarityMatrix(self, callsets):
@@ -260,9 +361,29 @@ def load_dataset(conf):
     if not conf.inputPath:
         raise SystemExit("--input-path (local .npz or .vcf[.gz]) or --synthetic V,N,seed is required: "
                          "the Google Genomics API the reference read from has been shut down")
-    if conf.inputPath.endswith(".npz"):
-        return ingest.load_npz(conf.inputPath)
-    return ingest.load_vcf(conf.inputPath, conf.references if not conf.all_references else None)
+    paths = conf.inputPath if isinstance(conf.inputPath, (list, tuple)) else [conf.inputPath]
+    refs = None if conf.all_references else conf.references
+    if len(paths) == 1 and conf.minAlleleFrequency is None:
+        if paths[0].endswith(".npz"):
+            return ingest.load_npz(paths[0])
+        return ingest.load_vcf(paths[0], refs)
+    # several variant sets (or the AF filter): full variant records are needed for keys and INFO/AF
+    print("Running PCA on %d datasets." % len(paths))  # VariantsCommon.scala:57
+    indexes, names, data = {}, {}, []
+    for k, path in enumerate(paths):
+        ids, nm, variants = ingest.load_vcf_records(path, parse_refs(refs, k))
+        for cid in ids:
+            indexes[cid] = len(indexes)
+        names.update(nm)
+        data.append(variants)
+    return indexes, names, data
+
+
+def parse_refs(refs, k):
+    """--references holds one list of tuples per variant set, in order (GenomicsConf.scala:47-51)."""
+    if not refs:
+        return None
+    return [refs[k]] if k < len(refs) else [refs[-1]]
 
 
 def main(args):

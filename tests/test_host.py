@@ -153,3 +153,50 @@ def test_vcf_ingest(tmp_path):
     _, idx, offs = data[0]
     assert list(offs) == [0, 1, 3] and list(idx) == [0, 1, 2]
     assert all(k.split("-")[0] == "brca1" for k in indexes)
+
+
+def test_murmur3_128_matches_guava_known_answers():
+    vp = load_pkg("variants_pca")
+    assert vp.murmur3_128_hex(b"") == "00000000000000000000000000000000"
+    # Guava: Hashing.murmur3_128().hashString("hello", UTF_8).toString()
+    assert vp.murmur3_128_hex(b"hello") == "029bbd41b3a7d8cb191dae486a901e5b"
+    # MurmurHash3_x64_128 reference vector ("The quick brown fox jumps over the lazy dog", seed 0)
+    assert vp.murmur3_128_hex(b"The quick brown fox jumps over the lazy dog") == "6c1b07bc7bbc4be347939ac4a93c437a"
+    k1 = vp.get_variant_key({"contig": "17", "start": 41196311, "end": 41196312, "referenceBases": "A",
+                             "alternateBases": ["G"]})
+    k2 = vp.get_variant_key({"contig": "17", "start": 41196311, "end": 41196312, "referenceBases": "A",
+                             "alternateBases": ["G", "T"]})
+    assert len(k1) == 32 and k1 != k2
+
+
+def _variant(contig, start, ref, alts, calls, af=None):
+    v = {"contig": contig, "start": start, "end": start + len(ref), "referenceBases": ref, "alternateBases": alts,
+         "calls": [{"callSetId": c, "genotype": g} for c, g in calls]}
+    if af is not None:
+        v["info"] = {"AF": [str(af)]}
+    return v
+
+
+def test_join_and_merge_follow_the_reference_semantics():
+    vp = load_pkg("variants_pca")
+    idx = {"a-0": 0, "a-1": 1, "b-0": 2, "c-0": 3}
+    a = [_variant("17", 10, "A", ["G"], [("a-0", [0, 1]), ("a-1", [0, 0])]),
+         _variant("17", 20, "C", ["T"], [("a-0", [1, 1]), ("a-1", [0, 1])]),
+         _variant("17", 30, "G", ["A"], [("a-0", [0, 0]), ("a-1", [0, 0])])]
+    b = [_variant("17", 10, "A", ["G"], [("b-0", [1, 0])]),
+         _variant("17", 20, "C", ["G"], [("b-0", [1, 1])]),          # different ALT: no match
+         _variant("17", 30, "G", ["A"], [("b-0", [0, 0])])]          # nobody varies: dropped at :164-166
+    c = [_variant("17", 10, "A", ["G"], [("c-0", [0, 1])]), _variant("17", 30, "G", ["A"], [("c-0", [1, 1])])]
+    joined = vp.join_datasets([a, b], idx)
+    assert sorted(map(sorted, joined)) == sorted(map(sorted, [[(True, 0), (False, 1), (True, 2)],
+                                                               [(False, 0), (False, 1), (False, 2)]]))
+    drv = vp.VariantsPcaDriver.__new__(vp.VariantsPcaDriver)
+    drv.conf, drv.indexes = vp.PcaConf([]), idx
+    assert sorted(map(sorted, drv.getCallsRdd([a, b]))) == [[0, 2]]
+    merged = drv.getCallsRdd([a, b, c])                                # keys present in all three sets
+    assert sorted(map(sorted, merged)) == [[0, 2, 3], [3]]
+    # AF filter (VariantsPca.scala:96-108): variants without AF are dropped, comparison in float
+    drv.conf = vp.PcaConf(["--min-allele-frequency", "0.05"])
+    data = [_variant("17", 1, "A", ["G"], [], af=0.05), _variant("17", 2, "A", ["G"], [], af=0.01),
+            _variant("17", 3, "A", ["G"], [])]
+    assert [v["start"] for v in drv.filterDataset(data)] == [1]
