@@ -482,3 +482,76 @@ def test_driver_main_end_to_end(P, O, tmp_path, capsys):
     assert by_name[names[0]][1] == ids[0].split("-")[0]
     saved = open(str(tmp_path / "res") + "-pca.tsv").read().splitlines()
     assert len(saved) == 40 and saved[0].split("\t")[0] == sorted(names)[0]
+
+
+# ------------------------------------------------------------------------------------------ compiled host
+def _write_vcf(path, sample_names, records, gz=False):
+    import gzip
+    opener = gzip.open if gz else open
+    with opener(path, "wt") as f:
+        f.write("##fileformat=VCFv4.2\n")
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(sample_names) + "\n")
+        for (chrom, pos, ref, alt, af, gts) in records:
+            info = "AF=%s" % af if af is not None else "."
+            f.write("%s\t%d\t.\t%s\t%s\t.\tPASS\t%s\tGT\t%s\n" % (chrom, pos, ref, alt, info, "\t".join(gts)))
+
+
+def _make_cohorts(tmp_path, seed=5):
+    """Three small variant sets over partly shared sites, with planted structure."""
+    rng = np.random.default_rng(seed)
+    bases = "ACGT"
+    sites = []
+    for k in range(160):
+        ref = bases[rng.integers(0, 4)]
+        alt = bases[(bases.index(ref) + 1 + rng.integers(0, 3)) % 4]
+        sites.append(("chr17" if k % 2 else "17", 41196312 + 7 * k, ref, alt))
+    sets = []
+    for d, nsamp in enumerate((11, 9, 7)):
+        names = ["D%dS%02d" % (d, i) for i in range(nsamp)]
+        pops = np.arange(nsamp) % 2
+        recs = []
+        for k, (chrom, pos, ref, alt) in enumerate(sites):
+            if d == 1 and k % 5 == 0:
+                continue                      # site missing from set 1 -> not joined
+            a = alt if not (d == 2 and k % 7 == 0) else alt + "T"   # different ALT in set 2 -> different key
+            p = np.where(pops == (k % 2), 0.6, 0.1)
+            gts = []
+            for i in range(nsamp):
+                g = (int(rng.random() < p[i]), int(rng.random() < p[i]))
+                gts.append("%d|%d" % g if rng.random() > 0.05 else "./.")
+            recs.append((chrom, pos, ref, a, "%.3f" % rng.uniform(0.0, 0.3) if k % 11 else None, gts))
+        recs.append(("X", 5, "A", "C", "0.2", ["1|1"] * nsamp))                 # dropped contig
+        recs.append(("17", 50000000, "A", "C", "0.2", ["1|1"] * nsamp))          # outside --references
+        path = str(tmp_path / ("set%d.vcf%s" % (d, ".gz" if d == 1 else "")))
+        _write_vcf(path, names, recs, gz=(d == 1))
+        sets.append(path)
+    return sets
+
+
+@pytest.mark.parametrize("nsets,extra", [(1, []), (2, []), (3, []), (2, ["--min-allele-frequency", "0.1"])])
+def test_cpp_driver_matches_python_driver(P, tmp_path, capsys, nsets, extra):
+    exe = os.path.join(ROOT, "spark-examples_amd", "variants_pca_driver")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    vp = load_pkg("variants_pca")
+    sets = _make_cohorts(tmp_path)[:nsets]
+    args = ["--input-path"] + sets + ["--references", "chr17:41196311:41277499", "--output-path", str(tmp_path / "py")] + extra
+    assert vp.main(args) == 0
+    py_out = capsys.readouterr().out.splitlines()
+    cpp_args = [a if a != str(tmp_path / "py") else str(tmp_path / "cpp") for a in args]
+    res = subprocess.run([exe] + cpp_args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+    assert res.returncode == 0, res.stderr
+    cpp_out = res.stdout.splitlines()
+    head_py = [l for l in py_out if "\t" not in l]
+    head_cpp = [l for l in cpp_out if "\t" not in l]
+    assert head_py == head_cpp
+    rows_py = [l.split("\t") for l in py_out if "\t" in l]
+    rows_cpp = [l.split("\t") for l in cpp_out if "\t" in l]
+    assert [r[:2] for r in rows_py] == [r[:2] for r in rows_cpp] and len(rows_py) == sum((11, 9, 7)[:nsets])
+    a = np.array([[float(r[2]), float(r[3])] for r in rows_py])
+    b = np.array([[float(r[2]), float(r[3])] for r in rows_cpp])
+    assert np.abs(align_sign(b, a) - a).max() < 1e-9
+    # identical formatting of identical doubles (Double.toString rules)
+    fmt = load_pkg("variants_pca").java_double_to_string
+    for r in rows_cpp:
+        assert fmt(float(r[2])) == r[2] and fmt(float(r[3])) == r[3]
+    assert open(str(tmp_path / "cpp") + "-pca.tsv").read().count("\n") == len(rows_cpp)
