@@ -83,10 +83,11 @@ Conf parse(int argc, char** argv) {
 }
 
 // ---- Double.toString (what Scala's string interpolation prints, :239) --------------------------
-std::string java_double(double d) {
+template <typename T>  // T = double: Double.toString; T = float: Float.toString (same layout rules)
+std::string java_number(T d) {
   if (std::isnan(d)) return "NaN";
   if (std::isinf(d)) return d > 0 ? "Infinity" : "-Infinity";
-  if (d == 0.0) return std::signbit(d) ? "-0.0" : "0.0";
+  if (d == 0) return std::signbit(d) ? "-0.0" : "0.0";
   char buf[64];
   auto r = std::to_chars(buf, buf + sizeof(buf), std::fabs(d), std::chars_format::scientific);  // shortest round trip
   std::string s(buf, r.ptr);                      // d.ddddde[+-]XX
@@ -113,6 +114,7 @@ std::string java_double(double d) {
   }
   return sign + digits.substr(0, 1) + "." + (digits.size() > 1 ? digits.substr(1) : "0") + "E" + std::to_string(e10);
 }
+std::string java_double(double d) { return java_number<double>(d); }
 
 // ---- Guava Hashing.murmur3_128().hashBytes(..).toString() -------------------------------------
 inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
@@ -320,8 +322,8 @@ int main(int argc, char** argv) {
 
   // filterDataset (:96-108)
   if (conf.has_maf) {
-    std::printf("Min allele frequency %s.\n", java_double((double)conf.min_allele_frequency).c_str());
     for (auto& d : data) {
+      std::printf("Min allele frequency %s.\n", java_number<float>(conf.min_allele_frequency).c_str());  // per dataset (:43)
       std::vector<Variant> kept;
       for (auto& v : d.variants)
         if (v.has_af && v.af >= conf.min_allele_frequency) kept.push_back(std::move(v));

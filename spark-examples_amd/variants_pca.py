@@ -226,9 +226,16 @@ class PcaConf(object):
         self.minAlleleFrequency = a.min_allele_frequency
 
 
-def java_double_to_string(d):
+def java_float_to_string(f):
+    """Float.toString (the reference prints --min-allele-frequency, a Float, at VariantsPca.scala:99)."""
+    f32 = np.float32(f)
+    return java_double_to_string(float(f32), shortest=np.format_float_scientific(abs(f32), unique=True, trim="0"))
+
+
+def java_double_to_string(d, shortest=None):
     """Double.toString, which the reference's string interpolation uses (VariantsPca.scala:239):
-    decimal for 1e-3 <= |d| < 1e7, otherwise computerised scientific notation (1.0E-4)."""
+    decimal for 1e-3 <= |d| < 1e7, otherwise computerised scientific notation (1.0E-4).
+    `shortest`: the shortest round-trip digits of |d| when they are not repr(double)'s (Float.toString)."""
     d = float(d)
     if d != d:
         return "NaN"
@@ -236,7 +243,7 @@ def java_double_to_string(d):
         return "Infinity" if d > 0 else "-Infinity"
     if d == 0.0:
         return "-0.0" if str(d).startswith("-") else "0.0"
-    r = repr(abs(d))
+    r = shortest if shortest is not None else repr(abs(d))
     mant, _, exp = r.partition("e")
     e10 = int(exp) if exp else 0
     ip, _, fp = mant.partition(".")
@@ -279,7 +286,7 @@ class VariantsPcaDriver(object):
         maf = self.conf.minAlleleFrequency
         if maf is None or isinstance(data, tuple):
             return data
-        print("Min allele frequency %s." % java_double_to_string(np.float32(maf)))
+        print("Min allele frequency %s." % java_float_to_string(maf))
         out = []
         for variant in data:
             af = (variant.get("info") or {}).get("AF")

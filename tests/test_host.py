@@ -76,6 +76,8 @@ def test_java_double_to_string():
     assert f(-0.008456233951873527) == "-0.008456233951873527"
     assert f(1.234e-4) == "1.234E-4" and f(1.0) == "1.0" and f(12345678.9) == "1.23456789E7"
     assert f(0.001) == "0.001" and f(9.999e-4) == "9.999E-4" and f(0.0) == "0.0" and f(100.0) == "100.0"
+    g = load_pkg("variants_pca").java_float_to_string
+    assert g(0.1) == "0.1" and g(0.05) == "0.05" and g(1e-4) == "1.0E-4" and g(0.25) == "0.25" and g(3) == "3.0"
 
 
 def test_pcaconf_flags_and_defaults():
