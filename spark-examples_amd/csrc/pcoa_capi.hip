@@ -424,6 +424,11 @@ int pcoa_create(pcoa_ctx** out, int32_t n_samples, int32_t device_ordinal, uint3
     if (!std::strcmp(kk, "i8")) c->use_i8 = true;
   }
   c->gram_kind = c->use_i8 ? 2 : 1;
+  {
+    // keep the int8 workspace at or below ~4 GiB whatever N is (one byte per genotype, Npad columns)
+    const int64_t by_mem = (((int64_t)4 << 30) / gram_i8_npad(n_samples)) / 1536 * 1536;
+    c->pack_chunk = std::max<int64_t>(1536, std::min<int64_t>(c->pack_chunk, by_mem));
+  }
   if (const char* pc = std::getenv("PCOA_DEBUG_PACK_CHUNK")) {
     const long long x = std::atoll(pc);
     if (x > 0 && x <= ((long long)1 << 24)) c->pack_chunk = (int64_t)x;

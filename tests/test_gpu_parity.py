@@ -411,6 +411,31 @@ def test_compute_from_loaded_matrix_entries_and_degenerate_inputs(P, O):
     assert np.abs(align_sign(comps, ref["components"])[:, 0] - ref["components"][:, 0]).max() < 1e-12
 
 
+def test_larger_sample_count_many_tiles(P, O):
+    """N = 6000 (24 x 24 tile grid, 300 upper tiles): Gram vs the BLAS oracle, centring vs the oracle, and the
+    eigenpairs by their residual against B (a 6000^2 LAPACK reference would take minutes)."""
+    synth = load_pkg("synth")
+    n, v, seed = 6000, 5000, 4242
+    offs = synth.pop_offsets(n)
+    thr = synth.thresholds(seed, 0, v)
+    x = synth.genotypes(seed, 0, thr, offs)
+    want = O.similarity_from_dense_blas(x)
+    with P.PcoaEngine(n) as eng:
+        eng.accumulate_synthetic(seed, offs, thr, 0)
+        assert np.array_equal(eng.gram(), want)
+        b, rs, nz, mm = eng.center()
+        bo, rso, nzo, mmo = O.center_matrix(want)
+        assert np.array_equal(b, bo) and nz == nzo and mm == mmo
+        comps, lam, _ = eng.compute(2)
+        t = eng.timings()
+    for c in range(2):
+        assert abs(np.linalg.norm(comps[:, c]) - 1) < 1e-12
+        assert np.linalg.norm(b @ comps[:, c] - lam[c] * comps[:, c]) <= 1e-9 * abs(lam[c])
+    assert abs(comps[:, 0] @ comps[:, 1]) < 1e-10 and lam[0] > lam[1] > 0
+    print("N=6000 PCoA wall %.2f ms (method %d, %d Lanczos steps)" %
+          (1e3 * t["compute_total_seconds"], t["eig_method"], t["lanczos_steps"]))
+
+
 # ------------------------------------------------------------------------------------------ multi-GPU plumbing
 def test_native_rccl_allreduce_single_rank(P, O):
     rng = np.random.default_rng(4)
