@@ -277,6 +277,31 @@ def main():
                                    "note": "same cohort handed over as uint8 [V][N] (pcoa_accumulate_dense_u8); "
                                            "not the BASELINE configs[1] fp32 boundary, reported for reference"}
             del x8
+        if world == 1:
+            # BASELINE configs[0] stand-in: BRCA1-sized region (2,500 variants) through the faithful CSR boundary
+            # (pcoa_accumulate_calls, host arrays), end to end: H2D + densify + Gram + finalize + PCoA + D2H
+            v1 = 2500
+            thr1 = synth.thresholds(1001, 0, v1)
+            x1 = synth.genotypes(1001, 0, thr1, offs, dtype=np.uint8)
+            x1 = x1[x1.any(axis=1)]
+            offs1 = np.concatenate([[0], np.cumsum(x1.sum(axis=1, dtype=np.int64))]).astype(np.int64)
+            idx1 = np.nonzero(x1)[1].astype(np.int32)
+            with P.PcoaEngine(n, device=local_rank) as e1:
+                walls = []
+                for _ in range(4):
+                    e1.reset()
+                    t1 = time.perf_counter()
+                    e1.accumulate_calls(idx1, offs1)
+                    e1.finalize()
+                    c1, l1, _ = e1.compute(2)
+                    walls.append(1e3 * (time.perf_counter() - t1))
+                tt1 = e1.timings()
+            out["config0_csr_end_to_end"] = {
+                "workload": "configs[0] stand-in: synthetic BRCA1-sized region, %d variants x %d samples, %d carriers, "
+                            "host CSR through pcoa_accumulate_calls" % (x1.shape[0], n, idx1.size),
+                "wall_ms": float(min(walls[1:])), "wall_ms_all": walls,
+                "eig_method": {1: "lanczos", 2: "householder"}.get(tt1["eig_method"], "?"),
+                "eigenvalues": [float(t) for t in l1]}
         if world == 1 and not args.no_cpu_baseline:
             base, s_ref, sample = cpu_baseline(x, n)
             out["cpu_baseline"] = base

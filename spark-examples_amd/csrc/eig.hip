@@ -280,17 +280,21 @@ __global__ __launch_bounds__(256) void bisect_kernel(const double* __restrict__ 
 // scheme: LU with partial pivoting of T - lambda I as in dgttrf, a few solves from a fixed
 // pseudo-random start, re-orthogonalisation inside clusters).  The recurrences are serial in i,
 // so lane 0 of a single wave runs them; norms and axpys use all 64 lanes.
-// scratch: dl[n] dd[n] du[n] du2[n] y[n]
+// scratch: dl[n] dd[n] du[n] du2[n] y[n]; with use_lds the five arrays and the pivots live in
+// dynamic LDS (44 n bytes, n <= ~3600), which cuts the latency of every step of the serial chain.
 __global__ __launch_bounds__(64) void invit_kernel(const double* __restrict__ d, const double* __restrict__ e,
                                                    int n, const double* __restrict__ lam, int k,
                                                    double* __restrict__ z, double* __restrict__ scratch,
-                                                   int* __restrict__ ipiv) {
+                                                   int* __restrict__ ipiv_global, int use_lds) {
+  extern __shared__ __attribute__((aligned(16))) double invit_lds[];
   const int lane = threadIdx.x;
-  double* dl = scratch;
-  double* dd = scratch + (int64_t)n;
-  double* du = scratch + 2 * (int64_t)n;
-  double* du2 = scratch + 3 * (int64_t)n;
-  double* y = scratch + 4 * (int64_t)n;
+  double* base = use_lds ? invit_lds : scratch;
+  double* dl = base;
+  double* dd = base + (int64_t)n;
+  double* du = base + 2 * (int64_t)n;
+  double* du2 = base + 3 * (int64_t)n;
+  double* y = base + 4 * (int64_t)n;
+  int* ipiv = use_lds ? reinterpret_cast<int*>(invit_lds + 5 * (int64_t)n) : ipiv_global;
 
   double tn = 0.0;
   for (int i = lane; i < n; i += 64) {
@@ -501,8 +505,19 @@ hipError_t launch_inverse_iteration(const EigWorkspace& ws, int32_t n, const dou
   // selected eigenvalues go to ws.lam[0..k) (the candidates there have been consumed by the host)
   hipError_t err = hipMemcpyAsync(ws.lam, lam_sel_host, sizeof(double) * k, hipMemcpyHostToDevice, stream);
   if (err != hipSuccess) return err;
-  hipLaunchKernelGGL(invit_kernel, dim3(1), dim3(64), 0, stream, ws.d, ws.e, n, ws.lam, k, ws.z, ws.scratch,
-                     ws.iscratch);
+  const size_t lds = (size_t)n * (5 * sizeof(double) + sizeof(int)) + 16;
+  const int use_lds = lds <= 150 * 1024;
+  if (use_lds && lds > 64 * 1024) {
+    static bool raised = false;  // opt in to more than 64 KiB of dynamic LDS once
+    if (!raised) {
+      err = hipFuncSetAttribute(reinterpret_cast<const void*>(invit_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (err != hipSuccess) return err;
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL(invit_kernel, dim3(1), dim3(64), use_lds ? lds : 0, stream, ws.d, ws.e, n, ws.lam, k, ws.z,
+                     ws.scratch, ws.iscratch, use_lds);
   return hipGetLastError();
 }
 
