@@ -184,6 +184,10 @@ int pcoa_gram_import_device_i64(pcoa_ctx* ctx, const int64_t* src_dev);
  * matrix.iterator emits them, VariantsPca.scala:189).  For parity tests and checkpoints. */
 int pcoa_gram_read_i64(pcoa_ctx* ctx, int64_t* out_nxn);
 
+/* Copies the block S[row0 .. row0+rows) x [col0 .. col0+cols) of the finalized S to host (row-major,
+ * rows x cols int64).  For spot checks and sliced checkpoints when N^2 entries are too many to move. */
+int pcoa_gram_read_block_i64(pcoa_ctx* ctx, int32_t row0, int32_t col0, int32_t rows, int32_t cols, int64_t* out);
+
 /* Loads S from host int64 [N][N] (resume from a checkpoint, or enter at computePca with matrix
  * entries produced elsewhere: computePca(matrixEntries), VariantsPca.scala:198). */
 int pcoa_gram_load_i64(pcoa_ctx* ctx, const int64_t* in_nxn);

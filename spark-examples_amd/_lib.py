@@ -89,6 +89,7 @@ _SIGNATURES = [
     ("pcoa_gram_export_device_i64", ctypes.c_int, [_vp, _vp]),
     ("pcoa_gram_import_device_i64", ctypes.c_int, [_vp, _vp]),
     ("pcoa_gram_read_i64", ctypes.c_int, [_vp, _vp]),
+    ("pcoa_gram_read_block_i64", ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _vp]),
     ("pcoa_gram_load_i64", ctypes.c_int, [_vp, _vp]),
     ("pcoa_center_read_f64", ctypes.c_int, [_vp, _vp, _vp, ctypes.POINTER(_i32), ctypes.POINTER(ctypes.c_double)]),
     ("pcoa_compute", ctypes.c_int, [_vp, _i32, _vp, _vp, ctypes.POINTER(_i32)]),

@@ -310,21 +310,48 @@ __device__ __forceinline__ void ring_round(StageI8<NWM, SKB>* lds, const int8_t*
    ...);
 }
 
-// Tile enumeration over the upper triangle.  Row blocks are 128*NWM samples, column blocks 256.
-//   NWM = 2: (ti, tj) with ti <= tj, T(T+1)/2 tiles.
-//   NWM = 1: row block r in [0, 2T), column block c >= r/2: T(T+1) tiles (half the size each).
+// Tile enumeration over the upper triangle (any bijection is valid: every tile is computed once).
+//   NWM = 2: tiles (ti <= tj) of 256 x 256, visited in BANDS of 16 tile rows; inside a band the order is
+//            column by column.  Workgroups that run at the same time (~256 consecutive indices) then
+//            cover about a 16 x 16 block of tiles and share 16 + 16 operand panels instead of 1 + 256,
+//            which is what keeps the contraction off the HBM roofline when N is large (N = 100k: 77,028
+//            tiles, 4 MB of operand per panel and launch).  At N = 2504 there is a single band.
+//   NWM = 1: row block r in [0, 2T) of 128 samples, column block c >= r/2: T(T+1) tiles, simple order.
+constexpr int BAND = 16;
+
 template <int NWM>
 __device__ __forceinline__ void tile_coords(int tile, int ntile, int& row_blk, int& col_blk) {
-  int sup = 0, rem = tile;  // super-row = 256-sample row block
-  const int per = (NWM == 2) ? 1 : 2;
-  while (rem >= per * (ntile - sup)) {
-    rem -= per * (ntile - sup);
-    ++sup;
-  }
   if (NWM == 2) {
-    row_blk = sup;
-    col_blk = sup + rem;
+    int r0 = 0, rem = tile;
+    for (;;) {
+      const int h = (ntile - r0 < BAND) ? (ntile - r0) : BAND;   // rows in this band
+      const int in_band = h * (h + 1) / 2 + (ntile - r0 - h) * h;
+      if (rem < in_band) {
+        const int tri = h * (h + 1) / 2;
+        if (rem < tri) {               // triangular head: column c (relative) holds c + 1 tiles
+          int c = 0;
+          while (rem >= c + 1) {
+            rem -= c + 1;
+            ++c;
+          }
+          row_blk = r0 + rem;
+          col_blk = r0 + c;
+        } else {                       // rectangular part: h tiles per column
+          const int q = rem - tri;
+          row_blk = r0 + q % h;
+          col_blk = r0 + h + q / h;
+        }
+        return;
+      }
+      rem -= in_band;
+      r0 += h;
+    }
   } else {
+    int sup = 0, rem = tile;
+    while (rem >= 2 * (ntile - sup)) {
+      rem -= 2 * (ntile - sup);
+      ++sup;
+    }
     const int half = rem / (ntile - sup);
     row_blk = 2 * sup + half;
     col_blk = sup + (rem - half * (ntile - sup));

@@ -191,6 +191,15 @@ int ensure(pcoa_ctx* c, T** buf, int64_t* cap, int64_t need) {
 
 int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
+// Rows of the fp32 staging tile: 256 MiB for ordinary N; for very wide matrices at least ~16k variants per
+// contraction launch (every launch pays one int32-atomic epilogue per output tile), capped at 8 GiB.
+int64_t staging_rows(int64_t n_variants, int64_t ld4) {
+  int64_t rows = ((int64_t)64 << 20) / ld4;
+  const int64_t want = 16384, cap = ((int64_t)2 << 30) / ld4;
+  if (rows < want) rows = std::min(want, cap);
+  return std::max<int64_t>(1, std::min(n_variants, rows));
+}
+
 constexpr int64_t kMaxLaunchVariants = (int64_t)1 << 24;  // fp32 accumulators exact below 2^24
 constexpr int64_t kFoldThreshold = (int64_t)1 << 30;      // fold int32 partials long before 2^31
 
@@ -515,7 +524,7 @@ int pcoa_accumulate_dense_f32(pcoa_ctx* c, const float* x, int64_t n_variants, i
   if (is_device_ptr) return gram_device(c, x, n_variants, ld);
   // host tile: stage through a device tile of at most ~256 MiB, rows packed at ld4 = round_up(n, 4)
   const int64_t ld4 = round_up(c->n, 4);
-  const int64_t rows_cap = std::max<int64_t>(1, std::min<int64_t>(n_variants, ((int64_t)64 << 20) / ld4));
+  const int64_t rows_cap = staging_rows(n_variants, ld4);
   int rc = ensure(c, &c->tile, &c->tile_elems, rows_cap * ld4);
   if (rc != PCOA_OK) return rc;
   for (int64_t v0 = 0; v0 < n_variants; v0 += rows_cap) {
@@ -576,7 +585,7 @@ int pcoa_accumulate_calls(pcoa_ctx* c, const int32_t* sample_idx, const int64_t*
     }
   }
   const int64_t ld4 = round_up(c->n, 4);
-  const int64_t rows_cap = std::max<int64_t>(1, std::min<int64_t>(n_variants, ((int64_t)64 << 20) / ld4));
+  const int64_t rows_cap = staging_rows(n_variants, ld4);
   int rc = PCOA_OK;
   if (!c->use_i8) {
     rc = ensure(c, &c->tile, &c->tile_elems, rows_cap * ld4);
@@ -649,7 +658,7 @@ int pcoa_accumulate_synthetic(pcoa_ctx* c, const pcoa_synth_params* p, int64_t f
   if (n_variants == 0) return PCOA_OK;
   if (!p || !p->thresholds) return fail(c, PCOA_ERR_INVALID_ARG, "synthetic params: null");
   const int64_t ld4 = round_up(c->n, 4);
-  const int64_t rows_cap = std::max<int64_t>(1, std::min<int64_t>(n_variants, ((int64_t)64 << 20) / ld4));
+  const int64_t rows_cap = staging_rows(n_variants, ld4);
   int rc = ensure(c, &c->tile, &c->tile_elems, rows_cap * ld4);
   if (rc != PCOA_OK) return rc;
   for (int64_t v0 = 0; v0 < n_variants; v0 += rows_cap) {
@@ -708,6 +717,32 @@ int pcoa_gram_read_i64(pcoa_ctx* c, int64_t* out_nxn) {
   if (rc != PCOA_OK) return rc;
   HIP_TRY(c, hipMemcpyAsync(out_nxn, c->xfer, sizeof(int64_t) * nn, hipMemcpyDeviceToHost, c->stream));
   return check_device_flags(c);
+}
+
+int pcoa_gram_read_block_i64(pcoa_ctx* c, int32_t row0, int32_t col0, int32_t rows, int32_t cols, int64_t* out) {
+  CHECK_CTX(c);
+  if (!out || rows < 0 || cols < 0 || row0 < 0 || col0 < 0 || (int64_t)row0 + rows > c->n || (int64_t)col0 + cols > c->n)
+    return fail(c, PCOA_ERR_INVALID_ARG, "block outside the N x N matrix or out is NULL");
+  if (rows == 0 || cols == 0) return PCOA_OK;
+  int rc = finalize_impl(c);
+  if (rc != PCOA_OK) return rc;
+  // int32 partial and (if folded) int64 total are copied as strided blocks and summed on the host:
+  // no N x N exchange buffer, so this also works when N^2 * 8 B would not fit (N = 100k: 80 GB)
+  std::vector<int32_t> a((size_t)rows * (size_t)cols);
+  HIP_TRY(c, hipMemcpy2DAsync(a.data(), sizeof(int32_t) * (size_t)cols, c->s32 + (size_t)row0 * c->n + col0,
+                              sizeof(int32_t) * (size_t)c->n, sizeof(int32_t) * (size_t)cols, (size_t)rows,
+                              hipMemcpyDeviceToHost, c->stream));
+  std::vector<int64_t> b;
+  if (c->s64) {
+    b.resize(a.size());
+    HIP_TRY(c, hipMemcpy2DAsync(b.data(), sizeof(int64_t) * (size_t)cols, c->s64 + (size_t)row0 * c->n + col0,
+                                sizeof(int64_t) * (size_t)c->n, sizeof(int64_t) * (size_t)cols, (size_t)rows,
+                                hipMemcpyDeviceToHost, c->stream));
+  }
+  rc = check_device_flags(c);  // synchronises the stream
+  if (rc != PCOA_OK) return rc;
+  for (size_t i = 0; i < a.size(); ++i) out[i] = (int64_t)a[i] + (c->s64 ? b[i] : 0);
+  return PCOA_OK;
 }
 
 int pcoa_gram_load_i64(pcoa_ctx* c, const int64_t* in_nxn) {
@@ -856,6 +891,10 @@ int pcoa_compute(pcoa_ctx* c, int32_t num_pc, double* out_components, double* ou
       c->eig_method = 1;
     } else if (force_lanczos) {
       return fail(c, PCOA_ERR_NOT_CONVERGED, "Lanczos did not reach a verified residual (PCOA_FLAG_EIG_LANCZOS set)");
+    } else if (n > 16384) {
+      return fail(c, PCOA_ERR_NOT_CONVERGED,
+                  "Lanczos did not reach a verified residual and the dense O(N^3) fallback is disabled above "
+                  "N = 16384 (set PCOA_FLAG_EIG_HOUSEHOLDER to force it)");
     }
   }
   if (!have_vectors) {

@@ -187,6 +187,12 @@ class PcoaEngine(object):
         self._check(self._lib.pcoa_gram_read_i64(self._ctx, _ptr(out)))
         return out
 
+    def gram_block(self, row0, col0, rows, cols):
+        """The block S[row0:row0+rows, col0:col0+cols] as int64 (no N x N staging)."""
+        out = np.zeros((int(rows), int(cols)), dtype=np.int64)
+        self._check(self._lib.pcoa_gram_read_block_i64(self._ctx, int(row0), int(col0), int(rows), int(cols), _ptr(out)))
+        return out
+
     def load_gram(self, s):
         a = np.ascontiguousarray(s, dtype=np.int64)
         if a.shape != (self.n, self.n):

@@ -177,6 +177,19 @@ def test_empty_and_ragged_inputs(P):
         assert s[6, 6] == 2 and s[0, 6] == 1 and s[6, 0] == 1 and s[0, 0] == 1 and s.sum() == 5
 
 
+def test_gram_block_readback(P, O):
+    rng = np.random.default_rng(8)
+    x = (rng.random((300, 70)) < 0.3).astype(np.float32)
+    want = O.similarity_from_dense(x, 70)
+    with P.PcoaEngine(70) as eng:
+        eng.accumulate_dense(x)
+        assert np.array_equal(eng.gram_block(0, 0, 70, 70), want)
+        assert np.array_equal(eng.gram_block(5, 33, 17, 20), want[5:22, 33:53])
+        assert np.array_equal(eng.gram_block(69, 0, 1, 70), want[69:70])
+        with pytest.raises(P.PcoaError):
+            eng.gram_block(60, 60, 11, 5)
+
+
 def test_index_out_of_range_is_rejected_and_leaves_s_unchanged(P):
     with P.PcoaEngine(5) as eng:
         eng.accumulate_callsets([[0, 1]])
