@@ -72,22 +72,24 @@ __global__ __launch_bounds__(256) void stats_kernel(const int64_t* __restrict__ 
 __global__ __launch_bounds__(256) void center_kernel(const int32_t* __restrict__ s32,
                                                      const int64_t* __restrict__ s64, int32_t n,
                                                      const double* __restrict__ row_sums,
-                                                     const double* __restrict__ stats, double* __restrict__ b,
-                                                     int32_t nbx) {
+                                                     const double* __restrict__ stats, double* __restrict__ b) {
+  // One workgroup per row, striding over the columns: the dispatch stays at N x 256 work-items.
+  // (A block per (row, 256-column chunk) is 1.0e10 work-items at N = 100,000 -- more than the 32-bit
+  // work-item count of a dispatch holds; it silently centred only part of the matrix.)
 #pragma clang fp contract(off)
-  const int i = blockIdx.x / nbx;
-  const int j = (blockIdx.x - i * nbx) * 256 + threadIdx.x;
-  if (j >= n) return;
+  const int i = blockIdx.x;
   const double rc = (double)n;
   const double row_mean = row_sums[i] / rc;
-  const double col_mean = row_sums[j] / rc;
   const double mmean = stats[1];
-  const int64_t idx = (int64_t)i * n + j;
-  const double data = (double)((int64_t)s32[idx] + (s64 ? s64[idx] : 0));
-  double t = data - row_mean;
-  t = t - col_mean;
-  t = t + mmean;
-  b[idx] = t;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    const double col_mean = row_sums[j] / rc;
+    const int64_t idx = (int64_t)i * n + j;
+    const double data = (double)((int64_t)s32[idx] + (s64 ? s64[idx] : 0));
+    double t = data - row_mean;
+    t = t - col_mean;
+    t = t + mmean;
+    b[idx] = t;
+  }
 }
 
 }  // namespace
@@ -100,9 +102,8 @@ hipError_t launch_center(const int32_t* s32, const int64_t* s64_or_null, int32_t
                      rs_i64);
   hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(256), 0, stream, rs_i64, n, stats, nz);
   if (b) {
-    const int32_t nbx = (n + 255) / 256;
-    hipLaunchKernelGGL(center_kernel, dim3((unsigned)((int64_t)nbx * n)), dim3(256), 0, stream, s32, s64_or_null,
-                       n, row_sums, stats, b, nbx);
+    hipLaunchKernelGGL(center_kernel, dim3((unsigned)n), dim3(256), 0, stream, s32, s64_or_null, n, row_sums, stats,
+                       b);
   }
   return hipGetLastError();
 }

@@ -17,6 +17,8 @@
 // a tiny spectral gap, breakdown) makes the caller fall back to the Householder solver, so the fast
 // path can never return a wrong answer silently.
 #include <cfloat>
+#include <cstdio>
+#include <cstdlib>
 
 #include "pcoa_internal.h"
 
@@ -253,6 +255,13 @@ hipError_t lanczos_topk(const EigWorkspace& ws, double* lz, int32_t n, int32_t k
     bool ok = true;
     for (int t = 0; t < k; ++t) ok = ok && accept(fabs(beta_m * ylast[t]), t);
     const bool breakdown = beta_m <= 1e-14 * scale;  // invariant subspace: T_m holds exact eigenvalues
+    static const bool trace = std::getenv("PCOA_DEBUG_LANCZOS") != nullptr;
+    if (trace) {
+      std::fprintf(stderr, "[lanczos] m=%d beta_m=%.3e scale=%.6e", m, beta_m, scale);
+      for (int t = 0; t < k; ++t)
+        std::fprintf(stderr, "  theta%d=%.10e est=%.3e gap=%.3e", t, lam_sel_host[t], fabs(beta_m * ylast[t]), gap[(size_t)t]);
+      std::fprintf(stderr, "  ok=%d\n", (int)ok);
+    }
     if (!ok && !breakdown) {
       if (m == mmax) return hipSuccess;
       continue;
@@ -271,6 +280,11 @@ hipError_t lanczos_topk(const EigWorkspace& ws, double* lz, int32_t n, int32_t k
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
     bool verified = true;
     for (int t = 0; t < k; ++t) verified = verified && std::isfinite(hres[t]) && accept(hres[t] * 0.125, t);
+    if (trace) {
+      std::fprintf(stderr, "[lanczos] m=%d true residuals:", m);
+      for (int t = 0; t < k; ++t) std::fprintf(stderr, " %.3e", hres[t]);
+      std::fprintf(stderr, "  verified=%d\n", (int)verified);
+    }
     if (verified) {
       *converged = 1;
       return hipGetLastError();

@@ -37,18 +37,23 @@ __global__ __launch_bounds__(256) void densify_csr_kernel(const int32_t* __restr
 // s[i][j] = s[j][i] for i > j, 32x32 tiles staged through LDS so both sides stay coalesced.
 __global__ __launch_bounds__(256) void symmetrize_i32_kernel(int32_t* __restrict__ s, int32_t n) {
   __shared__ int32_t t[32][33];
-  const int bi = blockIdx.y, bj = blockIdx.x;  // destination tile (rows bi, cols bj), bi >= bj
-  if (bi < bj) return;
+  const int ntile = (n + 31) / 32;
+  const int bj = blockIdx.x;                               // destination tile column
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  // read source tile (rows bj*32.., cols bi*32..) = the upper-triangular one
-  for (int r = ty; r < 32; r += 8) {
-    const int i = bj * 32 + r, j = bi * 32 + tx;
-    t[r][tx] = (i < n && j < n) ? s[(int64_t)i * n + j] : 0;
-  }
-  __syncthreads();
-  for (int r = ty; r < 32; r += 8) {
-    const int i = bi * 32 + r, j = bj * 32 + tx;
-    if (i < n && j < n && i > j) s[(int64_t)i * n + j] = t[tx][r];
+  // grid.y strides over the destination tile rows so that the dispatch stays below 2^32 work-items
+  for (int bi = blockIdx.y; bi < ntile; bi += gridDim.y) {
+    if (bi < bj) continue;  // uniform per workgroup
+    // read source tile (rows bj*32.., cols bi*32..) = the upper-triangular one
+    for (int r = ty; r < 32; r += 8) {
+      const int i = bj * 32 + r, j = bi * 32 + tx;
+      t[r][tx] = (i < n && j < n) ? s[(int64_t)i * n + j] : 0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+      const int i = bi * 32 + r, j = bj * 32 + tx;
+      if (i < n && j < n && i > j) s[(int64_t)i * n + j] = t[tx][r];
+    }
+    __syncthreads();
   }
 }
 
@@ -141,7 +146,8 @@ hipError_t launch_densify_csr(const int32_t* idx_dev, const int64_t* offs_dev, i
 
 hipError_t launch_symmetrize_i32(int32_t* s32, int32_t n, hipStream_t stream) {
   const unsigned t = (unsigned)((n + 31) / 32);
-  hipLaunchKernelGGL(symmetrize_i32_kernel, dim3(t, t), dim3(256), 0, stream, s32, n);
+  const unsigned ty = t < 2048u ? t : 2048u;  // t * ty * 256 work-items < 2^32 up to N = 262,144
+  hipLaunchKernelGGL(symmetrize_i32_kernel, dim3(t, ty), dim3(256), 0, stream, s32, n);
   return hipGetLastError();
 }
 
