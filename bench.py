@@ -38,7 +38,7 @@ def pkg(sub=None):
     return importlib.import_module("spark-examples_amd" + ("." + sub if sub else ""))
 
 
-def cpu_baseline(x_dev, n, budget_s=12.0):
+def cpu_baseline(x_dev, n, budget_s=20.0):
     """The oracle's faithful pair loop (reference VariantsPca.scala:184-190 restated in C/OpenMP) timed
     on this box's host cores, on a bounded sample of the same workload.  Baseline only."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))

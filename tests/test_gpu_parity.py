@@ -394,6 +394,31 @@ def test_tiny_spectral_gap_falls_back_or_converges_correctly(P, O):
             assert np.linalg.norm(b @ comps[:, c] - lam[c] * comps[:, c]) <= 1e-8 * abs(lam[c])
 
 
+def test_rank_deficient_inputs_through_the_lanczos_path(P, O):
+    """Few variants => B has rank <= V: the Krylov space is exhausted after a handful of steps (breakdown).
+    The fast path must either verify its pairs or fall back; the answer must be right either way."""
+    rng = np.random.default_rng(31)
+    n = 100
+    for v in (1, 2, 3, 7):
+        x = (rng.random((v, n)) < 0.4).astype(np.float32)
+        s = O.similarity_from_dense(x, n)
+        b = O.center_matrix(s)[0]
+        lam_ref = np.sort(np.linalg.eigvalsh(b))[::-1]
+        k = min(2, v)
+        with P.PcoaEngine(n) as eng:
+            eng.accumulate_dense(x)
+            comps, lam, _ = eng.compute(k)
+        assert np.allclose(lam, lam_ref[:k], rtol=1e-9, atol=1e-9 * abs(lam_ref[0]))
+        for c in range(k):
+            assert abs(np.linalg.norm(comps[:, c]) - 1) < 1e-12
+            if lam_ref[c] > 1e-6 * lam_ref[0] and (c + 1 >= n or lam_ref[c] - lam_ref[c + 1] > 1e-6 * lam_ref[0]):
+                assert np.linalg.norm(b @ comps[:, c] - lam[c] * comps[:, c]) <= 1e-9 * lam_ref[0]
+    with P.PcoaEngine(64) as eng:   # no variants at all: B = 0
+        comps, lam, nz = eng.compute(2)
+    assert nz == 0 and np.allclose(lam, 0) and np.isfinite(comps).all()
+    assert np.allclose(np.linalg.norm(comps, axis=0), 1.0)
+
+
 def test_compute_from_loaded_matrix_entries_and_degenerate_inputs(P, O):
     # computePca(matrixEntries) boundary: S produced elsewhere
     rng = np.random.default_rng(21)
