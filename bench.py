@@ -302,6 +302,20 @@ def main():
                 "wall_ms": float(min(walls[1:])), "wall_ms_all": walls,
                 "eig_method": {1: "lanczos", 2: "householder"}.get(tt1["eig_method"], "?"),
                 "eigenvalues": [float(t) for t in l1]}
+        if world == 1:
+            # PCIe-inclusive rates (host tiles through the staging path): noted, never `value`
+            hv = min(v, 131072)
+            xh = x[:hv].cpu().numpy()
+            xh8 = xh.astype(np.uint8)
+            pcie = {}
+            for name, arr, fn in (("host_fp32", xh, eng.accumulate_dense), ("host_uint8", xh8, eng.accumulate_dense_u8)):
+                eng.reset(); fn(arr); eng.finalize(); eng.sync()
+                t1 = time.perf_counter()
+                eng.reset(); fn(arr); eng.finalize(); eng.sync()
+                pcie[name + "_variants_per_s"] = hv / (time.perf_counter() - t1)
+            pcie["note"] = "%d variants from pageable host memory, H2D included (pcoa_accumulate_dense_* with is_device_ptr=0)" % hv
+            out["pcie_inclusive"] = pcie
+            del xh, xh8
         if world == 1 and not args.no_cpu_baseline:
             base, s_ref, sample = cpu_baseline(x, n)
             out["cpu_baseline"] = base

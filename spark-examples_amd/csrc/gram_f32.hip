@@ -120,7 +120,7 @@ __device__ __forceinline__ void store_tile(const f32x16& c, int32_t* __restrict_
   for (int r = 0; r < 16; ++r) {
     const int i = row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     const int v = (int)c[r];
-    if (i < n && j < n && v != 0) atomicAdd(&s32[(int64_t)i * n + j], v);
+    if (j >= i && j < n && v != 0) atomicAdd(&s32[(int64_t)i * n + j], v);  // upper triangle only
   }
 }
 
@@ -161,6 +161,8 @@ __global__ __launch_bounds__(NT) void gram_f32_kernel(const float* __restrict__ 
   const int nstage2 = (int)((k_end - k_begin + 2 * BK - 1) / (2 * BK)) * 2;
 
   const int col_i = ti * BM, col_j = tj * BM;
+  // diagonal tiles: wave (1, 0) covers rows 64..127 x cols 0..63, entirely below the diagonal -> no MFMAs
+  const bool idle = (col_i + wm * 64) > (col_j + wn * 64 + 63);
 
   f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
 
@@ -173,14 +175,14 @@ __global__ __launch_bounds__(NT) void gram_f32_kernel(const float* __restrict__ 
     issue_stage<VEC>(&lds[1], x, ld, k_begin + (int64_t)(s + 1) * BK, k_end, col_i, col_j, zeros, wave, lane);
     wait_vmcnt<LD>();
     wg_barrier();
-    compute_stage(&lds[0], wm, wn, lane, c00, c01, c10, c11);
+    if (!idle) compute_stage(&lds[0], wm, wn, lane, c00, c01, c10, c11);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     wg_barrier();  // every wave is done reading buffer 0
     // stage s+2 -> buffer 0 goes in flight (zero rows past k_end); stage s+1 must have landed
     issue_stage<VEC>(&lds[0], x, ld, k_begin + (int64_t)(s + 2) * BK, k_end, col_i, col_j, zeros, wave, lane);
     wait_vmcnt<LD>();
     wg_barrier();
-    compute_stage(&lds[1], wm, wn, lane, c00, c01, c10, c11);
+    if (!idle) compute_stage(&lds[1], wm, wn, lane, c00, c01, c10, c11);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     wg_barrier();  // every wave is done reading buffer 1
   }
