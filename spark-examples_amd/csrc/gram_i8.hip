@@ -252,10 +252,10 @@ __device__ __forceinline__ void mfma_step_i8(const FragsI8<NNI>& f, i32x16 (&acc
 // may still be in flight (counted vmcnt), and stage s+D is issued into the buffer stage s-1 used.
 // Inside the stage the fragment reads are software-pipelined one k32-step ahead of the MFMAs
 // (two register sets of 24 VGPRs), so the stage depth SKB does not cost registers.
-template <int NWM, int NNI, int SKB, int NST, int BUF>
+template <int NWM, int NNI, int SKB, int NST, int BUF, bool IDLE>
 __device__ __forceinline__ void ring_step(StageI8<NWM, SKB>* lds, const int8_t* __restrict__ p, int npad,
                                           int64_t kb_begin, int s, int ns, int col_i, int col_j, int wave, int lane,
-                                          int wm, int wn, bool idle, i32x16 (&acc)[4][NNI]) {
+                                          int wm, int wn, i32x16 (&acc)[4][NNI]) {
   constexpr int NWAVES = NWM * (8 / NNI);
   constexpr int PER_WAVE = SKB * (2 * NWM + 4) / NWAVES;
   constexpr int D = NST - 1;
@@ -271,7 +271,7 @@ __device__ __forceinline__ void ring_step(StageI8<NWM, SKB>* lds, const int8_t* 
     else wait_vmcnt<0>();
   }
   wg_barrier();  // all waves' stage-s DMA landed, and all waves are done reading the buffer of stage s-1
-  if (idle) {  // this wave's sub-tile lies below the diagonal: it only helps with the DMA
+  if constexpr (IDLE) {  // this wave's sub-tile lies below the diagonal: it only helps with the DMA
     if (s + D < ns)
       issue_stage_i8<NWM, SKB, NWAVES>(&lds[(BUF + D) % NST], p, npad, kb_begin + (int64_t)(s + D) * SKB, col_i,
                                        col_j, wave, lane);
@@ -305,13 +305,13 @@ __device__ __forceinline__ void ring_prologue(StageI8<NWM, SKB>* lds, const int8
 }
 
 // `count` consecutive stages starting at s (s is a multiple of NST, so stage s+i lives in buffer i)
-template <int NWM, int NNI, int SKB, int NST, int... Is>
+template <int NWM, int NNI, int SKB, int NST, bool IDLE, int... Is>
 __device__ __forceinline__ void ring_round(StageI8<NWM, SKB>* lds, const int8_t* __restrict__ p, int npad,
                                            int64_t kb_begin, int s, int ns, int count, int col_i, int col_j,
-                                           int wave, int lane, int wm, int wn, bool idle, i32x16 (&acc)[4][NNI],
+                                           int wave, int lane, int wm, int wn, i32x16 (&acc)[4][NNI],
                                            std::integer_sequence<int, Is...>) {
-  ((Is < count ? ring_step<NWM, NNI, SKB, NST, Is>(lds, p, npad, kb_begin, s + Is, ns, col_i, col_j, wave, lane, wm,
-                                                    wn, idle, acc)
+  ((Is < count ? ring_step<NWM, NNI, SKB, NST, Is, IDLE>(lds, p, npad, kb_begin, s + Is, ns, col_i, col_j, wave, lane,
+                                                          wm, wn, acc)
                : (void)0),
    ...);
 }
@@ -411,12 +411,21 @@ __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram
   ring_prologue<NWM, SKB, NST, NWAVES>(lds, p, npad, kb_begin, ns, col_i, col_j, wave, lane,
                                       std::make_integer_sequence<int, NST - 1>{});
   int s = 0;
+  if (idle) {  // wave-uniform: a separate loop with no accumulator traffic at all, then nothing to store
+    for (; s + NST - 1 < ns; s += NST)
+      ring_round<NWM, NNI, SKB, NST, true>(lds, p, npad, kb_begin, s, ns, NST, col_i, col_j, wave, lane, wm, wn, acc,
+                                           std::make_integer_sequence<int, NST>{});
+    if (s < ns)
+      ring_round<NWM, NNI, SKB, NST, true>(lds, p, npad, kb_begin, s, ns, ns - s, col_i, col_j, wave, lane, wm, wn,
+                                           acc, std::make_integer_sequence<int, NST - 1>{});
+    return;
+  }
   for (; s + NST - 1 < ns; s += NST)
-    ring_round<NWM, NNI, SKB, NST>(lds, p, npad, kb_begin, s, ns, NST, col_i, col_j, wave, lane, wm, wn, idle, acc,
-                                   std::make_integer_sequence<int, NST>{});
+    ring_round<NWM, NNI, SKB, NST, false>(lds, p, npad, kb_begin, s, ns, NST, col_i, col_j, wave, lane, wm, wn, acc,
+                                          std::make_integer_sequence<int, NST>{});
   if (s < ns)
-    ring_round<NWM, NNI, SKB, NST>(lds, p, npad, kb_begin, s, ns, ns - s, col_i, col_j, wave, lane, wm, wn, idle, acc,
-                                   std::make_integer_sequence<int, NST - 1>{});
+    ring_round<NWM, NNI, SKB, NST, false>(lds, p, npad, kb_begin, s, ns, ns - s, col_i, col_j, wave, lane, wm, wn,
+                                          acc, std::make_integer_sequence<int, NST - 1>{});
 
   // epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
   // Only the upper triangle (j >= i) is authoritative; pcoa_gram_finalize mirrors it.
