@@ -24,6 +24,18 @@ for s in $STEPS; do
     bench)
       timeout 900 python bench.py --gpus 1 --steps 5 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
       echo "bench exit $?" | tee -a $OUT/summary.txt; cat $OUT/bench.json | tee -a $OUT/summary.txt; tail -5 $OUT/bench.err ;;
+    pmcx)
+      # extra PMC passes: PMC_SETS="A,B,C D,E" -> one rocprofv3 run per space-separated set
+      i=0
+      for set in $PMC_SETS; do
+        i=$((i+1))
+        ( cd /tmp && timeout 600 rocprofv3 --pmc $(echo $set | tr ',' ' ') --output-format csv -d $OLDPWD/$OUT/pmc_x$i -o pmc -- python $OLDPWD/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --pcoa-reps 1 > /dev/null 2> $OLDPWD/$OUT/pmc_x$i.err )
+        echo "pmcx set $i ($set) exit $?" | tee -a $OUT/summary.txt
+      done
+      python tools/pmc_summary.py $OUT | tee -a $OUT/summary.txt
+      cp $OUT/pmc_summary.json $OUT/pmc_summary_full.json; find $OUT -name "*counter_collection*" -size +4M -delete ;;
+    counters)
+      rocprofv3 -L 2>/dev/null | grep -oE "^\s*(Name|name)\s*:\s*\S+|^[A-Za-z_0-9]+\s" | head -400 > $OUT/counters.txt; rocprofv3 -L > $OUT/counters_full.txt 2>&1; wc -l $OUT/counters_full.txt | tee -a $OUT/summary.txt ;;
     benchab)
       # within-run A/B: AB_VAR=<env var> AB_VALUES="a b" (interleaved, two rounds)
       for t in $AB_VALUES $AB_VALUES; do
