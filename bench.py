@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--samples", type=int, default=N_SAMPLES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pcoa-reps", type=int, default=3)
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the reference-only extras (uint8 input, config-0 CSR job, PCIe rates, Householder timing)")
     ap.add_argument("--allreduce", choices=["native", "torch"], default="native",
                     help="N>1: native = RCCL communicator inside libpcoa_hip (in-place int32), torch = "
                          "export -> torch.distributed.all_reduce -> import")
@@ -223,13 +225,13 @@ def main():
         pcoa_hh = []
         with P.PcoaEngine(n, device=local_rank, eig="householder") as eng_hh:
             eng_hh.load_gram(eng.gram())
-            for _ in range(2):
+            for _ in range(0 if args.no_extras else 2):
                 t1 = time.perf_counter()
                 comps_hh, lam_hh, _ = eng_hh.compute(2)
                 pcoa_hh.append(1e3 * (time.perf_counter() - t1))
             tim_hh = eng_hh.timings()
-        agree = float(max(np.linalg.norm(comps[:, c] - comps_hh[:, c] * np.sign(np.dot(comps[:, c], comps_hh[:, c])))
-                          for c in range(2)))
+        agree = None if args.no_extras else float(max(
+            np.linalg.norm(comps[:, c] - comps_hh[:, c] * np.sign(np.dot(comps[:, c], comps_hh[:, c]))) for c in range(2)))
         out = {
             "metric": METRIC, "value": value, "unit": "variants/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
@@ -249,7 +251,7 @@ def main():
                                    "backtransform_seconds")},
             "pcoa_method": {1: "lanczos (verified residual)", 2: "householder"}.get(tim2["eig_method"], "?"),
             "lanczos_steps": tim2["lanczos_steps"],
-            "pcoa_wall_ms_householder": float(min(pcoa_hh)),
+            "pcoa_wall_ms_householder": float(min(pcoa_hh)) if pcoa_hh else None,
             "pcoa_householder_breakdown_ms": {k: 1e3 * tim_hh[k] / 2 for k in
                                               ("center_seconds", "tridiag_seconds", "eig_seconds",
                                                "backtransform_seconds")},
@@ -257,7 +259,7 @@ def main():
             "eigenvalues": [float(t) for t in lam], "nonzero_rows": int(nz),
             "device": dev_name, "cu_count": cus,
         }
-        if world == 1:
+        if world == 1 and not args.no_extras:
             # the production input format (one byte per genotype): same contraction, 4x cheaper pre-pass
             x8 = x.to(torch.uint8)
             torch.cuda.synchronize(dev)
@@ -277,7 +279,7 @@ def main():
                                    "note": "same cohort handed over as uint8 [V][N] (pcoa_accumulate_dense_u8); "
                                            "not the BASELINE configs[1] fp32 boundary, reported for reference"}
             del x8
-        if world == 1:
+        if world == 1 and not args.no_extras:
             # BASELINE configs[0] stand-in: BRCA1-sized region (2,500 variants) through the faithful CSR boundary
             # (pcoa_accumulate_calls, host arrays), end to end: H2D + densify + Gram + finalize + PCoA + D2H
             v1 = 2500
@@ -302,7 +304,7 @@ def main():
                 "wall_ms": float(min(walls[1:])), "wall_ms_all": walls,
                 "eig_method": {1: "lanczos", 2: "householder"}.get(tt1["eig_method"], "?"),
                 "eigenvalues": [float(t) for t in l1]}
-        if world == 1:
+        if world == 1 and not args.no_extras:
             # PCIe-inclusive rates (host tiles through the staging path): noted, never `value`
             hv = min(v, 131072)
             xh = x[:hv].cpu().numpy()

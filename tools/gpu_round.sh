@@ -29,7 +29,7 @@ for s in $STEPS; do
       i=0
       for set in $PMC_SETS; do
         i=$((i+1))
-        ( cd /tmp && timeout 600 rocprofv3 --pmc $(echo $set | tr ',' ' ') --output-format csv -d $OLDPWD/$OUT/pmc_x$i -o pmc -- python $OLDPWD/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --pcoa-reps 1 > /dev/null 2> $OLDPWD/$OUT/pmc_x$i.err )
+        ( cd /tmp && timeout 600 rocprofv3 --pmc $(echo $set | tr ',' ' ') --output-format csv -d $OLDPWD/$OUT/pmc_x$i -o pmc -- python $OLDPWD/bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --pcoa-reps 1 > /dev/null 2> $OLDPWD/$OUT/pmc_x$i.err )
         echo "pmcx set $i ($set) exit $?" | tee -a $OUT/summary.txt
       done
       python tools/pmc_summary.py $OUT | tee -a $OUT/summary.txt
@@ -57,11 +57,11 @@ for s in $STEPS; do
       # keep the merge-back small: drop the raw per-dispatch trace if it is large
       find $OUT/prof -name "*kernel_trace*" -size +8M -delete ;;
     pmc)
-      ( cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OLDPWD/$OUT/pmc_fetch -o pmc -- python $OLDPWD/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --pcoa-reps 1 > /dev/null 2> $OLDPWD/$OUT/pmc_fetch.err )
+      ( cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OLDPWD/$OUT/pmc_fetch -o pmc -- python $OLDPWD/bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --pcoa-reps 1 > /dev/null 2> $OLDPWD/$OUT/pmc_fetch.err )
       echo "pmc fetch exit $?" | tee -a $OUT/summary.txt
-      ( cd /tmp && timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OLDPWD/$OUT/pmc_write -o pmc -- python $OLDPWD/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --pcoa-reps 1 > /dev/null 2> $OLDPWD/$OUT/pmc_write.err )
+      ( cd /tmp && timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OLDPWD/$OUT/pmc_write -o pmc -- python $OLDPWD/bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --pcoa-reps 1 > /dev/null 2> $OLDPWD/$OUT/pmc_write.err )
       echo "pmc write exit $?" | tee -a $OUT/summary.txt
-      ( cd /tmp && timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $OLDPWD/$OUT/pmc_sq -o pmc -- python $OLDPWD/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --pcoa-reps 1 > /dev/null 2> $OLDPWD/$OUT/pmc_sq.err )
+      ( cd /tmp && timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $OLDPWD/$OUT/pmc_sq -o pmc -- python $OLDPWD/bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --pcoa-reps 1 > /dev/null 2> $OLDPWD/$OUT/pmc_sq.err )
       echo "pmc sq exit $?" | tee -a $OUT/summary.txt
       python tools/pmc_summary.py $OUT | tee -a $OUT/summary.txt
       cp $OUT/pmc_summary.json $OUT/pmc_summary_full.json; find $OUT -name "*counter_collection*" -size +4M -delete ;;
