@@ -517,6 +517,10 @@ hipError_t launch_gram_i8_packed(const int8_t* p, int64_t nv, int32_t n, int32_t
   // one 512-thread workgroup per CU is resident; aim at ~7 work units per CU, >= 1024 variants each
   const int64_t target = (int64_t)(num_cu > 0 ? num_cu : 256) * 7;
   int64_t splitk = (target + ntri - 1) / ntri;
+  if (const char* sk = std::getenv("PCOA_GRAM_I8_SPLITK")) {  // experiment hook
+    const long long t = std::atoll(sk);
+    if (t > 0) splitk = t;
+  }
   const int64_t max_by_work = nstages * skb / 64;
   if (splitk > max_by_work) splitk = max_by_work;
   if (splitk < 1) splitk = 1;
