@@ -5,9 +5,12 @@ Workload (config.workload): BASELINE configs[1] per GPU -- synthetic 2,504 sampl
 fp32 (10.0 GB), resident in HBM before the timed region (weak scaling: every rank holds its own 1M-variant
 shard of one 1M*N_gpus-variant cohort; the generator is counter-based, so the cohort does not depend on N).
 
-One step = one pass of the hot path over the resident batch:
-    reset S -> Gram accumulation (fp32 MFMA, exact) -> finalize (mirror) -> [N>1: RCCL all-reduce of S].
-value = variants of ALL ranks per step * steps / max-over-ranks wall time of the K timed steps.
+One step = one pass of the hot path over the resident batch: the Gram accumulation of 10^6 variants per GPU
+(pre-pass + i8-MFMA contraction, exact).  The job = K steps, then ONE finalize (mirror) and, for N > 1, ONE RCCL
+all-reduce of S -- the reference reduces once per job too (reduceByKey after all partitions, VariantsPca.scala:190),
+and with --steps 5 this is exactly BASELINE configs[2]'s shape (5M variants per GPU, 40M at 8 GPUs).  The
+finalize/all-reduce is INSIDE the timed region.
+value = variants of ALL ranks over the K steps / max-over-ranks wall time of the timed region.
 The PCoA wall-clock (centring + eigensolve + D2H of N x 2, rank 0) is reported in `pcoa_wall_ms`.
 
 Contract: one JSON line on stdout from rank 0.  Launched by the driver as
@@ -138,9 +141,10 @@ def main():
                 allreduce_mode = "torch"
 
     def one_step():
-        nonlocal scratch
-        eng.reset()
         eng.accumulate_dense(x)
+
+    def finish_job():
+        nonlocal scratch
         if world > 1:
             if native is not None:
                 native.allreduce()
@@ -155,13 +159,18 @@ def main():
         if world > 1:
             td.barrier()
 
+    eng.reset()
     for _ in range(args.warmup):
         one_step()
+    finish_job()  # also warms the collective
     fence()
+    eng.reset()
     eng.reset_timings()
+    fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
+    finish_job()
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -263,14 +272,15 @@ def main():
             # the production input format (one byte per genotype): same contraction, 4x cheaper pre-pass
             x8 = x.to(torch.uint8)
             torch.cuda.synchronize(dev)
+            eng.reset()
             for _ in range(2):
-                eng.reset(); eng.accumulate_dense_u8(x8); eng.finalize()
-            eng.sync()
-            eng.reset_timings()
+                eng.accumulate_dense_u8(x8)
+            eng.finalize(); eng.sync()
+            eng.reset(); eng.reset_timings(); eng.sync()
             t1 = time.perf_counter()
             for _ in range(steps):
-                eng.reset(); eng.accumulate_dense_u8(x8); eng.finalize()
-            eng.sync()
+                eng.accumulate_dense_u8(x8)
+            eng.finalize(); eng.sync()
             dt8 = time.perf_counter() - t1
             t8 = eng.timings()
             out["alt_input_u8"] = {"value": v * steps / dt8, "unit": "variants/s", "ms_per_step": 1e3 * dt8 / steps,

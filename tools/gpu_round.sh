@@ -24,6 +24,13 @@ for s in $STEPS; do
     bench)
       timeout 900 python bench.py --gpus 1 --steps 5 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
       echo "bench exit $?" | tee -a $OUT/summary.txt; cat $OUT/bench.json | tee -a $OUT/summary.txt; tail -5 $OUT/bench.err ;;
+    pmcf32)
+      for c in FETCH_SIZE WRITE_SIZE; do
+        ( cd /tmp && timeout 900 rocprofv3 --pmc $c --output-format csv -d $OLDPWD/$OUT/pmc_f32_$c -o pmc -- python $OLDPWD/bench.py --gpus 1 --steps 2 --warmup 1 --gram-kernel f32 --no-cpu-baseline --no-extras --pcoa-reps 1 > /dev/null 2> $OLDPWD/$OUT/pmc_f32_$c.err )
+        echo "pmc f32 $c exit $?" | tee -a $OUT/summary.txt
+      done
+      python tools/pmc_summary.py $OUT | tee -a $OUT/summary.txt
+      cp $OUT/pmc_summary.json $OUT/pmc_summary_f32.json; find $OUT -name "*counter_collection*" -size +4M -delete ;;
     pmcx)
       # extra PMC passes: PMC_SETS="A,B,C D,E" -> one rocprofv3 run per space-separated set
       i=0
