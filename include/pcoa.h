@@ -42,8 +42,8 @@ typedef enum pcoa_status {
   PCOA_ERR_INDEX_RANGE = -5,   /* a callset index outside [0, N): the reference throws here
                                   (mapping(call.callsetId), VariantsPca.scala:59; Breeze bounds check :188) */
   PCOA_ERR_RCCL = -6,
-  PCOA_ERR_NOT_CONVERGED = -7, /* eigen-iteration failed to converge */
-  PCOA_ERR_STATE = -8          /* call order violated (e.g. compute before any finalize)         */
+  PCOA_ERR_NOT_CONVERGED = -7, /* no verified eigenpair (Lanczos-only mode, or N too large for the dense fallback) */
+  PCOA_ERR_STATE = -8          /* reserved                                                        */
 } pcoa_status;
 
 /* flags for pcoa_create */
@@ -82,7 +82,7 @@ typedef struct pcoa_timings {
 
 /* Synthetic genotype model (bench / tests only; not part of the reference).  Sample i belongs to
  * population p iff pop_offsets[p] <= i < pop_offsets[p+1].  Genotype X[v,i] = 1 iff
- * philox4x32-10(key = seed, counter = (v, i/4, 0, 0))[i%4] < thresholds[v*n_pops + p].
+ * philox4x32-10(key = (seed_lo, seed_hi), counter = (v_lo, v_hi, i/4, 0))[i%4] < thresholds[v*n_pops + p].
  * Pure integer arithmetic => bit-identical on host and device and invariant to sharding. */
 typedef struct pcoa_synth_params {
   uint64_t seed;

@@ -45,7 +45,6 @@ struct pcoa_ctx {
   int64_t* s64 = nullptr;          // [n][n] folded total (lazy), always symmetric
   int64_t variants_in_s32 = 0;     // variants accumulated into s32 since the last fold
   bool dirty = false;              // s32 has contributions not yet mirrored
-  bool have_data = false;
   float* zeros = nullptr;          // 4 KiB of zeros
   int32_t* err_flag = nullptr;     // device
 
@@ -234,7 +233,6 @@ void account_gram(pcoa_ctx* c, int64_t cur) {
   c->gram_bytes += 4.0 * (double)cur * (double)c->n + 4.0 * (double)c->n * (double)c->n;
   c->variants_in_s32 += cur;
   c->dirty = true;
-  c->have_data = true;
 }
 
 int fold_if_needed(pcoa_ctx* c, int64_t cur) {
@@ -348,7 +346,6 @@ int ensure_workspace(pcoa_ctx* c, int32_t k) {
     HIP_TRY(c, hipMalloc((void**)&c->ws.w, sizeof(double) * (size_t)(2 * n)));
     HIP_TRY(c, hipMalloc((void**)&c->ws.scratch, sizeof(double) * (size_t)(6 * n)));
     HIP_TRY(c, hipMalloc((void**)&c->ws.iscratch, sizeof(int32_t) * (size_t)(2 * n + 64)));
-    HIP_TRY(c, hipMalloc((void**)&c->ws.status, sizeof(int32_t) * 4));
     HIP_TRY(c, hipMalloc((void**)&c->row_sums, sizeof(double) * (size_t)n));
     HIP_TRY(c, hipMalloc((void**)&c->stats, sizeof(double) * (size_t)(2 + n)));
     HIP_TRY(c, hipMalloc((void**)&c->nz, sizeof(int32_t) * 4));
@@ -478,7 +475,7 @@ void pcoa_destroy(pcoa_ctx* c) {
   for (auto& ev : c->pool) (void)hipEventDestroy(ev);
   void* bufs[] = {c->s32, c->s64, c->zeros, c->err_flag, c->tile, c->csr_idx, c->csr_offs, c->thr_dev,
                   c->sample_pop, c->xfer, c->coll, c->pack_buf, c->lanczos_ws, c->ws.a, c->ws.d, c->ws.e, c->ws.tau, c->ws.q, c->ws.w, c->ws.lam,
-                  c->ws.z, c->ws.scratch, c->ws.iscratch, c->ws.status, c->row_sums, c->stats, c->nz,
+                  c->ws.z, c->ws.scratch, c->ws.iscratch, c->row_sums, c->stats, c->nz,
                   c->out_dev};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -512,7 +509,6 @@ int pcoa_reset(pcoa_ctx* c) {
   HIP_TRY(c, hipMemsetAsync(c->err_flag, 0, 16, c->stream));
   c->variants_in_s32 = 0;
   c->dirty = false;
-  c->have_data = false;
   return PCOA_OK;
 }
 
@@ -704,7 +700,6 @@ int pcoa_gram_import_device_i64(pcoa_ctx* c, const int64_t* src_dev) {
   HIP_TRY(c, hipMemsetAsync(c->s32, 0, sizeof(int32_t) * nn, c->stream));
   c->variants_in_s32 = 0;
   c->dirty = false;
-  c->have_data = true;
   return PCOA_OK;
 }
 
@@ -807,8 +802,7 @@ int pcoa_gram_allreduce_rccl(pcoa_ctx* c, void* nccl_comm) {
     r = ncclAllReduce(c->s32, c->s32, nn, ncclInt32, ncclSum, comm, c->stream);
     if (r != ncclSuccess) return fail(c, PCOA_ERR_RCCL, std::string("ncclAllReduce(int32): ") + ncclGetErrorString(r));
     c->variants_in_s32 = all[0];
-    c->have_data = true;
-    return PCOA_OK;
+      return PCOA_OK;
   }
   if (!c->xfer) HIP_TRY(c, hipMalloc((void**)&c->xfer, sizeof(int64_t) * nn));
   rc = pcoa_gram_export_device_i64(c, c->xfer);

@@ -67,12 +67,11 @@ struct EigWorkspace {
   double* e;        // [n]   off-diagonal of T (n-1 used)
   double* tau;      // [n]   reflector scalars (n-2 used)
   double* q;        // [n]   A22 * v  (raw matvec of the current step)
-  double* w;        // [2][n] rank-2 update vectors, ping-pong
+  double* w;        // [n]   rank-2 update vector of the previous step
   double* lam;      // [2*kmax] candidate eigenvalues (k largest then k smallest)
   double* z;        // [kmax][n] eigenvectors of T, then of A (column c at z + c*n)
   double* scratch;  // [6][n] LU factors for inverse iteration
-  int32_t* iscratch;// [n]
-  int32_t* status;  // [4] device status words (0 = ok)
+  int32_t* iscratch;// [2n + 64] pivots / eigenvalue indices
 };
 hipError_t launch_tridiagonalize(const EigWorkspace& ws, int32_t n, hipStream_t stream);
 // eigenvalues with ascending indices idx[0..count) of T -> lam_out[0..count) (device)
