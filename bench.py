@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 METRIC = "variants/sec into N×N Gram + PCoA wall-clock, 2504 samples, 1/2/4/8 GPU"
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 flop/clk/CU
 PEAK_I8_MFMA_TOPS = 5000.0      # MI355X_MICROARCH.md: i8 MFMA ~2x the bf16 rate (~2.5 PF dense) => ~5 POP/s dense
+PEAK_FP4_MFMA_TFLOPS = 10000.0  # MI355X_MICROARCH.md: MX-FP4 dense ~2x the fp8 rate (~5 PF dense) => ~10 PF dense
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 N_SAMPLES = 2504
 SEED = 1002                     # seed of configs[1]
@@ -83,8 +84,9 @@ def main():
     ap.add_argument("--allreduce", choices=["native", "torch"], default="native",
                     help="N>1: native = RCCL communicator inside libpcoa_hip (in-place int32), torch = "
                          "export -> torch.distributed.all_reduce -> import")
-    ap.add_argument("--gram-kernel", choices=["i8", "f32"], default="i8",
-                    help="i8: pack fp32->int8 + v_mfma_i32_32x32x32_i8 (default); f32: v_mfma_f32_32x32x2_f32")
+    ap.add_argument("--gram-kernel", choices=["auto", "fp4", "i8", "f32"], default="auto",
+                    help="auto (default): binary tiles -> pack to MX-FP4 + v_mfma_scale_f32_32x32x64_f8f6f4, tiles with "
+                         "multiplicities -> int8; fp4 / i8: force one; f32: v_mfma_f32_32x32x2_f32")
     args = ap.parse_args()
 
     import torch
@@ -192,11 +194,17 @@ def main():
         pmc_path = os.path.join(ROOT, "profiles", "gram_pmc_latest.json")
         if os.path.exists(pmc_path):
             try:
-                pmc = json.load(open(pmc_path)).get(args.gram_kernel, {})
+                pmc = json.load(open(pmc_path)).get({1: "f32", 2: "i8", 3: "fp4"}[tim["gram_kernel_kind"]], {})
             except Exception:
                 pmc = {}
-        if args.gram_kernel == "i8":
-            tile, peak, kname = 256, PEAK_I8_MFMA_TOPS, "gram_i8_kernel"
+        kind = tim["gram_kernel_kind"]          # what actually ran: 1 fp32, 2 int8, 3 MX-FP4
+        if kind == 3:
+            tile, peak, kname = 256, PEAK_FP4_MFMA_TFLOPS, "gram_packed_kernel<fp4>"
+            kdesc = ("pack fp32->k-blocked FP4 E2M1 (HBM-bound, verifies values are 0/1) + MX-FP4 MFMA "
+                     "v_mfma_scale_f32_32x32x64_f8f6f4 (unit scales, exact), upper-triangular 256x256 tiles, split-K, "
+                     "fp32 accumulators (< 2^24 per launch) -> int32 atomics")
+        elif kind == 2:
+            tile, peak, kname = 256, PEAK_I8_MFMA_TOPS, "gram_packed_kernel<i8>"
             kdesc = "pack fp32->k-blocked int8 (HBM-bound) + i8 MFMA v_mfma_i32_32x32x32_i8, upper-triangular 256x256 tiles, split-K, int32 accumulators"
         else:
             tile, peak, kname = 128, PEAK_FP32_MFMA_TFLOPS, "gram_f32_kernel"
@@ -210,14 +218,16 @@ def main():
                                          % frac_syrk,
                      "issued_tflops": achieved * frac_syrk, "issued_frac": achieved * frac_syrk / peak}
         roof_pack = None
-        if args.gram_kernel == "i8" and tim["pack_launches"] > 0:
+        if kind != 1 and tim["pack_launches"] > 0:
             pl = int(tim["pack_launches"])
             pack_s = tim["pack_seconds"] / pl
             pack_gbs = tim["pack_bytes"] / pl / pack_s / 1e9 if pack_s > 0 else 0.0
             roof_pack = {"bound": "hbm", "achieved": pack_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": pack_gbs / PEAK_HBM_GBS, "traffic": pmc.get("pack_hbm_bytes_per_launch"),
-                         "kernel": "pack_f32_i8_kernel", "avg_launch_ms": 1e3 * pack_s, "launches": pl,
-                         "bytes_convention": "algorithmic 4*V*N read + V*Npad written per launch"}
+                         "kernel": "pack_fp4_kernel" if kind == 3 else "pack_f32_i8_kernel",
+                         "avg_launch_ms": 1e3 * pack_s, "launches": pl,
+                         "bytes_convention": "algorithmic 4*V*N read + V*Npad%s written per launch"
+                                             % ("/2" if kind == 3 else "")}
         # the dominant kernel (larger share of the step) goes into `roofline`, the other into `roofline_other`
         if roof_pack is not None and tim["pack_seconds"] > tim["gram_kernel_seconds"]:
             roofline, roofline_other = roof_pack, roof_gram
@@ -244,12 +254,13 @@ def main():
         out = {
             "metric": METRIC, "value": value, "unit": "variants/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "i8->i32" if args.gram_kernel == "i8" else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": {1: "f32", 2: "i8->i32", 3: "fp4(e2m1)->f32->i32"}[kind], "data": "synthetic",
             "config": {"workload": "configs[1]: synthetic %d samples x %d variants fp32 per GPU, resident in HBM "
                                    "(Gram + eig on rank 0)" % (n, v),
                        "n_samples": n, "variants_per_gpu": v, "seed": SEED, "parallelism": "variant-sharded x%d" % world,
                        "allreduce": allreduce_mode,
-                       "gram_kernel": kdesc},
+                       "gram_kernel": kdesc, "gram_kernel_mode": args.gram_kernel,
+                       "fp4_fallback_chunks": int(tim["fp4_fallbacks"])},
             "roofline": roofline, "roofline_other": roofline_other,
             "gram_ms_per_step": 1e3 * tim["gram_kernel_seconds"] / steps,
             "pack_ms_per_step": 1e3 * tim["pack_seconds"] / steps,

@@ -47,9 +47,12 @@ typedef enum pcoa_status {
 } pcoa_status;
 
 /* flags for pcoa_create */
-#define PCOA_FLAG_DEFAULT        0u     /* i8-MFMA Gram: tile values must be integers in [0, 127]         */
+#define PCOA_FLAG_DEFAULT        0u     /* auto: MX-FP4 MFMA for binary (0/1) tiles, int8 MFMA for tiles that
+                                           hold carrier multiplicities 2..127 (decided per chunk, both exact)  */
 #define PCOA_FLAG_GRAM_F32_MFMA  0x1u  /* fp32-MFMA Gram kernel (v_mfma_f32_32x32x2_f32): any small ints */
-#define PCOA_FLAG_GRAM_I8_MFMA   0x2u  /* i8-MFMA Gram kernel (v_mfma_i32_32x32x32_i8), the default      */
+#define PCOA_FLAG_GRAM_I8_MFMA   0x2u  /* int8-MFMA Gram kernel only (v_mfma_i32_32x32x32_i8), values 0..127 */
+#define PCOA_FLAG_GRAM_FP4_MFMA  0x4u  /* MX-FP4 Gram kernel only (v_mfma_scale_f32_32x32x64_f8f6f4): a value
+                                           other than 0 / 1 is an error                                        */
 #define PCOA_FLAG_NO_SIGN_NORM   0x10u /* keep the eigensolver's native sign instead of sign-normalising */
 #define PCOA_FLAG_EIG_HOUSEHOLDER 0x20u /* always use the dense Householder + bisection eigensolver        */
 #define PCOA_FLAG_EIG_LANCZOS    0x40u /* Lanczos only: PCOA_ERR_NOT_CONVERGED instead of falling back      */
@@ -70,7 +73,7 @@ typedef struct pcoa_timings {
   double eig_seconds;           /* tridiagonal eigenvalues + inverse iteration                        */
   double backtransform_seconds; /* reflector back-transform + normalisation                           */
   double compute_total_seconds; /* wall of the last pcoa_compute (centring..D2H)                      */
-  int32_t gram_kernel_kind;     /* 1 = fp32 MFMA, 2 = i8 MFMA                                        */
+  int32_t gram_kernel_kind;     /* of the last launch: 1 = fp32 MFMA, 2 = int8 MFMA, 3 = MX-FP4 MFMA */
   int32_t reserved;
   double pack_seconds;          /* fp32 -> k-blocked int8 pre-pass of the i8 path (sum of launches)   */
   int64_t pack_launches;
@@ -78,6 +81,7 @@ typedef struct pcoa_timings {
   double lanczos_seconds;       /* Lanczos fast path of the eigensolver (sum over computes)           */
   int32_t eig_method;           /* of the last pcoa_compute: 1 = Lanczos (verified), 2 = Householder  */
   int32_t lanczos_steps;        /* Krylov dimension reached by the last pcoa_compute                  */
+  int64_t fp4_fallbacks;        /* chunks the auto mode re-ran on the int8 kernel (non-binary values) */
 } pcoa_timings;
 
 /* Synthetic genotype model (bench / tests only; not part of the reference).  Sample i belongs to

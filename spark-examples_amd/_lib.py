@@ -22,6 +22,7 @@ PCOA_ERR_STATE = -8
 PCOA_FLAG_DEFAULT = 0
 PCOA_FLAG_GRAM_F32_MFMA = 0x1
 PCOA_FLAG_GRAM_I8_MFMA = 0x2
+PCOA_FLAG_GRAM_FP4_MFMA = 0x4
 PCOA_FLAG_NO_SIGN_NORM = 0x10
 PCOA_FLAG_EIG_HOUSEHOLDER = 0x20
 PCOA_FLAG_EIG_LANCZOS = 0x40
@@ -50,6 +51,7 @@ class PcoaTimings(ctypes.Structure):
         ("lanczos_seconds", ctypes.c_double),
         ("eig_method", ctypes.c_int32),
         ("lanczos_steps", ctypes.c_int32),
+        ("fp4_fallbacks", ctypes.c_int64),
     ]
 
 

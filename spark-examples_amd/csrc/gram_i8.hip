@@ -23,6 +23,13 @@
 //      half-wave: conflict-free.  MFMA-bound: per stage a wave issues 16 MFMAs (512 cycles) against
 //      12 ds_read_b128 and 4 DMA instructions.
 //
+// FP4 variant (FMT = 1): binary genotypes are exactly representable in MX-FP4 (E2M1: 0 -> 0x0, 1.0 -> 0x2), and
+// v_mfma_scale_f32_32x32x64_f8f6f4 (block scales fixed at 2^0) runs at twice the i8 rate on HALF the operand
+// bytes: a k-block is then 32 variants (still 16 B per lane), products are 0/1 and the fp32 accumulators are
+// exact below 2^24 (a launch never exceeds that).  The contraction kernel is the same template; only the
+// MFMA instruction, the accumulator type and the pre-pass differ.  Tiles that hold anything but 0/1 are
+// re-run through the int8 path by the host (pcoa_capi.hip).
+//
 // Roofline: i8 MFMA, peak ~5 POP/s dense (2x the bf16 rate, MI355X_MICROARCH.md); algorithmic
 // intensity of the packed operands N/0.5 = 5008 op/B, so HBM is irrelevant once packed.
 #include <cstdlib>
@@ -181,6 +188,75 @@ __global__ __launch_bounds__(256) void densify_csr_i8_kernel(const int32_t* __re
   }
 }
 
+// ---- FP4 pre-pass: X (fp32 or uint8, values exactly 0 / 1) -> P4 [V/32][Npad][16 B], 32 nibbles per lane slice.
+// One thread: 32 variants x 4 samples, in two halves of 16 variants (8 bytes of each sample's slice per half).
+// flag bit 3 (value 8) is raised for a value that is not exactly 0 or 1.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void pack_fp4_kernel(const T* __restrict__ x, int64_t ld, int64_t nv, int n, int npad,
+                                                       int64_t nkb_pad, int8_t* __restrict__ p,
+                                                       int32_t* __restrict__ flag) {
+  const int groups = npad >> 2;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t kb = gid / groups;
+  const int g = (int)(gid - kb * groups);
+  if (kb >= nkb_pad) return;
+  const int i0 = g * 4;
+  bool bad = false;
+  uint32_t w[4][4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[s][q] = 0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    uint32_t one[16];  // bit s of one[t] = sample i0+s carries at variant 32*kb + 16*h + t
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int64_t row = kb * 32 + h * 16 + t;
+      uint32_t bits = 0;
+      if (row < nv) {
+        const T* src = x + row * ld + i0;
+        T v[4];
+        if (VEC == 4 && i0 + 3 < ld) {
+          if constexpr (sizeof(T) == 4) {
+            const float4 f = *reinterpret_cast<const float4*>(src);
+            v[0] = (T)f.x; v[1] = (T)f.y; v[2] = (T)f.z; v[3] = (T)f.w;
+          } else {
+            const uint32_t u = *reinterpret_cast<const uint32_t*>(src);
+            v[0] = (T)(u & 0xff); v[1] = (T)((u >> 8) & 0xff); v[2] = (T)((u >> 16) & 0xff); v[3] = (T)(u >> 24);
+          }
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) v[s] = (i0 + s < ld) ? src[s] : (T)0;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          if (i0 + s < n) {  // padding columns [n, ld) may hold anything: ignored
+            const bool is1 = (v[s] == (T)1);
+            bad |= !(is1 || v[s] == (T)0);
+            bits |= (is1 ? 1u : 0u) << s;
+          }
+        }
+      }
+      one[t] = bits;
+    }
+    // nibble of variant t = 0x2 (E2M1 1.0) or 0x0; 8 variants per 32-bit word
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) word |= (((one[q * 8 + b] >> s) & 1u) << 1) << (4 * b);
+        w[s][h * 2 + q] = word;
+      }
+  }
+  uint4* dst = reinterpret_cast<uint4*>(p + ((size_t)kb * npad + i0) * 16);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) dst[s] = make_uint4(w[s][0], w[s][1], w[s][2], w[s][3]);
+  if (bad) atomicOr(flag, 8);
+}
+
 // ---------------------------------------------------------------------------------------------- gemm
 // Template parameters
 //   NWM  waves along M (tile height 128*NWM); NNI 32-column MFMA tiles per wave along N (wave tile
@@ -239,23 +315,45 @@ __device__ __forceinline__ void load_frags_i8(const StageI8<NWM, SKB>* st, int k
     f.b[ni] = *reinterpret_cast<const i32x4*>(&st->pj[2 * k2 + hi][wn * 32 * NNI + ni * 32 + l31][0]);
 }
 
-template <int NNI>
-__device__ __forceinline__ void mfma_step_i8(const FragsI8<NNI>& f, i32x16 (&acc)[4][NNI]) {
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+// FMT 0: int8 operands, int32 accumulators.  FMT 1: MX-FP4 operands (scales 2^0), fp32 accumulators.
+template <int FMT>
+struct AccType { typedef i32x16 type; };
+template <>
+struct AccType<1> { typedef f32x16 type; };
+
+template <int FMT, int NNI>
+__device__ __forceinline__ void mfma_step_i8(const FragsI8<NNI>& f, typename AccType<FMT>::type (&acc)[4][NNI]) {
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < NNI; ++ni)
-      acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[mi], f.b[ni], acc[mi][ni], 0, 0, 0);
+    for (int ni = 0; ni < NNI; ++ni) {
+      if constexpr (FMT == 0) {
+        acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[mi], f.b[ni], acc[mi][ni], 0, 0, 0);
+      } else {
+        // 32 FP4 values per lane = 4 VGPRs; cbsz = blgp = 4 selects E2M1; E8M0 scale byte 127 = 2^0 for both
+        // operands.  Written as inline asm because the builtin takes 8-VGPR operand tuples (the FP4 form
+        // reads the low 4): materialising them doubles the fragment registers and the kernel spills.
+        // Hazards (cdna_hip_programming.md 5.7): operands come from ds_read (the compiler waits lgkmcnt before
+        // the statement since it names them as inputs); D feeds only the next MFMA as its whole C (no wait
+        // states needed); the epilogue's first VALU read of D is fenced by s_nops after the main loop.
+        asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] cbsz:4 blgp:4"
+                     : "+v"(acc[mi][ni])
+                     : "v"(f.a[mi]), "v"(f.b[ni]), "v"(0x7f7f7f7f));
+      }
+    }
 }
 
 // One stage of the ring.  Prefetch distance D = NST - 1: when stage s is consumed, stages s+1 .. s+D-1
 // may still be in flight (counted vmcnt), and stage s+D is issued into the buffer stage s-1 used.
 // Inside the stage the fragment reads are software-pipelined one k32-step ahead of the MFMAs
 // (two register sets of 24 VGPRs), so the stage depth SKB does not cost registers.
-template <int NWM, int NNI, int SKB, int NST, int BUF, bool IDLE>
+template <int FMT, int NWM, int NNI, int SKB, int NST, int BUF, bool IDLE>
 __device__ __forceinline__ void ring_step(StageI8<NWM, SKB>* lds, const int8_t* __restrict__ p, int npad,
                                           int64_t kb_begin, int s, int ns, int col_i, int col_j, int wave, int lane,
-                                          int wm, int wn, i32x16 (&acc)[4][NNI]) {
+                                          int wm, int wn, typename AccType<FMT>::type (&acc)[4][NNI]) {
   constexpr int NWAVES = NWM * (8 / NNI);
   constexpr int PER_WAVE = SKB * (2 * NWM + 4) / NWAVES;
   constexpr int D = NST - 1;
@@ -288,9 +386,9 @@ __device__ __forceinline__ void ring_step(StageI8<NWM, SKB>* lds, const int8_t* 
 #pragma unroll
   for (int k2 = 0; k2 < SKB / 2; k2 += 2) {
     if (k2 + 1 < SKB / 2) load_frags_i8<NWM, NNI, SKB>(&lds[BUF], k2 + 1, wm, wn, lane, f1);
-    mfma_step_i8<NNI>(f0, acc);
+    mfma_step_i8<FMT, NNI>(f0, acc);
     if (k2 + 2 < SKB / 2) load_frags_i8<NWM, NNI, SKB>(&lds[BUF], k2 + 2, wm, wn, lane, f0);
-    if (k2 + 1 < SKB / 2) mfma_step_i8<NNI>(f1, acc);
+    if (k2 + 1 < SKB / 2) mfma_step_i8<FMT, NNI>(f1, acc);
   }
 }
 
@@ -305,12 +403,13 @@ __device__ __forceinline__ void ring_prologue(StageI8<NWM, SKB>* lds, const int8
 }
 
 // `count` consecutive stages starting at s (s is a multiple of NST, so stage s+i lives in buffer i)
-template <int NWM, int NNI, int SKB, int NST, bool IDLE, int... Is>
+template <int FMT, int NWM, int NNI, int SKB, int NST, bool IDLE, int... Is>
 __device__ __forceinline__ void ring_round(StageI8<NWM, SKB>* lds, const int8_t* __restrict__ p, int npad,
                                            int64_t kb_begin, int s, int ns, int count, int col_i, int col_j,
-                                           int wave, int lane, int wm, int wn, i32x16 (&acc)[4][NNI],
+                                           int wave, int lane, int wm, int wn,
+                                           typename AccType<FMT>::type (&acc)[4][NNI],
                                            std::integer_sequence<int, Is...>) {
-  ((Is < count ? ring_step<NWM, NNI, SKB, NST, Is, IDLE>(lds, p, npad, kb_begin, s + Is, ns, col_i, col_j, wave, lane,
+  ((Is < count ? ring_step<FMT, NWM, NNI, SKB, NST, Is, IDLE>(lds, p, npad, kb_begin, s + Is, ns, col_i, col_j, wave, lane,
                                                           wm, wn, acc)
                : (void)0),
    ...);
@@ -373,7 +472,7 @@ __device__ __forceinline__ void tile_coords(int tile, int ntile, int& row_blk, i
   }
 }
 
-template <int NWM, int NNI, int SKB, int NST>
+template <int FMT, int NWM, int NNI, int SKB, int NST>
 __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram_i8_kernel(
     const int8_t* __restrict__ p, int npad, int64_t nstages, int n, int ntile, int ntri, int splitk,
     int64_t stages_per, int32_t* __restrict__ s32, int xcd_map) {
@@ -408,7 +507,7 @@ __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram
   // upper triangle; it skips its MFMAs (2 of 8 waves in 10 of 55 tiles at N = 2504).
   const bool idle = (col_i + wm * 128) > (col_j + wn * 32 * NNI + 32 * NNI - 1);
 
-  i32x16 acc[4][NNI];
+  typename AccType<FMT>::type acc[4][NNI];
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -422,20 +521,21 @@ __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram
   int s = 0;
   if (idle) {  // wave-uniform: a separate loop with no accumulator traffic at all, then nothing to store
     for (; s + NST - 1 < ns; s += NST)
-      ring_round<NWM, NNI, SKB, NST, true>(lds, p, npad, kb_begin, s, ns, NST, col_i, col_j, wave, lane, wm, wn, acc,
+      ring_round<FMT, NWM, NNI, SKB, NST, true>(lds, p, npad, kb_begin, s, ns, NST, col_i, col_j, wave, lane, wm, wn, acc,
                                            std::make_integer_sequence<int, NST>{});
     if (s < ns)
-      ring_round<NWM, NNI, SKB, NST, true>(lds, p, npad, kb_begin, s, ns, ns - s, col_i, col_j, wave, lane, wm, wn,
+      ring_round<FMT, NWM, NNI, SKB, NST, true>(lds, p, npad, kb_begin, s, ns, ns - s, col_i, col_j, wave, lane, wm, wn,
                                            acc, std::make_integer_sequence<int, NST - 1>{});
     return;
   }
   for (; s + NST - 1 < ns; s += NST)
-    ring_round<NWM, NNI, SKB, NST, false>(lds, p, npad, kb_begin, s, ns, NST, col_i, col_j, wave, lane, wm, wn, acc,
+    ring_round<FMT, NWM, NNI, SKB, NST, false>(lds, p, npad, kb_begin, s, ns, NST, col_i, col_j, wave, lane, wm, wn, acc,
                                           std::make_integer_sequence<int, NST>{});
   if (s < ns)
-    ring_round<NWM, NNI, SKB, NST, false>(lds, p, npad, kb_begin, s, ns, ns - s, col_i, col_j, wave, lane, wm, wn,
+    ring_round<FMT, NWM, NNI, SKB, NST, false>(lds, p, npad, kb_begin, s, ns, ns - s, col_i, col_j, wave, lane, wm, wn,
                                           acc, std::make_integer_sequence<int, NST - 1>{});
 
+  if constexpr (FMT == 1) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last asm MFMA -> VALU read of D
   // epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
   // Only the upper triangle (j >= i) is authoritative; pcoa_gram_finalize mirrors it.
 #pragma unroll
@@ -446,9 +546,12 @@ __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = col_i + wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int v = acc[mi][ni][r];
+        const int v = (int)acc[mi][ni][r];  // fp32 accumulators hold exact integers below 2^24
         if (j >= i && j < n && v != 0) atomicAdd(&s32[(int64_t)i * n + j], v);
       }
+      // keep the float->int conversions of one MFMA tile next to their atomics: hoisting all 128 of them
+      // ahead of the stores would need 128 more registers (the FP4 variant then spills)
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
@@ -456,13 +559,40 @@ __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram
 }  // namespace
 
 int64_t gram_i8_npad(int32_t n) { return ((int64_t)n + TM - 1) / TM * TM; }
-// k-blocks are padded to a multiple of 24 so that every stage depth (4, 6 or 8 k-blocks) divides it
-int64_t gram_i8_kb_pad(int64_t nv) {
-  const int64_t nkb = (nv + KB - 1) / KB;
+// k-blocks (16 variants for int8, 32 for FP4; 16 B per sample either way) are padded to a multiple of 24 so
+// that every stage depth (4, 6 or 8 k-blocks) divides the count
+int64_t gram_kb_pad(int64_t nv, int fmt) {
+  const int per = fmt == 1 ? 32 : KB;
+  const int64_t nkb = (nv + per - 1) / per;
   return (nkb + 23) / 24 * 24;
 }
-size_t gram_i8_workspace_bytes(int32_t n, int64_t nv) {
+int64_t gram_i8_kb_pad(int64_t nv) { return gram_kb_pad(nv, 0); }
+size_t gram_i8_workspace_bytes(int32_t n, int64_t nv) {  // the int8 size also covers the (half as large) FP4 operand
   return (size_t)gram_i8_kb_pad(nv) * (size_t)gram_i8_npad(n) * KB;
+}
+
+hipError_t launch_pack_fp4(const void* x, int is_u8, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
+                           hipStream_t stream) {
+  if (nv <= 0) return hipSuccess;
+  const int npad = (int)gram_i8_npad(n);
+  const int64_t nkb_pad = gram_kb_pad(nv, 1);
+  const int64_t threads = nkb_pad * (npad >> 2);
+  const int64_t blocks = (threads + 255) / 256;
+  if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+  const uintptr_t addr = reinterpret_cast<uintptr_t>(x);
+  const dim3 grid((unsigned)blocks), block(256);
+  if (is_u8) {
+    const bool vec = ((ld & 3) == 0) && ((addr & 3) == 0);
+    const uint8_t* xs = static_cast<const uint8_t*>(x);
+    if (vec) hipLaunchKernelGGL((pack_fp4_kernel<uint8_t, 4>), grid, block, 0, stream, xs, ld, nv, n, npad, nkb_pad, p, flag);
+    else hipLaunchKernelGGL((pack_fp4_kernel<uint8_t, 1>), grid, block, 0, stream, xs, ld, nv, n, npad, nkb_pad, p, flag);
+  } else {
+    const bool vec = ((ld & 3) == 0) && ((addr & 15) == 0);
+    const float* xs = static_cast<const float*>(x);
+    if (vec) hipLaunchKernelGGL((pack_fp4_kernel<float, 4>), grid, block, 0, stream, xs, ld, nv, n, npad, nkb_pad, p, flag);
+    else hipLaunchKernelGGL((pack_fp4_kernel<float, 1>), grid, block, 0, stream, xs, ld, nv, n, npad, nkb_pad, p, flag);
+  }
+  return hipGetLastError();
 }
 
 hipError_t launch_pack_f32_i8(const float* x, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
@@ -507,14 +637,22 @@ hipError_t launch_densify_csr_i8(const int32_t* idx_dev, const int64_t* offs_dev
   return hipGetLastError();
 }
 
+hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, int32_t* s32, int num_cu,
+                              hipStream_t stream, int* splitk_out);
+
 hipError_t launch_gram_i8_packed(const int8_t* p, int64_t nv, int32_t n, int32_t* s32, int num_cu,
                                  hipStream_t stream, int* splitk_out) {
+  return launch_gram_packed(p, 0, nv, n, s32, num_cu, stream, splitk_out);
+}
+
+hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, int32_t* s32, int num_cu,
+                              hipStream_t stream, int* splitk_out) {
   if (nv <= 0) return hipSuccess;
-  // PCOA_GRAM_I8_CFG = <k-blocks per stage><ring length>: 43 (default), 44, 25, 26, 63, 82
+  // PCOA_GRAM_I8_CFG = <k-blocks per stage><ring length>: 43 (default) or 44
   static const int cfg = [] {
     const char* v = std::getenv("PCOA_GRAM_I8_CFG");
     const int t = v ? std::atoi(v) : 43;
-    return (t == 44 || t == 25 || t == 26 || t == 63 || t == 82) ? t : 43;
+    return t == 44 ? 44 : 43;  // the deeper / shallower stage variants of DESIGN.md's table were all slower
   }();
   const int skb = cfg / 10;
   const int npad = (int)gram_i8_npad(n);
@@ -522,7 +660,7 @@ hipError_t launch_gram_i8_packed(const int8_t* p, int64_t nv, int32_t n, int32_t
   const int64_t ntri64 = (int64_t)ntile * (ntile + 1) / 2;
   if (ntri64 > (1 << 28)) return hipErrorInvalidValue;
   const int ntri = (int)ntri64;
-  const int64_t nstages = gram_i8_kb_pad(nv) / skb;
+  const int64_t nstages = gram_kb_pad(nv, fmt) / skb;
   // one 512-thread workgroup per CU is resident; aim at ~7 work units per CU, >= 1024 variants each
   const int64_t target = (int64_t)(num_cu > 0 ? num_cu : 256) * 7;
   int64_t splitk = (target + ntri - 1) / ntri;
@@ -543,15 +681,17 @@ hipError_t launch_gram_i8_packed(const int8_t* p, int64_t nv, int32_t n, int32_t
   if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
   if (splitk_out) *splitk_out = (int)splitk;
   const dim3 grid((unsigned)nblocks), block(512);
-#define PCOA_LAUNCH_I8(SKB_, NST_)                                                                            \
-  hipLaunchKernelGGL((gram_i8_kernel<2, 2, SKB_, NST_>), grid, block, 0, stream, p, npad, nstages, n, ntile, ntri, \
-                     (int)splitk, stages_per, s32, xcd_map)
+#define PCOA_LAUNCH_I8(SKB_, NST_)                                                                              \
+  do {                                                                                                          \
+    if (fmt == 1)                                                                                               \
+      hipLaunchKernelGGL((gram_i8_kernel<1, 2, 2, SKB_, NST_>), grid, block, 0, stream, p, npad, nstages, n, ntile, \
+                         ntri, (int)splitk, stages_per, s32, xcd_map);                                          \
+    else                                                                                                        \
+      hipLaunchKernelGGL((gram_i8_kernel<0, 2, 2, SKB_, NST_>), grid, block, 0, stream, p, npad, nstages, n, ntile, \
+                         ntri, (int)splitk, stages_per, s32, xcd_map);                                          \
+  } while (0)
   switch (cfg) {
     case 44: PCOA_LAUNCH_I8(4, 4); break;
-    case 25: PCOA_LAUNCH_I8(2, 5); break;
-    case 26: PCOA_LAUNCH_I8(2, 6); break;
-    case 63: PCOA_LAUNCH_I8(6, 3); break;
-    case 82: PCOA_LAUNCH_I8(8, 2); break;
     default: PCOA_LAUNCH_I8(4, 3); break;
   }
 #undef PCOA_LAUNCH_I8

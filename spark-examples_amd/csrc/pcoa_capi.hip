@@ -62,7 +62,10 @@ struct pcoa_ctx {
   int64_t* coll = nullptr;         // 2 int64: {variants in S32, has-S64 flag} agreed across ranks
   int8_t* pack_buf = nullptr;      // k-blocked int8 workspace of the i8 path (lazy)
   int64_t pack_cap = 0;            // bytes
-  bool use_i8 = true;              // i8-MFMA Gram (default) or fp32-MFMA Gram
+  bool use_i8 = true;              // packed-operand Gram (FP4 / int8) or fp32-MFMA Gram
+  int packed_mode = 0;             // 0 auto (FP4 for binary tiles, int8 otherwise), 2 int8 only, 3 FP4 only
+  int32_t* fp4_flag = nullptr;     // device: raised by the FP4 pre-pass on a value other than 0 / 1
+  int64_t fp4_fallbacks = 0;
   int64_t pack_chunk = (int64_t)1 << 20;  // variants packed + contracted per launch pair
   int64_t pack_launches = 0;
   double pack_bytes = 0;
@@ -243,7 +246,61 @@ int fold_if_needed(pcoa_ctx* c, int64_t cur) {
   return PCOA_OK;
 }
 
-// uint8 tile resident on the device -> k-blocked int8 -> i8 contraction (always the i8 path)
+// One chunk (<= pack_chunk variants) of a dense tile resident on the device: re-layout pre-pass into the
+// packed operand workspace, then the matrix-core contraction.
+//   auto : FP4 pre-pass (it also verifies that every value is exactly 0 or 1); if a tile holds a
+//          multiplicity the chunk is re-packed as int8 and contracted on the i8 MFMA instead;
+//   fp4  : FP4 only, a non-binary value is an error;   i8 : int8 only (values 0..127).
+int packed_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64_t ld) {
+  const int64_t need = (int64_t)gram_i8_workspace_bytes(c->n, cur);
+  int rc = ensure(c, &c->pack_buf, &c->pack_cap, need);
+  if (rc != PCOA_OK) return rc;
+  const double in_bytes = (is_u8 ? 1.0 : 4.0) * (double)cur * (double)c->n;
+  bool fp4 = c->packed_mode != 2;
+  if (fp4) {
+    int32_t* flag = c->err_flag;
+    if (c->packed_mode == 0) {
+      if (!c->fp4_flag) HIP_TRY(c, hipMalloc((void**)&c->fp4_flag, 16));
+      HIP_TRY(c, hipMemsetAsync(c->fp4_flag, 0, 16, c->stream));
+      flag = c->fp4_flag;
+    }
+    {
+      ScopedTimer t(c, T_PACK);
+      hipError_t e = launch_pack_fp4(x_chunk, is_u8, ld, cur, c->n, c->pack_buf, flag, c->stream);
+      if (e != hipSuccess) return hip_fail(c, e, "pack(fp4) kernel launch");
+    }
+    c->pack_launches += 1;
+    c->pack_bytes += in_bytes + 0.5 * (double)need;
+    if (c->packed_mode == 0) {
+      int32_t seen = 0;
+      HIP_TRY(c, hipMemcpyAsync(&seen, c->fp4_flag, sizeof(seen), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      if (seen) {  // a multiplicity (or garbage): this chunk takes the int8 path, which validates 0..127
+        fp4 = false;
+        c->fp4_fallbacks += 1;
+      }
+    }
+  }
+  if (!fp4) {
+    ScopedTimer t(c, T_PACK);
+    hipError_t e = is_u8 ? launch_pack_u8_i8(static_cast<const uint8_t*>(x_chunk), ld, cur, c->n, c->pack_buf,
+                                             c->err_flag, c->stream)
+                         : launch_pack_f32_i8(static_cast<const float*>(x_chunk), ld, cur, c->n, c->pack_buf,
+                                              c->err_flag, c->stream);
+    if (e != hipSuccess) return hip_fail(c, e, "pack(i8) kernel launch");
+    c->pack_launches += 1;
+    c->pack_bytes += in_bytes + (double)need;
+  }
+  {
+    ScopedTimer t(c, T_GRAM);
+    hipError_t e = launch_gram_packed(c->pack_buf, fp4 ? 1 : 0, cur, c->n, c->s32, c->num_cu, c->stream, nullptr);
+    if (e != hipSuccess) return hip_fail(c, e, "packed gram kernel launch");
+  }
+  c->gram_kind = fp4 ? 3 : 2;
+  return PCOA_OK;
+}
+
+// uint8 tile resident on the device (always a packed-operand path)
 int gram_device_u8(pcoa_ctx* c, const uint8_t* x_dev, int64_t nv, int64_t ld) {
   int64_t done = 0;
   const int64_t max_cur = std::min(c->max_launch, c->pack_chunk);
@@ -251,21 +308,8 @@ int gram_device_u8(pcoa_ctx* c, const uint8_t* x_dev, int64_t nv, int64_t ld) {
     const int64_t cur = std::min(nv - done, max_cur);
     int rc = fold_if_needed(c, cur);
     if (rc != PCOA_OK) return rc;
-    const int64_t need = (int64_t)gram_i8_workspace_bytes(c->n, cur);
-    rc = ensure(c, &c->pack_buf, &c->pack_cap, need);
+    rc = packed_chunk(c, x_dev + done * ld, 1, cur, ld);
     if (rc != PCOA_OK) return rc;
-    {
-      ScopedTimer t(c, T_PACK);
-      hipError_t e = launch_pack_u8_i8(x_dev + done * ld, ld, cur, c->n, c->pack_buf, c->err_flag, c->stream);
-      if (e != hipSuccess) return hip_fail(c, e, "pack(u8) kernel launch");
-    }
-    c->pack_launches += 1;
-    c->pack_bytes += (double)cur * (double)c->n + (double)need;
-    {
-      ScopedTimer t(c, T_GRAM);
-      hipError_t e = launch_gram_i8_packed(c->pack_buf, cur, c->n, c->s32, c->num_cu, c->stream, nullptr);
-      if (e != hipSuccess) return hip_fail(c, e, "gram i8 kernel launch");
-    }
     account_gram(c, cur);
     done += cur;
   }
@@ -283,25 +327,12 @@ int gram_device(pcoa_ctx* c, const float* x_dev, int64_t nv, int64_t ld) {
       if (rc != PCOA_OK) return rc;
     }
     if (c->use_i8) {
-      // fp32 tile -> k-blocked int8 (HBM-bound pre-pass), then the i8-MFMA contraction, back to back on
+      // fp32 tile -> packed operand (HBM-bound pre-pass), then the matrix-core contraction, back to back on
       // one stream.  (Running the pre-pass on a second stream beside the contraction was measured
       // SLOWER, 5.45 vs 5.09 ms per 10^6 variants: both kernels want all 256 CUs and the resident
       // pre-pass waves block placement of the 96 KiB-LDS contraction workgroups.)
-      const int64_t need = (int64_t)gram_i8_workspace_bytes(c->n, cur);
-      int rc = ensure(c, &c->pack_buf, &c->pack_cap, need);
+      int rc = packed_chunk(c, x_dev + done * ld, 0, cur, ld);
       if (rc != PCOA_OK) return rc;
-      {
-        ScopedTimer t(c, T_PACK);
-        hipError_t e = launch_pack_f32_i8(x_dev + done * ld, ld, cur, c->n, c->pack_buf, c->err_flag, c->stream);
-        if (e != hipSuccess) return hip_fail(c, e, "pack kernel launch");
-      }
-      c->pack_launches += 1;
-      c->pack_bytes += 4.0 * (double)cur * (double)c->n + (double)need;
-      {
-        ScopedTimer t(c, T_GRAM);
-        hipError_t e = launch_gram_i8_packed(c->pack_buf, cur, c->n, c->s32, c->num_cu, c->stream, nullptr);
-        if (e != hipSuccess) return hip_fail(c, e, "gram i8 kernel launch");
-      }
     } else {
       GramLaunch g;
       g.x = x_dev + done * ld;
@@ -328,6 +359,10 @@ int check_device_flags(pcoa_ctx* c) {
   HIP_TRY(c, hipMemcpyAsync(&flag, c->err_flag, sizeof(flag), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (flag & 1) return fail(c, PCOA_ERR_INDEX_RANGE, "a callset index outside [0, N) reached the device");
+  if (flag & 8)
+    return fail(c, PCOA_ERR_INVALID_ARG,
+                "a genotype tile holds a value other than 0 or 1 and PCOA_FLAG_GRAM_FP4_MFMA was forced; S is "
+                "invalid, call pcoa_reset; the default mode falls back to the int8 kernel by itself");
   if (flag & 4)
     return fail(c, PCOA_ERR_INVALID_ARG,
                 "a genotype tile holds a value that is not an integer in [0, 127] (carrier multiplicity); S is "
@@ -425,11 +460,14 @@ int pcoa_create(pcoa_ctx** out, int32_t n_samples, int32_t device_ordinal, uint3
   c->device = device_ordinal;
   c->flags = flags;
   c->use_i8 = !(flags & PCOA_FLAG_GRAM_F32_MFMA);
+  c->packed_mode = (flags & PCOA_FLAG_GRAM_I8_MFMA) ? 2 : (flags & PCOA_FLAG_GRAM_FP4_MFMA) ? 3 : 0;
   if (const char* kk = std::getenv("PCOA_GRAM_KERNEL")) {
     if (!std::strcmp(kk, "f32")) c->use_i8 = false;
-    if (!std::strcmp(kk, "i8")) c->use_i8 = true;
+    if (!std::strcmp(kk, "i8")) { c->use_i8 = true; c->packed_mode = 2; }
+    if (!std::strcmp(kk, "fp4")) { c->use_i8 = true; c->packed_mode = 3; }
+    if (!std::strcmp(kk, "auto")) { c->use_i8 = true; c->packed_mode = 0; }
   }
-  c->gram_kind = c->use_i8 ? 2 : 1;
+  c->gram_kind = c->use_i8 ? (c->packed_mode == 2 ? 2 : 3) : 1;
   {
     // keep the int8 workspace at or below ~4 GiB whatever N is (one byte per genotype, Npad columns)
     const int64_t by_mem = (((int64_t)4 << 30) / gram_i8_npad(n_samples)) / 1536 * 1536;
@@ -474,7 +512,7 @@ void pcoa_destroy(pcoa_ctx* c) {
   for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto& ev : c->pool) (void)hipEventDestroy(ev);
   void* bufs[] = {c->s32, c->s64, c->zeros, c->err_flag, c->tile, c->csr_idx, c->csr_offs, c->thr_dev,
-                  c->sample_pop, c->xfer, c->coll, c->pack_buf, c->lanczos_ws, c->ws.a, c->ws.d, c->ws.e, c->ws.tau, c->ws.q, c->ws.w, c->ws.lam,
+                  c->sample_pop, c->xfer, c->coll, c->fp4_flag, c->pack_buf, c->lanczos_ws, c->ws.a, c->ws.d, c->ws.e, c->ws.tau, c->ws.q, c->ws.w, c->ws.lam,
                   c->ws.z, c->ws.scratch, c->ws.iscratch, c->row_sums, c->stats, c->nz,
                   c->out_dev};
   for (void* b : bufs)
@@ -615,6 +653,7 @@ int pcoa_accumulate_calls(pcoa_ctx* c, const int32_t* sample_idx, const int64_t*
         ScopedTimer t(c, T_GRAM);
         HIP_TRY(c, launch_gram_i8_packed(c->pack_buf, rows, c->n, c->s32, c->num_cu, c->stream, nullptr));
       }
+      c->gram_kind = 2;  // carrier lists may repeat a callset: always the int8 kernel
       account_gram(c, rows);
       continue;
     }
@@ -978,6 +1017,7 @@ int pcoa_get_timings(pcoa_ctx* c, pcoa_timings* out) {
   out->lanczos_seconds = c->tsec[T_LANCZOS];
   out->eig_method = c->eig_method;
   out->lanczos_steps = c->lanczos_steps;
+  out->fp4_fallbacks = c->fp4_fallbacks;
   out->pack_seconds = c->tsec[T_PACK];
   out->pack_launches = c->pack_launches;
   out->pack_bytes = c->pack_bytes;

@@ -27,7 +27,8 @@ def _ptr(a):
 
 class PcoaEngine(object):
     def __init__(self, n_samples, device=0, flags=L.PCOA_FLAG_DEFAULT, gram_kernel=None, eig=None):
-        """gram_kernel: None/"i8" (default: exact i8-MFMA path) or "f32" (fp32-MFMA path).
+        """gram_kernel: None/"auto" (MX-FP4 MFMA for binary tiles, int8 MFMA for multiplicities; both exact),
+        "fp4", "i8" (force one of them) or "f32" (fp32-MFMA path).
         eig: None/"auto" (Lanczos with verified residual, Householder fallback), "householder", "lanczos"."""
         if eig == "householder":
             flags |= L.PCOA_FLAG_EIG_HOUSEHOLDER
@@ -37,8 +38,12 @@ class PcoaEngine(object):
             raise ValueError("eig must be 'auto', 'householder' or 'lanczos'")
         if gram_kernel == "f32":
             flags |= L.PCOA_FLAG_GRAM_F32_MFMA
-        elif gram_kernel not in (None, "i8"):
-            raise ValueError("gram_kernel must be 'i8' or 'f32'")
+        elif gram_kernel == "i8":
+            flags |= L.PCOA_FLAG_GRAM_I8_MFMA
+        elif gram_kernel == "fp4":
+            flags |= L.PCOA_FLAG_GRAM_FP4_MFMA
+        elif gram_kernel not in (None, "auto"):
+            raise ValueError("gram_kernel must be 'auto', 'fp4', 'i8' or 'f32'")
         self._lib = L.load()
         self._ctx = ctypes.c_void_p()
         rc = self._lib.pcoa_create(ctypes.byref(self._ctx), int(n_samples), int(device), int(flags))

@@ -33,7 +33,9 @@ def callsets_of(x):
     return [list(np.nonzero(r)[0]) for r in x]
 
 
-KERNELS = ["i8", "f32"]  # both Gram kernels must give the reference's integers
+# every Gram kernel must give the reference's integers: auto = MX-FP4 MFMA for binary tiles with a
+# per-chunk int8 fallback, fp4 / i8 / f32 force one kernel
+KERNELS = ["auto", "fp4", "i8", "f32"]
 
 
 # ------------------------------------------------------------------------------------------ Gram
@@ -123,9 +125,16 @@ def test_u8_boundary_matches_oracle_host_and_device(P, O, n, v):
     x = (rng.random((v, n)) < 0.25).astype(np.uint8)
     x[0, 0] = 3  # multiplicities up to 127 are legal
     want = (x.T.astype(np.int64) @ x.astype(np.int64))
+    with P.PcoaEngine(n, gram_kernel="fp4") as eng:   # binary uint8 tile on the FP4 kernel
+        xb = np.minimum(x, 1)
+        eng.accumulate_dense_u8(xb)
+        assert np.array_equal(eng.gram(), xb.T.astype(np.int64) @ xb.astype(np.int64))
+        assert eng.timings()["gram_kernel_kind"] == 3
     with P.PcoaEngine(n) as eng:
         eng.accumulate_dense_u8(x)
         assert np.array_equal(eng.gram(), want)
+        t = eng.timings()
+        assert t["fp4_fallbacks"] == 1 and t["gram_kernel_kind"] == 2   # the 3 sent this chunk to the int8 kernel
         eng.reset()
         for ld in (n, n + 1, ((n + 15) // 16) * 16 + 16):  # unaligned and padded strides, padding = 0xff
             buf = torch.full((v, ld), 255, dtype=torch.uint8, device="cuda")
@@ -155,15 +164,52 @@ def test_i8_path_rejects_non_integer_or_large_values_and_f32_path_accepts_intege
     xb[7, 2] = 127.0
     xb[9, 2] = 3.0
     want = (xb.T.astype(np.int64) @ xb.astype(np.int64))
-    for kernel in KERNELS:
+    for kernel in ("auto", "i8", "f32"):
         with P.PcoaEngine(12, gram_kernel=kernel) as eng:
             eng.accumulate_dense(xb)
             assert np.array_equal(eng.gram(), want)
+    with P.PcoaEngine(12, gram_kernel="fp4") as eng:   # forced FP4 refuses anything but 0 / 1
+        eng.accumulate_dense(xb)
+        with pytest.raises(P.PcoaError) as ei:
+            eng.gram()
+        assert "other than 0 or 1" in str(ei.value)
     xb[7, 2] = 300.0  # beyond int8: only the fp32-MFMA kernel takes it
     want = (xb.T.astype(np.int64) @ xb.astype(np.int64))
     with P.PcoaEngine(12, gram_kernel="f32") as eng:
         eng.accumulate_dense(xb)
         assert np.array_equal(eng.gram(), want)
+
+
+def test_auto_mode_picks_fp4_per_chunk_and_falls_back_to_int8_on_multiplicities(P, O):
+    """auto: binary chunks run on the MX-FP4 MFMA, a chunk holding a multiplicity is re-packed as int8;
+    the sum over chunks is exact either way (chunk size forced small through the debug hook)."""
+    rng = np.random.default_rng(77)
+    n, v = 333, 1000
+    x = (rng.random((v, n)) < 0.3).astype(np.float32)
+    x[700, 5] = 2.0          # only the chunk holding variant 700 must fall back
+    x[701, 9] = 100.0
+    want = (x.T.astype(np.int64) @ x.astype(np.int64))
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r);"
+            "from conftest import load_pkg; P = load_pkg(); x = np.load(sys.argv[1]);"
+            "e = P.PcoaEngine(x.shape[1]); e.accumulate_dense(x); s = e.gram(); t = e.timings();"
+            "np.save(sys.argv[2], s); print(json.dumps([t['fp4_fallbacks'], t['pack_launches']]))"
+            ) % (ROOT, os.path.join(ROOT, "tests"))
+    import json
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        np.save(os.path.join(td, "x.npy"), x)
+        env = dict(os.environ, PCOA_DEBUG_PACK_CHUNK="256")
+        out = subprocess.check_output([sys.executable, "-c", code, os.path.join(td, "x.npy"),
+                                       os.path.join(td, "s.npy")], env=env)
+        fallbacks, packs = json.loads(out.decode().strip().splitlines()[-1])
+        assert np.array_equal(np.load(os.path.join(td, "s.npy")), want)
+        assert fallbacks == 1 and packs == 4 + 1   # 4 chunks, one of them packed twice
+    with P.PcoaEngine(n) as eng:                   # binary input: no fallback, FP4 kernel
+        xb = np.minimum(x, 1.0)
+        eng.accumulate_dense(xb)
+        assert np.array_equal(eng.gram(), O.similarity_from_dense(xb, n))
+        t = eng.timings()
+        assert t["fp4_fallbacks"] == 0 and t["gram_kernel_kind"] == 3
 
 
 def test_empty_and_ragged_inputs(P):
@@ -235,7 +281,9 @@ def test_multi_launch_and_int64_fold_paths(P, O):
     import tempfile
     with tempfile.TemporaryDirectory() as td:
         np.save(os.path.join(td, "x.npy"), x)
-        for extra in ({"PCOA_GRAM_KERNEL": "f32"}, {"PCOA_GRAM_KERNEL": "i8", "PCOA_DEBUG_PACK_CHUNK": "48"}):
+        for extra in ({"PCOA_GRAM_KERNEL": "f32"}, {"PCOA_GRAM_KERNEL": "i8", "PCOA_DEBUG_PACK_CHUNK": "48"},
+                      {"PCOA_GRAM_KERNEL": "fp4", "PCOA_DEBUG_PACK_CHUNK": "48"},
+                      {"PCOA_GRAM_KERNEL": "auto", "PCOA_DEBUG_PACK_CHUNK": "40"}):
             env = dict(os.environ, PCOA_DEBUG_MAX_LAUNCH="64", PCOA_DEBUG_FOLD_THRESHOLD="200", **extra)
             subprocess.check_call([sys.executable, "-c", code, os.path.join(td, "x.npy"),
                                    os.path.join(td, "s.npy")], env=env)
@@ -304,9 +352,10 @@ def test_full_config2_size_properties(P):
         eng.accumulate_dense(x[:400001])
         eng.accumulate_dense(x[400001:])
         assert np.array_equal(eng.gram(), s)
-    with P.PcoaEngine(n, gram_kernel="f32") as eng:   # the fp32-MFMA kernel gives the same integers
-        eng.accumulate_dense(x)
-        assert np.array_equal(eng.gram(), s)
+    for kernel in ("i8", "f32"):   # the int8- and fp32-MFMA kernels give the same integers as the FP4 one
+        with P.PcoaEngine(n, gram_kernel=kernel) as eng:
+            eng.accumulate_dense(x)
+            assert np.array_equal(eng.gram(), s), kernel
 
 
 # ------------------------------------------------------------------------------------------ PCA
