@@ -49,6 +49,15 @@ for s in $STEPS; do
         env $AB_VAR=$t timeout 600 python bench.py --gpus 1 --steps 8 --warmup 2 --no-cpu-baseline --pcoa-reps 1 > $OUT/bench_ab_$t.json 2>> $OUT/bench_ab.err
         python -c "import json,sys; d=json.load(open('$OUT/bench_ab_$t.json')); print('$AB_VAR=$t: value %.1f M/s, ms/step %.3f, gram %.3f ms, pack %.3f ms' % (d['value']/1e6, d['ms_per_step'], d['gram_ms_per_step'], d['pack_ms_per_step']))" | tee -a $OUT/summary.txt
       done ;;
+    abenv)
+      # AB_SETS="A=1 B=2;C=3;" -> one bench run per ';'-separated environment (empty = defaults), two rounds
+      for round in 1 2; do
+        IFS=';' read -ra SETS <<< "$AB_SETS"
+        for set in "${SETS[@]}"; do
+          env $set timeout 600 python bench.py --gpus 1 --steps 8 --warmup 2 --no-cpu-baseline --no-extras --pcoa-reps 1 > $OUT/bench_abenv.json 2>> $OUT/bench_ab.err
+          python -c "import json,sys; d=json.load(open('$OUT/bench_abenv.json')); print('[%s] value %.1f M/s, ms/step %.3f, gram %.3f ms, pack %.3f ms' % ('$set', d['value']/1e6, d['ms_per_step'], d['gram_ms_per_step'], d['pack_ms_per_step']))" | tee -a $OUT/summary.txt
+        done
+      done ;;
     testsab)
       for t in $AB_VALUES; do
         env $AB_VAR=$t timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 600 -x -k "gram or config2 or full_config2 or multi_launch or synthetic" > $OUT/tests_$t.log 2>&1
