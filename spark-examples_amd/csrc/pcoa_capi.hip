@@ -68,9 +68,12 @@ struct pcoa_ctx {
   int64_t fp4_fallbacks = 0;
   // overlapped pipeline: the HBM-bound pre-pass of sub-chunk i+1 runs on a second (low-priority) stream beside
   // the matrix-core contraction of sub-chunk i
-  bool overlap = false;
+  int overlap = 0;                 // 0 off, 1 two streams with priorities, 2 two streams on disjoint CU masks
+  int pack_cus_per_xcd = 8;        // overlap 2: CUs per XCD reserved for the pre-pass stream
   int64_t sub_chunk = (int64_t)1 << 18;
   hipStream_t pack_stream = nullptr;
+  hipStream_t gram_stream = nullptr;
+  hipEvent_t ev_join = nullptr;
   int8_t* pack_buf2 = nullptr;
   int64_t pack_cap2 = 0;
   hipEvent_t ev_fork = nullptr, ev_packed[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
@@ -313,11 +316,34 @@ int packed_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64
 
 constexpr int kMaxSub = 64;
 
+// CU mask of the pre-pass stream: k CUs of every XCD (k = 4, 8, 12, ... 28).  The bit -> (XCD, CU) layout of the
+// mask is either "32 consecutive bits per XCD" or "bit i -> XCD i % 8"; the pattern below gives every XCD exactly k
+// CUs under both: whole groups of 8 consecutive bits inside each 32-bit word, plus (k % 8 == 4) four bits of the
+// next group at residues (word + 2t) % 8.
+void pack_cu_mask(int k, uint32_t mask[8]) {
+  for (int j = 0; j < 8; ++j) {
+    uint32_t m = 0;
+    for (int g = 0; g < k / 8; ++g) m |= 0xffu << (8 * g);
+    if (k % 8 >= 4)
+      for (int t = 0; t < 4; ++t) m |= 1u << (8 * (k / 8) + (j + 2 * t) % 8);
+    mask[j] = m;
+  }
+}
+
 int overlap_setup(pcoa_ctx* c) {
   if (c->pack_stream) return PCOA_OK;
-  int least = 0, greatest = 0;
-  HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
-  HIP_TRY(c, hipStreamCreateWithPriority(&c->pack_stream, hipStreamNonBlocking, least));
+  if (c->overlap == 2 && c->num_cu == 256) {
+    uint32_t mp[8], mg[8];
+    pack_cu_mask(c->pack_cus_per_xcd, mp);
+    for (int j = 0; j < 8; ++j) mg[j] = ~mp[j];
+    HIP_TRY(c, hipExtStreamCreateWithCUMask(&c->pack_stream, 8, mp));
+    HIP_TRY(c, hipExtStreamCreateWithCUMask(&c->gram_stream, 8, mg));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  } else {
+    int least = 0, greatest = 0;
+    HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIP_TRY(c, hipStreamCreateWithPriority(&c->pack_stream, hipStreamNonBlocking, least));
+  }
   HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   for (int b = 0; b < 2; ++b) {
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_packed[b], hipEventDisableTiming));
@@ -343,6 +369,8 @@ int packed_overlapped(pcoa_ctx* c, const void* x, int is_u8, int64_t nv, int64_t
   const int64_t esz = is_u8 ? 1 : 4;
   const char* xb = static_cast<const char*>(x);
   const bool autom = c->packed_mode == 0;
+  hipStream_t gs = c->gram_stream ? c->gram_stream : c->stream;
+  const int gram_cus = c->gram_stream ? c->num_cu - 8 * c->pack_cus_per_xcd : c->num_cu;
   for (int64_t g0 = 0; g0 < nv; g0 += sub * kMaxSub) {
     const int64_t gn = std::min(nv - g0, sub * kMaxSub);
     if ((rc = fold_if_needed(c, gn)) != PCOA_OK) return rc;
@@ -350,6 +378,7 @@ int packed_overlapped(pcoa_ctx* c, const void* x, int is_u8, int64_t nv, int64_t
     if (autom) HIP_TRY(c, hipMemsetAsync(c->sub_flags, 0, sizeof(int32_t) * kMaxSub, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
     HIP_TRY(c, hipStreamWaitEvent(c->pack_stream, c->ev_fork, 0));
+    if (gs != c->stream) HIP_TRY(c, hipStreamWaitEvent(gs, c->ev_fork, 0));
     for (int i = 0; i < ns; ++i) {
       const int b = i & 1;
       const int64_t v0 = g0 + (int64_t)i * sub;
@@ -365,16 +394,20 @@ int packed_overlapped(pcoa_ctx* c, const void* x, int is_u8, int64_t nv, int64_t
       c->pack_launches += 1;
       c->pack_bytes += (double)esz * (double)cur * (double)c->n + 0.5 * (double)gram_i8_workspace_bytes(c->n, cur);
       HIP_TRY(c, hipEventRecord(c->ev_packed[b], c->pack_stream));
-      HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_packed[b], 0));
+      HIP_TRY(c, hipStreamWaitEvent(gs, c->ev_packed[b], 0));
       {
-        ScopedTimer t(c, T_GRAM);
-        hipError_t e = launch_gram_packed(buf[b], 1, cur, c->n, c->s32, c->num_cu, c->stream, nullptr,
+        ScopedTimer t(c, T_GRAM, gs);
+        hipError_t e = launch_gram_packed(buf[b], 1, cur, c->n, c->s32, gram_cus, gs, nullptr,
                                           autom ? c->sub_flags + i : nullptr);
         if (e != hipSuccess) return hip_fail(c, e, "packed gram kernel launch");
       }
-      HIP_TRY(c, hipEventRecord(c->ev_consumed[b], c->stream));
+      HIP_TRY(c, hipEventRecord(c->ev_consumed[b], gs));
       c->gram_kind = 3;
       account_gram(c, cur);
+    }
+    if (gs != c->stream) {
+      HIP_TRY(c, hipEventRecord(c->ev_join, gs));
+      HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     }
     if (autom) {
       int32_t seen[kMaxSub];
@@ -584,7 +617,11 @@ int pcoa_create(pcoa_ctx** out, int32_t n_samples, int32_t device_ordinal, uint3
     if (!std::strcmp(kk, "auto")) { c->use_i8 = true; c->packed_mode = 0; }
   }
   c->gram_kind = c->use_i8 ? (c->packed_mode == 2 ? 2 : 3) : 1;
-  if (const char* ov = std::getenv("PCOA_OVERLAP")) c->overlap = std::atoi(ov) != 0;
+  if (const char* ov = std::getenv("PCOA_OVERLAP")) c->overlap = std::atoi(ov);
+  if (const char* pc = std::getenv("PCOA_PACK_CUS")) {
+    const int t = std::atoi(pc);
+    if (t >= 4 && t <= 28 && t % 4 == 0) c->pack_cus_per_xcd = t;
+  }
   if (const char* sc = std::getenv("PCOA_SUB_CHUNK")) {
     const long long t = std::atoll(sc);
     if (t >= 1024) c->sub_chunk = t;
@@ -634,6 +671,7 @@ void pcoa_destroy(pcoa_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->pack_stream) (void)hipStreamSynchronize(c->pack_stream);
+  if (c->gram_stream) (void)hipStreamSynchronize(c->gram_stream);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto& ev : c->pool) (void)hipEventDestroy(ev);
@@ -644,7 +682,8 @@ void pcoa_destroy(pcoa_ctx* c) {
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->pack_stream) (void)hipStreamDestroy(c->pack_stream);
-  for (hipEvent_t ev : {c->ev_fork, c->ev_packed[0], c->ev_packed[1], c->ev_consumed[0], c->ev_consumed[1]})
+  if (c->gram_stream) (void)hipStreamDestroy(c->gram_stream);
+  for (hipEvent_t ev : {c->ev_join, c->ev_fork, c->ev_packed[0], c->ev_packed[1], c->ev_consumed[0], c->ev_consumed[1]})
     if (ev) (void)hipEventDestroy(ev);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
