@@ -475,11 +475,8 @@ __device__ __forceinline__ void tile_coords(int tile, int ntile, int& row_blk, i
 template <int FMT, int NWM, int NNI, int SKB, int NST>
 __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram_i8_kernel(
     const int8_t* __restrict__ p, int npad, int64_t nstages, int n, int ntile, int ntri, int splitk,
-    int64_t stages_per, int32_t* __restrict__ s32, int xcd_map, const int32_t* __restrict__ skip_flag) {
+    int64_t stages_per, int32_t* __restrict__ s32, int xcd_map) {
   __shared__ __attribute__((aligned(16))) StageI8<NWM, SKB> lds[NST];
-  // set by the FP4 pre-pass of THIS chunk when it met a value other than 0 / 1: the host re-runs the chunk on
-  // the int8 kernel, this launch must then add nothing (uniform scalar load)
-  if (skip_flag != nullptr && *skip_flag != 0) return;
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -640,13 +637,16 @@ hipError_t launch_densify_csr_i8(const int32_t* idx_dev, const int64_t* offs_dev
   return hipGetLastError();
 }
 
+hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, int32_t* s32, int num_cu,
+                              hipStream_t stream, int* splitk_out);
+
 hipError_t launch_gram_i8_packed(const int8_t* p, int64_t nv, int32_t n, int32_t* s32, int num_cu,
                                  hipStream_t stream, int* splitk_out) {
-  return launch_gram_packed(p, 0, nv, n, s32, num_cu, stream, splitk_out, nullptr);
+  return launch_gram_packed(p, 0, nv, n, s32, num_cu, stream, splitk_out);
 }
 
 hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, int32_t* s32, int num_cu,
-                              hipStream_t stream, int* splitk_out, const int32_t* skip_flag) {
+                              hipStream_t stream, int* splitk_out) {
   if (nv <= 0) return hipSuccess;
   // PCOA_GRAM_I8_CFG = <k-blocks per stage><ring length>: 43 (default) or 44
   static const int cfg = [] {
@@ -655,12 +655,8 @@ hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, i
     return t == 44 ? 44 : 43;  // the deeper / shallower stage variants of DESIGN.md's table were all slower
   }();
   const int skb = cfg / 10;
-  // PCOA_DEBUG_ALIAS_K (timing experiments only, results are WRONG): every k-block aliases the first one, so the
-  // whole operand stream hits in cache -- the contraction's speed with a perfect memory system
-  static const bool alias_k = std::getenv("PCOA_DEBUG_ALIAS_K") != nullptr;
-  const int npad_real = (int)gram_i8_npad(n);
-  const int npad = alias_k ? 0 : npad_real;
-  const int ntile = npad_real / TJ;
+  const int npad = (int)gram_i8_npad(n);
+  const int ntile = npad / TJ;
   const int64_t ntri64 = (int64_t)ntile * (ntile + 1) / 2;
   if (ntri64 > (1 << 28)) return hipErrorInvalidValue;
   const int ntri = (int)ntri64;
@@ -689,10 +685,10 @@ hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, i
   do {                                                                                                          \
     if (fmt == 1)                                                                                               \
       hipLaunchKernelGGL((gram_i8_kernel<1, 2, 2, SKB_, NST_>), grid, block, 0, stream, p, npad, nstages, n, ntile, \
-                         ntri, (int)splitk, stages_per, s32, xcd_map, skip_flag);                               \
+                         ntri, (int)splitk, stages_per, s32, xcd_map);                                          \
     else                                                                                                        \
       hipLaunchKernelGGL((gram_i8_kernel<0, 2, 2, SKB_, NST_>), grid, block, 0, stream, p, npad, nstages, n, ntile, \
-                         ntri, (int)splitk, stages_per, s32, xcd_map, skip_flag);                               \
+                         ntri, (int)splitk, stages_per, s32, xcd_map);                                          \
   } while (0)
   switch (cfg) {
     case 44: PCOA_LAUNCH_I8(4, 4); break;

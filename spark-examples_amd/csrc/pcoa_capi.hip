@@ -66,18 +66,6 @@ struct pcoa_ctx {
   int packed_mode = 0;             // 0 auto (FP4 for binary tiles, int8 otherwise), 2 int8 only, 3 FP4 only
   int32_t* fp4_flag = nullptr;     // device: raised by the FP4 pre-pass on a value other than 0 / 1
   int64_t fp4_fallbacks = 0;
-  // overlapped pipeline: the HBM-bound pre-pass of sub-chunk i+1 runs on a second (low-priority) stream beside
-  // the matrix-core contraction of sub-chunk i
-  int overlap = 0;                 // 0 off, 1 two streams with priorities, 2 two streams on disjoint CU masks
-  int pack_cus_per_xcd = 8;        // overlap 2: CUs per XCD reserved for the pre-pass stream
-  int64_t sub_chunk = (int64_t)1 << 18;
-  hipStream_t pack_stream = nullptr;
-  hipStream_t gram_stream = nullptr;
-  hipEvent_t ev_join = nullptr;
-  int8_t* pack_buf2 = nullptr;
-  int64_t pack_cap2 = 0;
-  hipEvent_t ev_fork = nullptr, ev_packed[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
-  int32_t* sub_flags = nullptr;    // device, kMaxSub ints: FP4 pre-pass verdict per sub-chunk
   int64_t pack_chunk = (int64_t)1 << 20;  // variants packed + contracted per launch pair
   int64_t pack_launches = 0;
   double pack_bytes = 0;
@@ -172,15 +160,14 @@ struct ScopedTimer {
   pcoa_ctx* c;
   EventPair p;
   bool on;
-  hipStream_t st;
-  ScopedTimer(pcoa_ctx* ctx, int cat, hipStream_t stream = nullptr) : c(ctx), on(false), st(stream ? stream : ctx->stream) {
+  ScopedTimer(pcoa_ctx* ctx, int cat) : c(ctx), on(false) {
     p.a = get_event(c);
     p.b = get_event(c);
     p.cat = cat;
-    if (p.a && p.b && hipEventRecord(p.a, st) == hipSuccess) on = true;
+    if (p.a && p.b && hipEventRecord(p.a, c->stream) == hipSuccess) on = true;
   }
   ~ScopedTimer() {
-    if (on && hipEventRecord(p.b, st) == hipSuccess) {
+    if (on && hipEventRecord(p.b, c->stream) == hipSuccess) {
       c->pending.push_back(p);
       if (c->pending.size() > 2048) drain_events(c, true);
     } else {
@@ -306,150 +293,15 @@ int packed_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64
   }
   {
     ScopedTimer t(c, T_GRAM);
-    hipError_t e = launch_gram_packed(c->pack_buf, fp4 ? 1 : 0, cur, c->n, c->s32, c->num_cu, c->stream, nullptr,
-                                      nullptr);
+    hipError_t e = launch_gram_packed(c->pack_buf, fp4 ? 1 : 0, cur, c->n, c->s32, c->num_cu, c->stream, nullptr);
     if (e != hipSuccess) return hip_fail(c, e, "packed gram kernel launch");
   }
   c->gram_kind = fp4 ? 3 : 2;
   return PCOA_OK;
 }
 
-constexpr int kMaxSub = 64;
-
-// CU mask of the pre-pass stream: k CUs of every XCD (k = 4, 8, 12, ... 28).  The bit -> (XCD, CU) layout of the
-// mask is either "32 consecutive bits per XCD" or "bit i -> XCD i % 8"; the pattern below gives every XCD exactly k
-// CUs under both: whole groups of 8 consecutive bits inside each 32-bit word, plus (k % 8 == 4) four bits of the
-// next group at residues (word + 2t) % 8.
-void pack_cu_mask(int k, uint32_t mask[8]) {
-  for (int j = 0; j < 8; ++j) {
-    uint32_t m = 0;
-    for (int g = 0; g < k / 8; ++g) m |= 0xffu << (8 * g);
-    if (k % 8 >= 4)
-      for (int t = 0; t < 4; ++t) m |= 1u << (8 * (k / 8) + (j + 2 * t) % 8);
-    mask[j] = m;
-  }
-}
-
-int overlap_setup(pcoa_ctx* c) {
-  if (c->pack_stream) return PCOA_OK;
-  if (c->overlap == 2 && c->num_cu == 256) {
-    uint32_t mp[8], mg[8];
-    pack_cu_mask(c->pack_cus_per_xcd, mp);
-    for (int j = 0; j < 8; ++j) mg[j] = ~mp[j];
-    HIP_TRY(c, hipExtStreamCreateWithCUMask(&c->pack_stream, 8, mp));
-    HIP_TRY(c, hipExtStreamCreateWithCUMask(&c->gram_stream, 8, mg));
-    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-  } else {
-    int least = 0, greatest = 0;
-    HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
-    HIP_TRY(c, hipStreamCreateWithPriority(&c->pack_stream, hipStreamNonBlocking, least));
-  }
-  HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-  for (int b = 0; b < 2; ++b) {
-    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_packed[b], hipEventDisableTiming));
-    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_consumed[b], hipEventDisableTiming));
-  }
-  HIP_TRY(c, hipMalloc((void**)&c->sub_flags, sizeof(int32_t) * kMaxSub));
-  return PCOA_OK;
-}
-
-// Overlapped form of the packed path for a large dense tile resident on the device: sub-chunks of
-// c->sub_chunk variants, pre-pass(i+1) on the low-priority stream beside contraction(i) on the engine's stream,
-// two operand workspaces.  auto mode: the FP4 pre-pass raises sub_flags[i] on a non-binary value, the FP4
-// contraction of that sub-chunk then returns at once (device-side predicate, no host round trip inside the
-// pipeline) and the host re-runs the flagged sub-chunks on the int8 kernel after the group.
-int packed_overlapped(pcoa_ctx* c, const void* x, int is_u8, int64_t nv, int64_t ld) {
-  int rc = overlap_setup(c);
-  if (rc != PCOA_OK) return rc;
-  const int64_t sub = c->sub_chunk;
-  const int64_t need = (int64_t)gram_i8_workspace_bytes(c->n, sub);
-  if ((rc = ensure(c, &c->pack_buf, &c->pack_cap, need)) != PCOA_OK) return rc;
-  if ((rc = ensure(c, &c->pack_buf2, &c->pack_cap2, need)) != PCOA_OK) return rc;
-  int8_t* buf[2] = {c->pack_buf, c->pack_buf2};
-  const int64_t esz = is_u8 ? 1 : 4;
-  const char* xb = static_cast<const char*>(x);
-  const bool autom = c->packed_mode == 0;
-  hipStream_t gs = c->gram_stream ? c->gram_stream : c->stream;
-  const int gram_cus = c->gram_stream ? c->num_cu - 8 * c->pack_cus_per_xcd : c->num_cu;
-  for (int64_t g0 = 0; g0 < nv; g0 += sub * kMaxSub) {
-    const int64_t gn = std::min(nv - g0, sub * kMaxSub);
-    if ((rc = fold_if_needed(c, gn)) != PCOA_OK) return rc;
-    const int ns = (int)((gn + sub - 1) / sub);
-    if (autom) HIP_TRY(c, hipMemsetAsync(c->sub_flags, 0, sizeof(int32_t) * kMaxSub, c->stream));
-    HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
-    HIP_TRY(c, hipStreamWaitEvent(c->pack_stream, c->ev_fork, 0));
-    if (gs != c->stream) HIP_TRY(c, hipStreamWaitEvent(gs, c->ev_fork, 0));
-    for (int i = 0; i < ns; ++i) {
-      const int b = i & 1;
-      const int64_t v0 = g0 + (int64_t)i * sub;
-      const int64_t cur = std::min(sub, g0 + gn - v0);
-      const void* xi = xb + v0 * ld * esz;
-      if (i >= 2) HIP_TRY(c, hipStreamWaitEvent(c->pack_stream, c->ev_consumed[b], 0));
-      {
-        ScopedTimer t(c, T_PACK, c->pack_stream);
-        hipError_t e = launch_pack_fp4(xi, is_u8, ld, cur, c->n, buf[b], autom ? c->sub_flags + i : c->err_flag,
-                                       c->pack_stream);
-        if (e != hipSuccess) return hip_fail(c, e, "pack(fp4) kernel launch");
-      }
-      c->pack_launches += 1;
-      c->pack_bytes += (double)esz * (double)cur * (double)c->n + 0.5 * (double)gram_i8_workspace_bytes(c->n, cur);
-      HIP_TRY(c, hipEventRecord(c->ev_packed[b], c->pack_stream));
-      HIP_TRY(c, hipStreamWaitEvent(gs, c->ev_packed[b], 0));
-      {
-        ScopedTimer t(c, T_GRAM, gs);
-        hipError_t e = launch_gram_packed(buf[b], 1, cur, c->n, c->s32, gram_cus, gs, nullptr,
-                                          autom ? c->sub_flags + i : nullptr);
-        if (e != hipSuccess) return hip_fail(c, e, "packed gram kernel launch");
-      }
-      HIP_TRY(c, hipEventRecord(c->ev_consumed[b], gs));
-      c->gram_kind = 3;
-      account_gram(c, cur);
-    }
-    if (gs != c->stream) {
-      HIP_TRY(c, hipEventRecord(c->ev_join, gs));
-      HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-    }
-    if (autom) {
-      int32_t seen[kMaxSub];
-      HIP_TRY(c, hipMemcpyAsync(seen, c->sub_flags, sizeof(int32_t) * ns, hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(c, hipStreamSynchronize(c->stream));
-      for (int i = 0; i < ns; ++i) {
-        if (!seen[i]) continue;
-        const int64_t v0 = g0 + (int64_t)i * sub;
-        const int64_t cur = std::min(sub, g0 + gn - v0);
-        const void* xi = xb + v0 * ld * esz;
-        c->fp4_fallbacks += 1;
-        {
-          ScopedTimer t(c, T_PACK);
-          hipError_t e = is_u8 ? launch_pack_u8_i8(static_cast<const uint8_t*>(xi), ld, cur, c->n, buf[0], c->err_flag,
-                                                   c->stream)
-                               : launch_pack_f32_i8(static_cast<const float*>(xi), ld, cur, c->n, buf[0], c->err_flag,
-                                                    c->stream);
-          if (e != hipSuccess) return hip_fail(c, e, "pack(i8) kernel launch");
-        }
-        c->pack_launches += 1;
-        c->pack_bytes += (double)esz * (double)cur * (double)c->n + (double)gram_i8_workspace_bytes(c->n, cur);
-        {
-          ScopedTimer t(c, T_GRAM);
-          hipError_t e = launch_gram_packed(buf[0], 0, cur, c->n, c->s32, c->num_cu, c->stream, nullptr, nullptr);
-          if (e != hipSuccess) return hip_fail(c, e, "packed gram kernel launch");
-        }
-        c->gram_kind = 2;
-        c->gram_launches += 1;  // the variants were already counted for the skipped FP4 launch
-      }
-    }
-  }
-  return PCOA_OK;
-}
-
-bool use_overlap(const pcoa_ctx* c, int64_t nv) {
-  return c->overlap && c->use_i8 && c->packed_mode != 2 && nv >= 2 * c->sub_chunk && c->max_launch >= c->sub_chunk &&
-         c->pack_chunk >= c->sub_chunk;
-}
-
 // uint8 tile resident on the device (always a packed-operand path)
 int gram_device_u8(pcoa_ctx* c, const uint8_t* x_dev, int64_t nv, int64_t ld) {
-  if (use_overlap(c, nv)) return packed_overlapped(c, x_dev, 1, nv, ld);
   int64_t done = 0;
   const int64_t max_cur = std::min(c->max_launch, c->pack_chunk);
   while (done < nv) {
@@ -466,7 +318,6 @@ int gram_device_u8(pcoa_ctx* c, const uint8_t* x_dev, int64_t nv, int64_t ld) {
 
 // X tile already resident on the device: split into launches that keep fp32/int32 exact.
 int gram_device(pcoa_ctx* c, const float* x_dev, int64_t nv, int64_t ld) {
-  if (use_overlap(c, nv)) return packed_overlapped(c, x_dev, 0, nv, ld);
   int64_t done = 0;
   const int64_t max_cur = c->use_i8 ? std::min(c->max_launch, c->pack_chunk) : c->max_launch;
   while (done < nv) {
@@ -617,15 +468,6 @@ int pcoa_create(pcoa_ctx** out, int32_t n_samples, int32_t device_ordinal, uint3
     if (!std::strcmp(kk, "auto")) { c->use_i8 = true; c->packed_mode = 0; }
   }
   c->gram_kind = c->use_i8 ? (c->packed_mode == 2 ? 2 : 3) : 1;
-  if (const char* ov = std::getenv("PCOA_OVERLAP")) c->overlap = std::atoi(ov);
-  if (const char* pc = std::getenv("PCOA_PACK_CUS")) {
-    const int t = std::atoi(pc);
-    if (t >= 4 && t <= 28 && t % 4 == 0) c->pack_cus_per_xcd = t;
-  }
-  if (const char* sc = std::getenv("PCOA_SUB_CHUNK")) {
-    const long long t = std::atoll(sc);
-    if (t >= 1024) c->sub_chunk = t;
-  }
   {
     // keep the int8 workspace at or below ~4 GiB whatever N is (one byte per genotype, Npad columns)
     const int64_t by_mem = (((int64_t)4 << 30) / gram_i8_npad(n_samples)) / 1536 * 1536;
@@ -648,12 +490,8 @@ int pcoa_create(pcoa_ctx** out, int32_t n_samples, int32_t device_ordinal, uint3
   if ((e = hipGetDeviceProperties(&prop, device_ordinal)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   std::snprintf(c->dev_name, sizeof(c->dev_name), "%s (%s)", prop.name, prop.gcnArchName);
-  {
-    int least = 0, greatest = 0;  // the engine's stream outranks the pre-pass stream of the overlapped pipeline
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    if ((e = hipStreamCreateWithPriority(&c->own_stream, hipStreamNonBlocking, greatest)) != hipSuccess)
-      return bail(e, "hipStreamCreate");
-  }
+  if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess)
+    return bail(e, "hipStreamCreate");
   c->stream = c->own_stream;
   const size_t nn = (size_t)n_samples * (size_t)n_samples;
   if ((e = hipMalloc((void**)&c->s32, sizeof(int32_t) * nn)) != hipSuccess) return bail(e, "hipMalloc(S)");
@@ -670,21 +508,15 @@ int pcoa_create(pcoa_ctx** out, int32_t n_samples, int32_t device_ordinal, uint3
 void pcoa_destroy(pcoa_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->pack_stream) (void)hipStreamSynchronize(c->pack_stream);
-  if (c->gram_stream) (void)hipStreamSynchronize(c->gram_stream);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto& ev : c->pool) (void)hipEventDestroy(ev);
   void* bufs[] = {c->s32, c->s64, c->zeros, c->err_flag, c->tile, c->csr_idx, c->csr_offs, c->thr_dev,
-                  c->sample_pop, c->xfer, c->coll, c->fp4_flag, c->sub_flags, c->pack_buf, c->pack_buf2, c->lanczos_ws, c->ws.a, c->ws.d, c->ws.e, c->ws.tau, c->ws.q, c->ws.w, c->ws.lam,
+                  c->sample_pop, c->xfer, c->coll, c->fp4_flag, c->pack_buf, c->lanczos_ws, c->ws.a, c->ws.d, c->ws.e, c->ws.tau, c->ws.q, c->ws.w, c->ws.lam,
                   c->ws.z, c->ws.scratch, c->ws.iscratch, c->row_sums, c->stats, c->nz,
                   c->out_dev};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
-  if (c->pack_stream) (void)hipStreamDestroy(c->pack_stream);
-  if (c->gram_stream) (void)hipStreamDestroy(c->gram_stream);
-  for (hipEvent_t ev : {c->ev_join, c->ev_fork, c->ev_packed[0], c->ev_packed[1], c->ev_consumed[0], c->ev_consumed[1]})
-    if (ev) (void)hipEventDestroy(ev);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }

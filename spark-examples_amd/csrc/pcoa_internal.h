@@ -44,7 +44,7 @@ int64_t gram_kb_pad(int64_t nv, int fmt);
 hipError_t launch_pack_fp4(const void* x, int is_u8, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
                            hipStream_t stream);
 hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, int32_t* s32, int num_cu,
-                              hipStream_t stream, int* splitk_out, const int32_t* skip_flag_dev);
+                              hipStream_t stream, int* splitk_out);
 hipError_t launch_gram_i8_packed(const int8_t* p, int64_t nv, int32_t n, int32_t* s32, int num_cu,
                                  hipStream_t stream, int* splitk_out);
 

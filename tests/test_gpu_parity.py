@@ -212,40 +212,6 @@ def test_auto_mode_picks_fp4_per_chunk_and_falls_back_to_int8_on_multiplicities(
         assert t["fp4_fallbacks"] == 0 and t["gram_kernel_kind"] == 3
 
 
-def test_overlapped_pipeline_is_exact_and_recovers_from_multiplicities(P, O):
-    """PCOA_OVERLAP=1: pre-pass(i+1) on a second stream beside contraction(i); the FP4 contraction of a
-    sub-chunk whose pre-pass saw a multiplicity is predicated off on the device and the host re-runs that
-    sub-chunk on the int8 kernel.  Same integers as the serial path, fp32 and uint8 boundaries."""
-    rng = np.random.default_rng(78)
-    n, v = 333, 7000
-    x = (rng.random((v, n)) < 0.3).astype(np.float32)
-    want_bin = O.similarity_from_dense(x, n)
-    xm = x.copy()
-    xm[3100, 5] = 2.0
-    xm[6999, 9] = 100.0
-    want_mul = (xm.T.astype(np.int64) @ xm.astype(np.int64))
-    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r);"
-            "from conftest import load_pkg; P = load_pkg(); x = np.load(sys.argv[1]); import torch;"
-            "e = P.PcoaEngine(x.shape[1]);"
-            "xd = torch.from_numpy(x).cuda();"
-            "e.accumulate_dense(xd); s = e.gram(); t = e.timings(); e.reset();"
-            "e.accumulate_dense_u8(xd.to(torch.uint8)); s8 = e.gram();"
-            "np.save(sys.argv[2], np.stack([s, s8])); print(json.dumps([t['fp4_fallbacks'], t['pack_launches']]))"
-            ) % (ROOT, os.path.join(ROOT, "tests"))
-    import json
-    import tempfile
-    with tempfile.TemporaryDirectory() as td:
-        env = dict(os.environ, PCOA_OVERLAP="1", PCOA_SUB_CHUNK="1024")
-        for name, arr, want, nfall in (("bin", x, want_bin, 0), ("mul", xm, want_mul, 2)):
-            np.save(os.path.join(td, name + ".npy"), arr)
-            out = subprocess.check_output([sys.executable, "-c", code, os.path.join(td, name + ".npy"),
-                                           os.path.join(td, "s.npy")], env=env)
-            fallbacks, packs = json.loads(out.decode().strip().splitlines()[-1])
-            got = np.load(os.path.join(td, "s.npy"))
-            assert np.array_equal(got[0], want) and np.array_equal(got[1], want), name
-            assert fallbacks == nfall and packs == 7 + nfall, (name, fallbacks, packs)
-
-
 def test_empty_and_ragged_inputs(P):
     with P.PcoaEngine(7) as eng:
         eng.accumulate_calls(np.zeros(0, dtype=np.int32), np.zeros(1, dtype=np.int64))       # no variants
