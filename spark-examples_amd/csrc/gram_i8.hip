@@ -415,6 +415,117 @@ __device__ __forceinline__ void ring_round(StageI8<NWM, SKB>* lds, const int8_t*
    ...);
 }
 
+// ---- ping-pong schedule (PP = true) -------------------------------------------------------------------------
+// The plain ring above keeps all eight waves in phase: after every barrier they all read fragments, then all
+// issue MFMAs, and the matrix pipe idles during the read burst (53-64 % MFMA-busy measured).  Here the waves
+// form two groups, one wave of each group per SIMD (waves w and w+4 share a SIMD), half a stage apart:
+//
+//   phase 2s   : group 0 reads the fragments of stage s (12 ds_read_b128)  | group 1 issues the MFMAs of stage s-1
+//   phase 2s+1 : group 0 issues the 16 MFMAs of stage s                    | group 1 reads the fragments of stage s
+//
+// with one raw s_barrier after every phase, so the matrix pipe of every SIMD always has one wave feeding it while
+// the other wave's LDS reads are in flight.  Buffer of stage s is read in phases 2s (group 0) and 2s+1 (group 1) and
+// is free after the barrier that ends phase 2s+1; the DMA of stage s+NST-1 into the buffer of stage s-1 is issued by
+// both groups at the start of phase 2s and has until the barrier that ends phase 2(s+NST-1)-1 to land (counted
+// vmcnt: only the following stage's DMA may still be in flight there).
+__device__ __forceinline__ void raw_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int FMT, int NWM, int NNI, int SKB, int NST, int BUF, int GRP, bool IDLE>
+__device__ __forceinline__ void pp_stage(StageI8<NWM, SKB>* lds, const int8_t* __restrict__ p, int npad,
+                                         int64_t kb_begin, int s, int ns, int col_i, int col_j, int wave, int lane,
+                                         int wm, int wn, typename AccType<FMT>::type (&acc)[4][NNI],
+                                         FragsI8<NNI> (&f)[SKB / 2]) {
+  constexpr int NWAVES = NWM * (8 / NNI);
+  constexpr int PER_WAVE = SKB * (2 * NWM + 4) / NWAVES;
+  constexpr int D = NST - 1;
+  static_assert(D >= 1 && D * PER_WAVE < 64, "vmcnt is a 6-bit counter");
+  const bool more = s + D < ns;  // a DMA is issued during this stage
+  if constexpr (GRP == 0) {
+    // ---- phase 2s: read stage s, issue the DMA of stage s+D
+    if constexpr (!IDLE) {
+#pragma unroll
+      for (int k2 = 0; k2 < SKB / 2; ++k2) load_frags_i8<NWM, NNI, SKB>(&lds[BUF], k2, wm, wn, lane, f[k2]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more)
+      issue_stage_i8<NWM, SKB, NWAVES>(&lds[(BUF + D) % NST], p, npad, kb_begin + (int64_t)(s + D) * SKB, col_i, col_j,
+                                       wave, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    raw_barrier();
+    // ---- phase 2s+1: the MFMAs of stage s
+    if constexpr (!IDLE) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int k2 = 0; k2 < SKB / 2; ++k2) mfma_step_i8<FMT, NNI>(f[k2], acc);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  } else {
+    // ---- phase 2s: issue the DMA of stage s+D, then the MFMAs of stage s-1
+    if (more)
+      issue_stage_i8<NWM, SKB, NWAVES>(&lds[(BUF + D) % NST], p, npad, kb_begin + (int64_t)(s + D) * SKB, col_i, col_j,
+                                       wave, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!IDLE) {
+      if (s > 0) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int k2 = 0; k2 < SKB / 2; ++k2) mfma_step_i8<FMT, NNI>(f[k2], acc);
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+    raw_barrier();
+    // ---- phase 2s+1: read stage s
+    if constexpr (!IDLE) {
+#pragma unroll
+      for (int k2 = 0; k2 < SKB / 2; ++k2) load_frags_i8<NWM, NNI, SKB>(&lds[BUF], k2, wm, wn, lane, f[k2]);
+    }
+  }
+  // end of phase 2s+1: stage s+1 must have landed (own share), only the DMA of stage s+2.. may stay in flight
+  if (s + 1 < ns) {
+    const int rem = ns - 2 - s;  // stages after s+1 whose DMA has been issued: min(rem, D-1)
+    const int keep = rem < D - 1 ? rem : D - 1;
+    if (keep >= 2) wait_vmcnt<(D >= 3 ? 2 * PER_WAVE : 0)>();
+    else if (keep == 1) wait_vmcnt<(D >= 2 ? PER_WAVE : 0)>();
+    else wait_vmcnt<0>();
+  }
+  if constexpr (GRP == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  raw_barrier();
+}
+
+template <int FMT, int NWM, int NNI, int SKB, int NST, int GRP, bool IDLE, int... Is>
+__device__ __forceinline__ void pp_round(StageI8<NWM, SKB>* lds, const int8_t* __restrict__ p, int npad,
+                                         int64_t kb_begin, int s, int ns, int count, int col_i, int col_j, int wave,
+                                         int lane, int wm, int wn, typename AccType<FMT>::type (&acc)[4][NNI],
+                                         FragsI8<NNI> (&f)[SKB / 2], std::integer_sequence<int, Is...>) {
+  ((Is < count ? pp_stage<FMT, NWM, NNI, SKB, NST, Is, GRP, IDLE>(lds, p, npad, kb_begin, s + Is, ns, col_i, col_j, wave,
+                                                                  lane, wm, wn, acc, f)
+               : (void)0),
+   ...);
+}
+
+template <int FMT, int NWM, int NNI, int SKB, int NST, int GRP, bool IDLE>
+__device__ __forceinline__ void pp_loop(StageI8<NWM, SKB>* lds, const int8_t* __restrict__ p, int npad,
+                                        int64_t kb_begin, int ns, int col_i, int col_j, int wave, int lane, int wm,
+                                        int wn, typename AccType<FMT>::type (&acc)[4][NNI]) {
+  FragsI8<NNI> f[SKB / 2];
+  int s = 0;
+  for (; s + NST - 1 < ns; s += NST)
+    pp_round<FMT, NWM, NNI, SKB, NST, GRP, IDLE>(lds, p, npad, kb_begin, s, ns, NST, col_i, col_j, wave, lane, wm, wn, acc,
+                                                 f, std::make_integer_sequence<int, NST>{});
+  if (s < ns)
+    pp_round<FMT, NWM, NNI, SKB, NST, GRP, IDLE>(lds, p, npad, kb_begin, s, ns, ns - s, col_i, col_j, wave, lane, wm, wn,
+                                                 acc, f, std::make_integer_sequence<int, NST - 1>{});
+  if constexpr (GRP == 1 && !IDLE) {  // phase 2*ns: group 1's MFMAs of the last stage, nobody to wait for
+#pragma unroll
+    for (int k2 = 0; k2 < SKB / 2; ++k2) mfma_step_i8<FMT, NNI>(f[k2], acc);
+  }
+}
+
 // Tile enumeration over the upper triangle (any bijection is valid: every tile is computed once).
 //   NWM = 2: tiles (ti <= tj) of 256 x 256, visited in BANDS of 16 tile rows; inside a band the order is
 //            column by column.  Workgroups that run at the same time (~256 consecutive indices) then
@@ -472,7 +583,7 @@ __device__ __forceinline__ void tile_coords(int tile, int ntile, int& row_blk, i
   }
 }
 
-template <int FMT, int NWM, int NNI, int SKB, int NST>
+template <int FMT, int NWM, int NNI, int SKB, int NST, bool PP>
 __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram_i8_kernel(
     const int8_t* __restrict__ p, int npad, int64_t nstages, int n, int ntile, int ntri, int splitk,
     int64_t stages_per, int32_t* __restrict__ s32, int xcd_map) {
@@ -518,6 +629,21 @@ __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram
   // prologue: stages 0 .. D-1 go in flight
   ring_prologue<NWM, SKB, NST, NWAVES>(lds, p, npad, kb_begin, ns, col_i, col_j, wave, lane,
                                       std::make_integer_sequence<int, NST - 1>{});
+  if constexpr (PP) {
+    static_assert(!PP || (NWM == 2 && NNI == 2), "ping-pong: 8 waves, group = wave / 4 = wm");
+    // stage 0 must have landed before group 0 reads it in phase 0
+    if (ns > 1 && NST > 2) wait_vmcnt<(NST > 2 ? SKB * (2 * NWM + 4) / NWAVES : 0)>();
+    else wait_vmcnt<0>();
+    raw_barrier();
+    if (wm == 0) {
+      pp_loop<FMT, NWM, NNI, SKB, NST, 0, false>(lds, p, npad, kb_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
+    } else if (idle) {
+      pp_loop<FMT, NWM, NNI, SKB, NST, 1, true>(lds, p, npad, kb_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
+      return;
+    } else {
+      pp_loop<FMT, NWM, NNI, SKB, NST, 1, false>(lds, p, npad, kb_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
+    }
+  } else {
   int s = 0;
   if (idle) {  // wave-uniform: a separate loop with no accumulator traffic at all, then nothing to store
     for (; s + NST - 1 < ns; s += NST)
@@ -534,6 +660,7 @@ __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram
   if (s < ns)
     ring_round<FMT, NWM, NNI, SKB, NST, false>(lds, p, npad, kb_begin, s, ns, ns - s, col_i, col_j, wave, lane, wm, wn,
                                           acc, std::make_integer_sequence<int, NST - 1>{});
+  }
 
   if constexpr (FMT == 1) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last asm MFMA -> VALU read of D
   // epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
@@ -652,9 +779,9 @@ hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, i
   static const int cfg = [] {
     const char* v = std::getenv("PCOA_GRAM_I8_CFG");
     const int t = v ? std::atoi(v) : 43;
-    return t == 44 ? 44 : 43;  // the deeper / shallower stage variants of DESIGN.md's table were all slower
+    return (t == 44 || t == 143 || t == 144) ? t : 43;  // 1xx = ping-pong schedule
   }();
-  const int skb = cfg / 10;
+  const int skb = (cfg % 100) / 10;
   const int npad = (int)gram_i8_npad(n);
   const int ntile = npad / TJ;
   const int64_t ntri64 = (int64_t)ntile * (ntile + 1) / 2;
@@ -681,18 +808,20 @@ hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, i
   if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
   if (splitk_out) *splitk_out = (int)splitk;
   const dim3 grid((unsigned)nblocks), block(512);
-#define PCOA_LAUNCH_I8(SKB_, NST_)                                                                              \
+#define PCOA_LAUNCH_I8(SKB_, NST_, PP_)                                                                            \
   do {                                                                                                          \
     if (fmt == 1)                                                                                               \
-      hipLaunchKernelGGL((gram_i8_kernel<1, 2, 2, SKB_, NST_>), grid, block, 0, stream, p, npad, nstages, n, ntile, \
+      hipLaunchKernelGGL((gram_i8_kernel<1, 2, 2, SKB_, NST_, PP_>), grid, block, 0, stream, p, npad, nstages, n, ntile, \
                          ntri, (int)splitk, stages_per, s32, xcd_map);                                          \
     else                                                                                                        \
-      hipLaunchKernelGGL((gram_i8_kernel<0, 2, 2, SKB_, NST_>), grid, block, 0, stream, p, npad, nstages, n, ntile, \
+      hipLaunchKernelGGL((gram_i8_kernel<0, 2, 2, SKB_, NST_, PP_>), grid, block, 0, stream, p, npad, nstages, n, ntile, \
                          ntri, (int)splitk, stages_per, s32, xcd_map);                                          \
   } while (0)
   switch (cfg) {
-    case 44: PCOA_LAUNCH_I8(4, 4); break;
-    default: PCOA_LAUNCH_I8(4, 3); break;
+    case 44: PCOA_LAUNCH_I8(4, 4, false); break;
+    case 143: PCOA_LAUNCH_I8(4, 3, true); break;
+    case 144: PCOA_LAUNCH_I8(4, 4, true); break;
+    default: PCOA_LAUNCH_I8(4, 3, false); break;
   }
 #undef PCOA_LAUNCH_I8
   return hipGetLastError();
