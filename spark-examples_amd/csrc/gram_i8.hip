@@ -425,9 +425,10 @@ __device__ __forceinline__ void ring_round(StageI8<NWM, SKB>* lds, const int8_t*
 //
 // with one raw s_barrier after every phase, so the matrix pipe of every SIMD always has one wave feeding it while
 // the other wave's LDS reads are in flight.  Buffer of stage s is read in phases 2s (group 0) and 2s+1 (group 1) and
-// is free after the barrier that ends phase 2s+1; the DMA of stage s+NST-1 into the buffer of stage s-1 is issued in
-// each group's READ phase (2s for group 0, 2s+1 for group 1 -- never beside a group's own MFMAs) and has until the
-// barrier that ends phase 2(s+NST-1)-1 to land (counted vmcnt: only later stages' DMA may still be in flight there).
+// is free after the barrier that ends phase 2s+1; the DMA of stage s+NST-1 into the buffer of stage s-1 is issued by
+// both groups at the start of phase 2s and has until the barrier that ends phase 2(s+NST-1)-1 to land (counted
+// vmcnt: only the following stage's DMA may still be in flight there).  (Moving group 1's DMA issue out of its
+// MFMA phase into its read phase was measured 2 % slower: 1.265 vs 1.237 ms per 10^6 variants, commit 4f657f1.)
 __device__ __forceinline__ void raw_barrier() {
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
@@ -465,8 +466,11 @@ __device__ __forceinline__ void pp_stage(StageI8<NWM, SKB>* lds, const int8_t* _
       __builtin_amdgcn_s_setprio(0);
     }
   } else {
-    // ---- phase 2s: the MFMAs of stage s-1 (nothing else: one LDS-DMA instruction costs 60+ issue cycles,
-    // MI355X_MICROARCH.md, and would delay the whole phase; this group's DMA goes into its read phase below)
+    // ---- phase 2s: issue the DMA of stage s+D, then the MFMAs of stage s-1
+    if (more)
+      issue_stage_i8<NWM, SKB, NWAVES>(&lds[(BUF + D) % NST], p, npad, kb_begin + (int64_t)(s + D) * SKB, col_i, col_j,
+                                       wave, lane);
+    __builtin_amdgcn_sched_barrier(0);
     if constexpr (!IDLE) {
       if (s > 0) {
         __builtin_amdgcn_s_setprio(1);
@@ -476,15 +480,11 @@ __device__ __forceinline__ void pp_stage(StageI8<NWM, SKB>* lds, const int8_t* _
       }
     }
     raw_barrier();
-    // ---- phase 2s+1: read stage s, issue the DMA of stage s+D (its buffer was free one phase ago)
+    // ---- phase 2s+1: read stage s
     if constexpr (!IDLE) {
 #pragma unroll
       for (int k2 = 0; k2 < SKB / 2; ++k2) load_frags_i8<NWM, NNI, SKB>(&lds[BUF], k2, wm, wn, lane, f[k2]);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    if (more)
-      issue_stage_i8<NWM, SKB, NWAVES>(&lds[(BUF + D) % NST], p, npad, kb_begin + (int64_t)(s + D) * SKB, col_i, col_j,
-                                       wave, lane);
   }
   // end of phase 2s+1: stage s+1 must have landed (own share), only the DMA of stage s+2.. may stay in flight
   if (s + 1 < ns) {
@@ -776,11 +776,11 @@ hipError_t launch_gram_i8_packed(const int8_t* p, int64_t nv, int32_t n, int32_t
 hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, int32_t* s32, int num_cu,
                               hipStream_t stream, int* splitk_out) {
   if (nv <= 0) return hipSuccess;
-  // PCOA_GRAM_I8_CFG = <k-blocks per stage><ring length>: 43 (default) or 44
+  // PCOA_GRAM_I8_CFG = [1]<k-blocks per stage><ring length>: 143 (default, ping-pong), 144, 43 / 44 (in-phase ring)
   static const int cfg = [] {
     const char* v = std::getenv("PCOA_GRAM_I8_CFG");
-    const int t = v ? std::atoi(v) : 43;
-    return (t == 44 || t == 143 || t == 144) ? t : 43;  // 1xx = ping-pong schedule
+    const int t = v ? std::atoi(v) : 143;
+    return (t == 43 || t == 44 || t == 144) ? t : 143;  // 1xx = ping-pong schedule (default), xx = in-phase ring
   }();
   const int skb = (cfg % 100) / 10;
   const int npad = (int)gram_i8_npad(n);
@@ -820,9 +820,9 @@ hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, i
   } while (0)
   switch (cfg) {
     case 44: PCOA_LAUNCH_I8(4, 4, false); break;
-    case 143: PCOA_LAUNCH_I8(4, 3, true); break;
     case 144: PCOA_LAUNCH_I8(4, 4, true); break;
-    default: PCOA_LAUNCH_I8(4, 3, false); break;
+    case 43: PCOA_LAUNCH_I8(4, 3, false); break;
+    default: PCOA_LAUNCH_I8(4, 3, true); break;
   }
 #undef PCOA_LAUNCH_I8
   return hipGetLastError();
