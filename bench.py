@@ -300,6 +300,36 @@ def main():
                                    "note": "same cohort handed over as uint8 [V][N] (pcoa_accumulate_dense_u8); "
                                            "not the BASELINE configs[1] fp32 boundary, reported for reference"}
             del x8
+            # the bit-packed boundary (1 bit per genotype, 313 B per variant): expand to FP4 + the same contraction
+            words = (n + 31) // 32
+            bits = torch.empty((v, words), dtype=torch.int32, device=dev)
+            wts = (1 << torch.arange(32, device=dev, dtype=torch.int64))
+            for r0 in range(0, v, 1 << 16):
+                xb = torch.nn.functional.pad(x[r0:r0 + (1 << 16)] > 0, (0, words * 32 - n))
+                val = (xb.view(-1, words, 32).to(torch.int64) * wts).sum(dim=2)
+                bits[r0:r0 + val.shape[0]] = torch.where(val >= 2 ** 31, val - 2 ** 32, val).to(torch.int32)
+            del xb, val
+            torch.cuda.synchronize(dev)
+            s_dense = eng.gram()
+            eng.reset()
+            for _ in range(2):
+                eng.accumulate_bits(bits)
+            eng.finalize(); eng.sync()
+            eng.reset(); eng.reset_timings(); eng.sync()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                eng.accumulate_bits(bits)
+            eng.finalize(); eng.sync()
+            dtb = time.perf_counter() - t1
+            tb = eng.timings()
+            out["alt_input_bits"] = {"value": v * steps / dtb, "unit": "variants/s", "ms_per_step": 1e3 * dtb / steps,
+                                     "expand_ms_per_step": 1e3 * tb["pack_seconds"] / steps,
+                                     "gram_ms_per_step": 1e3 * tb["gram_kernel_seconds"] / steps,
+                                     "bytes_per_variant": 4 * words,
+                                     "same_gram_as_dense_input": bool(np.array_equal(eng.gram(), s_dense)),
+                                     "note": "same cohort as carrier bitsets [V][ceil(N/32)] uint32 "
+                                             "(pcoa_accumulate_bits, SURVEY 8d '1-bit-packed twin'); reported separately"}
+            del bits
         if world == 1 and not args.no_extras:
             # BASELINE configs[0] stand-in: BRCA1-sized region (2,500 variants) through the faithful CSR boundary
             # (pcoa_accumulate_calls, host arrays), end to end: H2D + densify + Gram + finalize + PCoA + D2H

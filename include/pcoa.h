@@ -149,6 +149,17 @@ int pcoa_accumulate_dense_f32(pcoa_ctx* ctx, const float* x, int64_t n_variants,
  * Gram path").  Always runs the i8-MFMA kernel.  Host or device pointer as above. */
 int pcoa_accumulate_dense_u8(pcoa_ctx* ctx, const uint8_t* x, int64_t n_variants, int64_t ld, int is_device_ptr);
 
+/* Bit-packed variants x samples tile: row v is the carrier BITSET of variant v, 1 bit per genotype; sample i is
+ * bit (i & 31) of the little-endian word bits[v * ld_words + (i >> 5)], ld_words >= ceil(N / 32); bits of samples
+ * >= N are ignored.  313 B per variant at N = 2504 (32x less than the fp32 tile: BASELINE configs[2]'s 40 M variants
+ * are 12.5 GB).  Host or device pointer.  A bitset cannot repeat a callset, so the tile is binary by construction and
+ * always runs on the MX-FP4 kernel (not available with PCOA_FLAG_GRAM_F32_MFMA).
+ * Replaces: the same RDD[Seq[Int]] rows as pcoa_accumulate_calls (getCallsRdd, VariantsPca.scala:153-168; the
+ * hasVariation indicator of extractCallInfo, :56-60), one bit per (variant, callset) instead of a list of indices;
+ * SURVEY 8(d) "1-bit-packed twin", 8(f) rank 2. */
+int pcoa_accumulate_bits(pcoa_ctx* ctx, const uint32_t* bits, int64_t n_variants, int64_t ld_words,
+                         int is_device_ptr);
+
 /* Generates variants [first_variant, first_variant + n_variants) of the synthetic model directly
  * in HBM and accumulates them (no host tile).  params->thresholds covers exactly that range. */
 int pcoa_accumulate_synthetic(pcoa_ctx* ctx, const pcoa_synth_params* params, int64_t first_variant,

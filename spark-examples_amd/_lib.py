@@ -81,6 +81,7 @@ _SIGNATURES = [
     ("pcoa_accumulate_calls", ctypes.c_int, [_vp, _vp, _vp, _i64]),
     ("pcoa_accumulate_dense_f32", ctypes.c_int, [_vp, _vp, _i64, _i64, ctypes.c_int]),
     ("pcoa_accumulate_dense_u8", ctypes.c_int, [_vp, _vp, _i64, _i64, ctypes.c_int]),
+    ("pcoa_accumulate_bits", ctypes.c_int, [_vp, _vp, _i64, _i64, ctypes.c_int]),
     ("pcoa_accumulate_synthetic", ctypes.c_int, [_vp, ctypes.POINTER(PcoaSynthParams), _i64, _i64]),
     ("pcoa_synth_fill_f32", ctypes.c_int, [_vp, ctypes.POINTER(PcoaSynthParams), _i64, _i64, _vp, _i64]),
     ("pcoa_gram_finalize", ctypes.c_int, [_vp]),

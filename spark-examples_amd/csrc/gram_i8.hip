@@ -257,6 +257,56 @@ __global__ __launch_bounds__(256) void pack_fp4_kernel(const T* __restrict__ x, 
   if (bad) atomicOr(flag, 8);
 }
 
+// ---- bit-packed boundary: carrier bitsets (1 bit per genotype, row v = variant v, bit i & 31 of word i >> 5 =
+// sample i) -> P4.  One wave per (k-block of 32 variants, 64 samples): the 64 bits of a row that belong to the wave's
+// samples are a wave-uniform pair of dwords (scalar loads) and, held in an SGPR pair, they ARE a lane mask:
+// v_cndmask_b32 with that pair as condition hands every lane its own sample's bit as a positioned FP4 nibble in one
+// instruction.  2 VALU ops per row, one coalesced 16-B store per lane (1 KiB per wave).  A bitset cannot repeat a
+// callset, so the tile is binary by construction and always takes the FP4 kernel.
+__global__ __launch_bounds__(256) void expand_bits_fp4_kernel(const uint32_t* __restrict__ bits, int64_t ld_words,
+                                                              int64_t nv, int n, int npad, int64_t nkb_pad,
+                                                              int8_t* __restrict__ p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int groups = npad >> 6;                               // 64-sample groups per k-block (multiple of 4)
+  const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t kb = wid / groups;
+  const int g = (int)(wid - kb * groups);
+  if (kb >= nkb_pad) return;
+  const int live = n - 64 * g;                                // samples of this group that exist (may be <= 0)
+  const uint64_t live_mask = live >= 64 ? ~0ull : (live <= 0 ? 0ull : ((1ull << live) - 1ull));
+  // dword indices clamped into the row so that every load is legal; what must not count is masked off instead
+  // (no branches: the 64 scalar loads of a wave go out back to back)
+  const int64_t last = ld_words - 1;
+  const int64_t w0 = (2 * g < last) ? 2 * g : last;
+  const bool has_hi = 2 * g + 1 <= last;
+  const int64_t w1 = has_hi ? 2 * g + 1 : last;
+  const uint64_t hi_mask = has_hi ? ~0ull : 0xffffffffull;
+  uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {  // two batches of 16 rows: 32 scalar loads in flight, then 16 selects
+    uint64_t m[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int64_t row = kb * 32 + h * 16 + t;
+      const uint32_t* r = bits + (row < nv ? row : nv - 1) * ld_words;  // wave-uniform address: scalar loads
+      m[t] = (((uint64_t)r[w1] << 32) | r[w0]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int64_t row = kb * 32 + h * 16 + t;
+      const uint64_t mm = (m[t] & hi_mask & live_mask) & (row < nv ? ~0ull : 0ull);
+      uint32_t nib;
+      const uint32_t one = 2u << (4 * (t & 7));               // E2M1 1.0 at this variant's nibble
+      asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(nib) : "v"(one), "s"(mm));
+      w[h * 2 + (t >> 3)] |= nib;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  *reinterpret_cast<uint4*>(p + ((size_t)kb * npad + (size_t)64 * g + lane) * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 // ---------------------------------------------------------------------------------------------- gemm
 // Template parameters
 //   NWM  waves along M (tile height 128*NWM); NNI 32-column MFMA tiles per wave along N (wave tile
@@ -720,6 +770,18 @@ hipError_t launch_pack_fp4(const void* x, int is_u8, int64_t ld, int64_t nv, int
     if (vec) hipLaunchKernelGGL((pack_fp4_kernel<float, 4>), grid, block, 0, stream, xs, ld, nv, n, npad, nkb_pad, p, flag);
     else hipLaunchKernelGGL((pack_fp4_kernel<float, 1>), grid, block, 0, stream, xs, ld, nv, n, npad, nkb_pad, p, flag);
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_expand_bits_fp4(const uint32_t* bits, int64_t ld_words, int64_t nv, int32_t n, int8_t* p,
+                                  hipStream_t stream) {
+  if (nv <= 0) return hipSuccess;
+  const int npad = (int)gram_i8_npad(n);
+  const int64_t nkb_pad = gram_kb_pad(nv, 1);
+  const int64_t blocks = nkb_pad * (npad >> 6) / 4;  // npad is a multiple of 256: 4 waves = 4 sample groups of one k-block
+  if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(expand_bits_fp4_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, bits, ld_words, nv, n, npad,
+                     nkb_pad, p);
   return hipGetLastError();
 }
 

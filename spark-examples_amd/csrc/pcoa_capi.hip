@@ -598,6 +598,64 @@ int pcoa_accumulate_dense_u8(pcoa_ctx* c, const uint8_t* x, int64_t n_variants, 
   return PCOA_OK;
 }
 
+namespace {
+// bit-packed tile resident on the device -> FP4 operand -> FP4 contraction
+int gram_device_bits(pcoa_ctx* c, const uint32_t* bits_dev, int64_t nv, int64_t ld_words) {
+  int64_t done = 0;
+  const int64_t max_cur = std::min(c->max_launch, c->pack_chunk);
+  while (done < nv) {
+    const int64_t cur = std::min(nv - done, max_cur);
+    int rc = fold_if_needed(c, cur);
+    if (rc != PCOA_OK) return rc;
+    const int64_t need = (int64_t)gram_i8_workspace_bytes(c->n, cur);
+    rc = ensure(c, &c->pack_buf, &c->pack_cap, need);
+    if (rc != PCOA_OK) return rc;
+    {
+      ScopedTimer t(c, T_PACK);
+      hipError_t e = launch_expand_bits_fp4(bits_dev + done * ld_words, ld_words, cur, c->n, c->pack_buf, c->stream);
+      if (e != hipSuccess) return hip_fail(c, e, "expand(bits) kernel launch");
+    }
+    c->pack_launches += 1;
+    c->pack_bytes += 4.0 * (double)((c->n + 31) / 32) * (double)cur + 0.5 * (double)need;
+    {
+      ScopedTimer t(c, T_GRAM);
+      hipError_t e = launch_gram_packed(c->pack_buf, 1, cur, c->n, c->s32, c->num_cu, c->stream, nullptr);
+      if (e != hipSuccess) return hip_fail(c, e, "packed gram kernel launch");
+    }
+    c->gram_kind = 3;
+    account_gram(c, cur);
+    done += cur;
+  }
+  return PCOA_OK;
+}
+}  // namespace
+
+int pcoa_accumulate_bits(pcoa_ctx* c, const uint32_t* bits, int64_t n_variants, int64_t ld_words, int is_device_ptr) {
+  CHECK_CTX(c);
+  if (n_variants < 0 || (n_variants > 0 && !bits))
+    return fail(c, PCOA_ERR_INVALID_ARG, "bits is NULL or n_variants < 0");
+  const int64_t need_words = ((int64_t)c->n + 31) / 32;
+  if (ld_words < need_words) return fail(c, PCOA_ERR_INVALID_ARG, "ld_words must be >= ceil(n_samples / 32)");
+  if (!c->use_i8)
+    return fail(c, PCOA_ERR_INVALID_ARG, "the bit-packed boundary needs a packed-operand engine (not PCOA_FLAG_GRAM_F32_MFMA)");
+  if (n_variants == 0) return PCOA_OK;
+  if (is_device_ptr) return gram_device_bits(c, bits, n_variants, ld_words);
+  // host bitsets: staged densely (ceil(N/32) words per row) through the tile buffer, at most 256 MiB at a time
+  const int64_t rows_cap = std::max<int64_t>(1, std::min<int64_t>(n_variants, ((int64_t)64 << 20) / need_words));
+  int rc = ensure(c, &c->tile, &c->tile_elems, rows_cap * need_words);
+  if (rc != PCOA_OK) return rc;
+  uint32_t* stage = reinterpret_cast<uint32_t*>(c->tile);
+  for (int64_t v0 = 0; v0 < n_variants; v0 += rows_cap) {
+    const int64_t rows = std::min(rows_cap, n_variants - v0);
+    HIP_TRY(c, hipMemcpy2DAsync(stage, (size_t)need_words * 4, bits + v0 * ld_words, (size_t)ld_words * 4,
+                                (size_t)need_words * 4, (size_t)rows, hipMemcpyHostToDevice, c->stream));
+    rc = gram_device_bits(c, stage, rows, need_words);
+    if (rc != PCOA_OK) return rc;
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return PCOA_OK;
+}
+
 int pcoa_accumulate_calls(pcoa_ctx* c, const int32_t* sample_idx, const int64_t* row_offsets, int64_t n_variants) {
   CHECK_CTX(c);
   if (n_variants < 0 || !row_offsets) return fail(c, PCOA_ERR_INVALID_ARG, "row_offsets is NULL or n_variants < 0");

@@ -155,6 +155,25 @@ class PcoaEngine(object):
         ldv = a.shape[1] if ld is None else int(ld)
         self._check(self._lib.pcoa_accumulate_dense_u8(self._ctx, _ptr(a), nv, ldv, 0))
 
+    def accumulate_bits(self, bits, n_variants=None, ld_words=None):
+        """Bit-packed tile: row v = carrier bitset of variant v, sample i = bit (i & 31) of word i >> 5
+        (`ingest.pack_bits` builds it).  numpy uint32 [V][W] (host) or a torch int32 CUDA tensor (read in place)."""
+        if hasattr(bits, "data_ptr") and getattr(bits, "is_cuda", False):
+            import torch  # plumbing only
+            assert bits.dtype == torch.int32 and bits.dim() == 2 and bits.stride(1) == 1
+            nv = int(bits.shape[0]) if n_variants is None else int(n_variants)
+            ldv = int(bits.stride(0)) if ld_words is None else int(ld_words)
+            self._keepalive.append(bits)
+            torch.cuda.current_stream(bits.device).synchronize()  # see accumulate_dense
+            self._check(self._lib.pcoa_accumulate_bits(self._ctx, ctypes.c_void_p(bits.data_ptr()), nv, ldv, 1))
+            return
+        a = np.ascontiguousarray(bits, dtype=np.uint32)
+        if a.ndim != 2:
+            raise ValueError("bits must be 2-D [variants][words]")
+        nv = a.shape[0] if n_variants is None else int(n_variants)
+        ldv = a.shape[1] if ld_words is None else int(ld_words)
+        self._check(self._lib.pcoa_accumulate_bits(self._ctx, _ptr(a), nv, ldv, 0))
+
     def accumulate_dense_device_ptr(self, ptr, n_variants, ld):
         self._check(self._lib.pcoa_accumulate_dense_f32(self._ctx, ctypes.c_void_p(int(ptr)), int(n_variants),
                                                         int(ld), 1))

@@ -166,3 +166,16 @@ def synthetic_dataset(spec):
         names[cid] = "S%06d" % i
     indexes = dict((cid, i) for i, cid in enumerate(ids))
     return indexes, names, [("csr", idx, offs)]
+
+
+def pack_bits(x, pad_words=0):
+    """Dense 0/1 [variants][samples] -> carrier bitsets uint32 [variants][ceil(N/32) + pad_words] in the layout of
+    pcoa_accumulate_bits: sample i = bit (i & 31) of word i >> 5 (little-endian bit order)."""
+    x = np.asarray(x)
+    v, n = x.shape
+    words = (n + 31) // 32
+    b = np.packbits(x.astype(bool), axis=1, bitorder="little")          # [v][ceil(n/8)] bytes
+    out = np.zeros((v, (words + pad_words) * 4), dtype=np.uint8)
+    out[:, : b.shape[1]] = b
+    return out.view("<u4")
+

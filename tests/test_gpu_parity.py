@@ -149,6 +149,39 @@ def test_u8_boundary_matches_oracle_host_and_device(P, O, n, v):
             eng.gram()
 
 
+@pytest.mark.parametrize("n,v", [(1, 1), (5, 3), (31, 40), (32, 33), (33, 100), (64, 64), (65, 31), (300, 777),
+                                 (1030, 200), (2504, 3000)])
+def test_bit_packed_boundary_matches_oracle_host_and_device(P, O, n, v):
+    """pcoa_accumulate_bits: carrier bitsets, host and device pointers, padded / odd row strides whose padding
+    bits are garbage, accumulation on top of the other boundaries."""
+    import torch
+    ingest = load_pkg("ingest")
+    rng = np.random.default_rng(5 * n + v)
+    x = (rng.random((v, n)) < 0.3).astype(np.uint8)
+    want = x.T.astype(np.int64) @ x.astype(np.int64)
+    bits = ingest.pack_bits(x)
+    assert bits.shape == (v, (n + 31) // 32)
+    with P.PcoaEngine(n) as eng:
+        eng.accumulate_bits(bits)                                    # host, tight stride
+        assert np.array_equal(eng.gram(), want)
+        assert eng.timings()["gram_kernel_kind"] == 3
+        for pad in (1, 2, 5):                                        # device, padded stride, garbage in the padding
+            wide = ingest.pack_bits(x, pad_words=pad)
+            wide[:, bits.shape[1]:] = 0xdeadbeef
+            if n % 32:
+                wide[:, bits.shape[1] - 1] |= np.uint32((0xffffffff << (n % 32)) & 0xffffffff)  # bits of samples >= N
+            eng.accumulate_bits(torch.from_numpy(wide.view(np.int32)).cuda())
+        eng.accumulate_bits(wide)                                    # host, padded stride
+        eng.accumulate_dense(x.astype(np.float32))                   # mixes with the dense boundary
+        assert np.array_equal(eng.gram(), 6 * want)
+    with P.PcoaEngine(n, gram_kernel="f32") as eng:
+        with pytest.raises(P.PcoaError):
+            eng.accumulate_bits(bits)
+    with P.PcoaEngine(n) as eng:
+        with pytest.raises(P.PcoaError):
+            eng.accumulate_bits(bits[:, :-1] if bits.shape[1] > 1 else np.zeros((v, 0), dtype=np.uint32))
+
+
 def test_i8_path_rejects_non_integer_or_large_values_and_f32_path_accepts_integers(P, O):
     x = np.zeros((40, 12), dtype=np.float32)
     x[3, 4] = 1.0
