@@ -258,53 +258,64 @@ __global__ __launch_bounds__(256) void pack_fp4_kernel(const T* __restrict__ x, 
 }
 
 // ---- bit-packed boundary: carrier bitsets (1 bit per genotype, row v = variant v, bit i & 31 of word i >> 5 =
-// sample i) -> P4.  One wave per (k-block of 32 variants, 64 samples): the 64 bits of a row that belong to the wave's
-// samples are a wave-uniform pair of dwords (scalar loads) and, held in an SGPR pair, they ARE a lane mask:
-// v_cndmask_b32 with that pair as condition hands every lane its own sample's bit as a positioned FP4 nibble in one
-// instruction.  2 VALU ops per row, one coalesced 16-B store per lane (1 KiB per wave).  A bitset cannot repeat a
-// callset, so the tile is binary by construction and always takes the FP4 kernel.
+// sample i) -> P4.  One wave = one k-block (32 variants) x 256 samples: lane (t, j) loads the 16 bytes of row t
+// that hold samples 128 j .. 128 j + 127 of the wave's range (one vector load per wave, 32 contiguous bytes per
+// row).  The 32 x 32 bit transposes go through v_readlane: the two dwords of row t that belong to a group of 64
+// samples land in an SGPR pair, and an SGPR pair IS a lane mask -- v_cndmask_b32 with it as condition hands every
+// lane its own sample's bit as a positioned FP4 nibble.  4 VALU ops per (row, 64 samples), one coalesced 16-B store
+// per lane and group.  (A first version with scalar loads instead of the vector load + readlane was 5x slower:
+// 1.74 ms per 10^6 variants, scalar-cache bound.)  A bitset cannot repeat a callset, so the tile is binary by
+// construction and always takes the FP4 kernel.
+template <int VEC>
 __global__ __launch_bounds__(256) void expand_bits_fp4_kernel(const uint32_t* __restrict__ bits, int64_t ld_words,
                                                               int64_t nv, int n, int npad, int64_t nkb_pad,
                                                               int8_t* __restrict__ p) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int groups = npad >> 6;                               // 64-sample groups per k-block (multiple of 4)
+  const int gpk = npad >> 8;                                  // 256-sample groups per k-block
   const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
-  const int64_t kb = wid / groups;
-  const int g = (int)(wid - kb * groups);
+  const int64_t kb = wid / gpk;
+  const int G = (int)(wid - kb * gpk);
   if (kb >= nkb_pad) return;
-  const int live = n - 64 * g;                                // samples of this group that exist (may be <= 0)
-  const uint64_t live_mask = live >= 64 ? ~0ull : (live <= 0 ? 0ull : ((1ull << live) - 1ull));
-  // dword indices clamped into the row so that every load is legal; what must not count is masked off instead
-  // (no branches: the 64 scalar loads of a wave go out back to back)
-  const int64_t last = ld_words - 1;
-  const int64_t w0 = (2 * g < last) ? 2 * g : last;
-  const bool has_hi = 2 * g + 1 <= last;
-  const int64_t w1 = has_hi ? 2 * g + 1 : last;
-  const uint64_t hi_mask = has_hi ? ~0ull : 0xffffffffull;
-  uint32_t w[4] = {0u, 0u, 0u, 0u};
+  const int t = lane & 31, j = lane >> 5;
+  const int64_t row = kb * 32 + t;
+  const int64_t w = 8 * (int64_t)G + 4 * j;                   // first of this lane's four dwords
+  uint32_t c[4] = {0u, 0u, 0u, 0u};
+  if (row < nv) {
+    const uint32_t* r = bits + row * ld_words;
+    if (VEC == 4 && w + 3 < ld_words) {
+      const uint4 u = *reinterpret_cast<const uint4*>(r + w);
+      c[0] = u.x; c[1] = u.y; c[2] = u.z; c[3] = u.w;
+    } else {
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {  // two batches of 16 rows: 32 scalar loads in flight, then 16 selects
-    uint64_t m[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int64_t row = kb * 32 + h * 16 + t;
-      const uint32_t* r = bits + (row < nv ? row : nv - 1) * ld_words;  // wave-uniform address: scalar loads
-      m[t] = (((uint64_t)r[w1] << 32) | r[w0]);
+      for (int q = 0; q < 4; ++q)
+        if (w + q < ld_words) c[q] = r[w + q];
     }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int64_t row = kb * 32 + h * 16 + t;
-      const uint64_t mm = (m[t] & hi_mask & live_mask) & (row < nv ? ~0ull : 0ull);
-      uint32_t nib;
-      const uint32_t one = 2u << (4 * (t & 7));               // E2M1 1.0 at this variant's nibble
-      asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(nib) : "v"(one), "s"(mm));
-      w[h * 2 + (t >> 3)] |= nib;
-    }
-    __builtin_amdgcn_sched_barrier(0);
   }
-  *reinterpret_cast<uint4*>(p + ((size_t)kb * npad + (size_t)64 * g + lane) * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+  // bits of samples >= N (row padding, the tail of the last word) are ignored
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t first = 32 * (w + q);
+    if (first >= n) c[q] = 0u;
+    else if (first + 32 > n) c[q] &= (1u << (n - (int)first)) - 1u;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {                               // samples 256 G + 64 q + lane
+    uint32_t o[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int t2 = 0; t2 < 32; ++t2) {
+      const int src = t2 + 32 * (q >> 1);                     // the lane that loaded row t2, half q >> 1
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)c[2 * (q & 1)], src);
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)c[2 * (q & 1) + 1], src);
+      const uint64_t m = ((uint64_t)hi << 32) | lo;
+      uint32_t nib;
+      const uint32_t one = 2u << (4 * (t2 & 7));              // E2M1 1.0 at this variant's nibble
+      asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(nib) : "v"(one), "s"(m));
+      o[t2 >> 3] |= nib;
+    }
+    *reinterpret_cast<uint4*>(p + ((size_t)kb * npad + (size_t)256 * G + 64 * q + lane) * 16) =
+        make_uint4(o[0], o[1], o[2], o[3]);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- gemm
@@ -778,10 +789,15 @@ hipError_t launch_expand_bits_fp4(const uint32_t* bits, int64_t ld_words, int64_
   if (nv <= 0) return hipSuccess;
   const int npad = (int)gram_i8_npad(n);
   const int64_t nkb_pad = gram_kb_pad(nv, 1);
-  const int64_t blocks = nkb_pad * (npad >> 6) / 4;  // npad is a multiple of 256: 4 waves = 4 sample groups of one k-block
+  const int64_t blocks = nkb_pad * (npad >> 8) / 4;  // nkb_pad is a multiple of 24: whole blocks of 4 waves
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(expand_bits_fp4_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, bits, ld_words, nv, n, npad,
-                     nkb_pad, p);
+  const bool vec = ((ld_words & 3) == 0) && ((reinterpret_cast<uintptr_t>(bits) & 15) == 0);
+  if (vec)
+    hipLaunchKernelGGL(expand_bits_fp4_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, stream, bits, ld_words, nv, n,
+                       npad, nkb_pad, p);
+  else
+    hipLaunchKernelGGL(expand_bits_fp4_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, bits, ld_words, nv, n,
+                       npad, nkb_pad, p);
   return hipGetLastError();
 }
 
