@@ -257,6 +257,65 @@ __global__ __launch_bounds__(256) void pack_fp4_kernel(const T* __restrict__ x, 
   if (bad) atomicOr(flag, 8);
 }
 
+// uint8 input, 8-byte loads: one thread packs 32 variants x 8 samples (a wave reads 512 contiguous bytes per row
+// instead of the 256 of the generic kernel above: 2504-byte rows are not line-aligned, so short segments pay for an
+// extra 128-B line each).  Four batches of 8 rows; per batch the 0/1 bytes of row t are OR-ed in at bit t, which
+// leaves one byte of 8 row-bits per sample, and `spread8` turns that byte into 8 FP4 nibbles (bit t -> 0x2 << 4t).
+__device__ __forceinline__ uint32_t spread8_fp4(uint32_t b) {  // b < 256
+  uint32_t x = (b | (b << 12)) & 0x000F000Fu;
+  x = (x | (x << 6)) & 0x03030303u;
+  x = (x | (x << 3)) & 0x11111111u;
+  return x << 1;
+}
+
+__global__ __launch_bounds__(256) void pack_u8x8_fp4_kernel(const uint8_t* __restrict__ x, int64_t ld, int64_t nv, int n,
+                                                            int npad, int64_t nkb_pad, int8_t* __restrict__ p,
+                                                            int32_t* __restrict__ flag) {
+  const int groups = npad >> 3;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t kb = gid / groups;
+  const int g = (int)(gid - kb * groups);
+  if (kb >= nkb_pad) return;
+  const int i0 = g * 8;
+  // byte masks of the columns that exist (< n); columns in [n, ld) may hold anything
+  uint32_t m[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    uint32_t mm = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (i0 + 4 * d + b < n) mm |= 0xffu << (8 * b);
+    m[d] = mm;
+  }
+  const bool in_row = i0 < ld;  // ld is a multiple of 8 on this path, so the whole 8-byte load is inside the row
+  uint32_t o[8][4];
+  uint32_t bad = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    uint32_t a0 = 0, a1 = 0;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int64_t row = kb * 32 + q * 8 + t;
+      uint2 u = make_uint2(0u, 0u);
+      if (row < nv && in_row) u = *reinterpret_cast<const uint2*>(x + row * ld + i0);
+      u.x &= m[0];
+      u.y &= m[1];
+      bad |= (u.x | u.y) & 0xfefefefeu;
+      a0 |= (u.x & 0x01010101u) << t;
+      a1 |= (u.y & 0x01010101u) << t;
+    }
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx) {
+      o[sidx][q] = spread8_fp4((a0 >> (8 * sidx)) & 0xffu);
+      o[4 + sidx][q] = spread8_fp4((a1 >> (8 * sidx)) & 0xffu);
+    }
+  }
+  uint4* dst = reinterpret_cast<uint4*>(p + ((size_t)kb * npad + i0) * 16);
+#pragma unroll
+  for (int sidx = 0; sidx < 8; ++sidx) dst[sidx] = make_uint4(o[sidx][0], o[sidx][1], o[sidx][2], o[sidx][3]);
+  if (bad) atomicOr(flag, 8);
+}
+
 // ---- bit-packed boundary: carrier bitsets (1 bit per genotype, row v = variant v, bit i & 31 of word i >> 5 =
 // sample i) -> P4.  One wave = one k-block (32 variants) x 256 samples: lane (t, j) loads the 16 bytes of row t
 // that hold samples 128 j .. 128 j + 127 of the wave's range (one vector load per wave, 32 contiguous bytes per
@@ -773,6 +832,13 @@ hipError_t launch_pack_fp4(const void* x, int is_u8, int64_t ld, int64_t nv, int
   if (is_u8) {
     const bool vec = ((ld & 3) == 0) && ((addr & 3) == 0);
     const uint8_t* xs = static_cast<const uint8_t*>(x);
+    if (((ld & 7) == 0) && ((addr & 7) == 0)) {
+      const int64_t blocks8 = (nkb_pad * (npad >> 3) + 255) / 256;
+      if (blocks8 > 0x7fffffffLL) return hipErrorInvalidValue;
+      hipLaunchKernelGGL(pack_u8x8_fp4_kernel, dim3((unsigned)blocks8), block, 0, stream, xs, ld, nv, n, npad, nkb_pad, p,
+                         flag);
+      return hipGetLastError();
+    }
     if (vec) hipLaunchKernelGGL((pack_fp4_kernel<uint8_t, 4>), grid, block, 0, stream, xs, ld, nv, n, npad, nkb_pad, p, flag);
     else hipLaunchKernelGGL((pack_fp4_kernel<uint8_t, 1>), grid, block, 0, stream, xs, ld, nv, n, npad, nkb_pad, p, flag);
   } else {
