@@ -33,6 +33,7 @@
 // Roofline: i8 MFMA, peak ~5 POP/s dense (2x the bf16 rate, MI355X_MICROARCH.md); algorithmic
 // intensity of the packed operands N/0.5 = 5008 op/B, so HBM is irrelevant once packed.
 #include <cstdlib>
+#include <type_traits>
 #include <utility>
 
 #include "pcoa_internal.h"
@@ -191,17 +192,24 @@ __global__ __launch_bounds__(256) void densify_csr_i8_kernel(const int32_t* __re
 // ---- FP4 pre-pass: X (fp32 or uint8, values exactly 0 / 1) -> P4 [V/32][Npad][16 B], 32 nibbles per lane slice.
 // One thread: 32 variants x 4 samples, in two halves of 16 variants (8 bytes of each sample's slice per half).
 // flag bit 3 (value 8) is raised for a value that is not exactly 0 or 1.
-template <typename T, int VEC>
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <typename T, int VEC, bool NT = false>
 __global__ __launch_bounds__(256) void pack_fp4_kernel(const T* __restrict__ x, int64_t ld, int64_t nv, int n, int npad,
                                                        int64_t nkb_pad, int8_t* __restrict__ p,
                                                        int32_t* __restrict__ flag) {
-  const int groups = npad >> 2;
-  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t kb = gid / groups;
-  const int g = (int)(gid - kb * groups);
+  // a wave = 64 consecutive 4-sample groups of ONE k-block (npad / 4 is a multiple of 64): the k-block index is
+  // wave-uniform, which keeps the row addresses in SGPRs (scalar base + one per-lane column offset)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gw = npad >> 8;  // waves per k-block
+  const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t kb = wid / gw;
+  const int g = (int)(wid - kb * gw) * 64 + lane;
   if (kb >= nkb_pad) return;
   const int i0 = g * 4;
   bool bad = false;
+  uint32_t badw = 0;
   uint32_t w[4][4];
 #pragma unroll
   for (int s = 0; s < 4; ++s)
@@ -210,35 +218,65 @@ __global__ __launch_bounds__(256) void pack_fp4_kernel(const T* __restrict__ x, 
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     uint32_t one[16];  // bit s of one[t] = sample i0+s carries at variant 32*kb + 16*h + t
+    if constexpr (VEC == 4) {
+      // VEC == 4 means ld % 4 == 0: a group of 4 columns is wholly inside the row or wholly padding.  Branch-free
+      // (address clamped into the tile, result masked) and in two steps -- all 16 row loads of the half first, then
+      // the arithmetic -- so that 16 loads per lane are in flight; left to itself the compiler waits for every row
+      // before loading the next one.
+      typedef typename std::conditional<sizeof(T) == 4, f32x4_t, uint32_t>::type Raw;
+      Raw raw[16];
+      const int64_t col = (i0 < ld) ? i0 : 0;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int64_t row = kb * 32 + h * 16 + t;
-      uint32_t bits = 0;
-      if (row < nv) {
-        const T* src = x + row * ld + i0;
-        T v[4];
-        if (VEC == 4 && i0 + 3 < ld) {
+      for (int t = 0; t < 16; ++t) {
+        const int64_t row = kb * 32 + h * 16 + t;
+        const T* src = x + (row < nv ? row : nv - 1) * ld + col;
+        if constexpr (NT) raw[t] = __builtin_nontemporal_load(reinterpret_cast<const Raw*>(src));
+        else raw[t] = *reinterpret_cast<const Raw*>(src);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int64_t row = kb * 32 + h * 16 + t;
+        const uint32_t valid = (uint32_t)(row < nv) & (uint32_t)(i0 < ld);
+        uint32_t bits = 0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {   // integer logic only: `&&` / `||` would come back as branches
+          uint32_t is1, is0;
           if constexpr (sizeof(T) == 4) {
-            const float4 f = *reinterpret_cast<const float4*>(src);
-            v[0] = (T)f.x; v[1] = (T)f.y; v[2] = (T)f.z; v[3] = (T)f.w;
+            is1 = (uint32_t)(raw[t][s] == 1.0f);
+            is0 = (uint32_t)(raw[t][s] == 0.0f);
           } else {
-            const uint32_t u = *reinterpret_cast<const uint32_t*>(src);
-            v[0] = (T)(u & 0xff); v[1] = (T)((u >> 8) & 0xff); v[2] = (T)((u >> 16) & 0xff); v[3] = (T)(u >> 24);
+            const uint32_t b = (raw[t] >> (8 * s)) & 0xffu;
+            is1 = (uint32_t)(b == 1u);
+            is0 = (uint32_t)(b == 0u);
           }
-        } else {
+          const uint32_t live = valid & (uint32_t)(i0 + s < n);  // columns [n, ld) may hold anything
+          badw |= live & ((is1 | is0) ^ 1u);
+          bits |= (live & is1) << s;
+        }
+        one[t] = bits;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int64_t row = kb * 32 + h * 16 + t;
+        uint32_t bits = 0;
+        if (row < nv) {
+          const T* src = x + row * ld + i0;
+          T v[4];
 #pragma unroll
           for (int s = 0; s < 4; ++s) v[s] = (i0 + s < ld) ? src[s] : (T)0;
-        }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          if (i0 + s < n) {  // padding columns [n, ld) may hold anything: ignored
-            const bool is1 = (v[s] == (T)1);
-            bad |= !(is1 || v[s] == (T)0);
-            bits |= (is1 ? 1u : 0u) << s;
+          for (int s = 0; s < 4; ++s) {
+            if (i0 + s < n) {  // padding columns [n, ld) may hold anything: ignored
+              const bool is1 = (v[s] == (T)1);
+              bad |= !(is1 || v[s] == (T)0);
+              bits |= (is1 ? 1u : 0u) << s;
+            }
           }
         }
+        one[t] = bits;
       }
-      one[t] = bits;
     }
     // nibble of variant t = 0x2 (E2M1 1.0) or 0x0; 8 variants per 32-bit word
 #pragma unroll
@@ -254,7 +292,7 @@ __global__ __launch_bounds__(256) void pack_fp4_kernel(const T* __restrict__ x, 
   uint4* dst = reinterpret_cast<uint4*>(p + ((size_t)kb * npad + i0) * 16);
 #pragma unroll
   for (int s = 0; s < 4; ++s) dst[s] = make_uint4(w[s][0], w[s][1], w[s][2], w[s][3]);
-  if (bad) atomicOr(flag, 8);
+  if (bad || badw) atomicOr(flag, 8);
 }
 
 // uint8 input, 8-byte loads: one thread packs 32 variants x 8 samples (a wave reads 512 contiguous bytes per row
@@ -844,7 +882,9 @@ hipError_t launch_pack_fp4(const void* x, int is_u8, int64_t ld, int64_t nv, int
   } else {
     const bool vec = ((ld & 3) == 0) && ((addr & 15) == 0);
     const float* xs = static_cast<const float*>(x);
-    if (vec) hipLaunchKernelGGL((pack_fp4_kernel<float, 4>), grid, block, 0, stream, xs, ld, nv, n, npad, nkb_pad, p, flag);
+    static const bool nt = std::getenv("PCOA_PACK_NT") != nullptr;
+    if (vec && nt) hipLaunchKernelGGL((pack_fp4_kernel<float, 4, true>), grid, block, 0, stream, xs, ld, nv, n, npad, nkb_pad, p, flag);
+    else if (vec) hipLaunchKernelGGL((pack_fp4_kernel<float, 4>), grid, block, 0, stream, xs, ld, nv, n, npad, nkb_pad, p, flag);
     else hipLaunchKernelGGL((pack_fp4_kernel<float, 1>), grid, block, 0, stream, xs, ld, nv, n, npad, nkb_pad, p, flag);
   }
   return hipGetLastError();
