@@ -85,7 +85,7 @@ def main():
                     help="N>1: native = RCCL communicator inside libpcoa_hip (in-place int32), torch = "
                          "export -> torch.distributed.all_reduce -> import")
     ap.add_argument("--gram-kernel", choices=["auto", "fp4", "i8", "f32"], default="auto",
-                    help="auto (default): binary tiles -> pack to MX-FP4 + v_mfma_scale_f32_32x32x64_f8f6f4, tiles with "
+                    help="auto (default): binary tiles -> pack to MX-FP4 + v_mfma_f32_32x32x64_f8f6f4, tiles with "
                          "multiplicities -> int8; fp4 / i8: force one; f32: v_mfma_f32_32x32x2_f32")
     args = ap.parse_args()
 
@@ -201,7 +201,7 @@ def main():
         if kind == 3:
             tile, peak, kname = 256, PEAK_FP4_MFMA_TFLOPS, "gram_packed_kernel<fp4>"
             kdesc = ("pack fp32->k-blocked FP4 E2M1 (HBM-bound, verifies values are 0/1) + MX-FP4 MFMA "
-                     "v_mfma_scale_f32_32x32x64_f8f6f4 (unit scales, exact), upper-triangular 256x256 tiles, split-K, "
+                     "v_mfma_f32_32x32x64_f8f6f4 (unscaled form, exact), upper-triangular 256x256 tiles, split-K, "
                      "fp32 accumulators (< 2^24 per launch) -> int32 atomics")
         elif kind == 2:
             tile, peak, kname = 256, PEAK_I8_MFMA_TOPS, "gram_packed_kernel<i8>"

@@ -51,7 +51,7 @@ typedef enum pcoa_status {
                                            hold carrier multiplicities 2..127 (decided per chunk, both exact)  */
 #define PCOA_FLAG_GRAM_F32_MFMA  0x1u  /* fp32-MFMA Gram kernel (v_mfma_f32_32x32x2_f32): any small ints */
 #define PCOA_FLAG_GRAM_I8_MFMA   0x2u  /* int8-MFMA Gram kernel only (v_mfma_i32_32x32x32_i8), values 0..127 */
-#define PCOA_FLAG_GRAM_FP4_MFMA  0x4u  /* MX-FP4 Gram kernel only (v_mfma_scale_f32_32x32x64_f8f6f4): a value
+#define PCOA_FLAG_GRAM_FP4_MFMA  0x4u  /* MX-FP4 Gram kernel only (v_mfma_f32_32x32x64_f8f6f4): a value
                                            other than 0 / 1 is an error                                        */
 #define PCOA_FLAG_NO_SIGN_NORM   0x10u /* keep the eigensolver's native sign instead of sign-normalising */
 #define PCOA_FLAG_EIG_HOUSEHOLDER 0x20u /* always use the dense Householder + bisection eigensolver        */

@@ -24,7 +24,7 @@
 //      12 ds_read_b128 and 4 DMA instructions.
 //
 // FP4 variant (FMT = 1): binary genotypes are exactly representable in MX-FP4 (E2M1: 0 -> 0x0, 1.0 -> 0x2), and
-// v_mfma_scale_f32_32x32x64_f8f6f4 (block scales fixed at 2^0) runs at twice the i8 rate on HALF the operand
+// v_mfma_f32_32x32x64_f8f6f4 (the unscaled form: no block scale is applied) runs at twice the i8 rate on HALF the operand
 // bytes: a k-block is then 32 variants (still 16 B per lane), products are 0/1 and the fp32 accumulators are
 // exact below 2^24 (a launch never exceeds that).  The contraction kernel is the same template; only the
 // MFMA instruction, the accumulator type and the pre-pass differ.  Tiles that hold anything but 0/1 are
@@ -482,6 +482,7 @@ struct AccType { typedef i32x16 type; };
 template <>
 struct AccType<1> { typedef f32x16 type; };
 
+
 template <int FMT, int NNI>
 __device__ __forceinline__ void mfma_step_i8(const FragsI8<NNI>& f, typename AccType<FMT>::type (&acc)[4][NNI]) {
 #pragma unroll
@@ -491,15 +492,16 @@ __device__ __forceinline__ void mfma_step_i8(const FragsI8<NNI>& f, typename Acc
       if constexpr (FMT == 0) {
         acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[mi], f.b[ni], acc[mi][ni], 0, 0, 0);
       } else {
-        // 32 FP4 values per lane = 4 VGPRs; cbsz = blgp = 4 selects E2M1; E8M0 scale byte 127 = 2^0 for both
-        // operands.  Written as inline asm because the builtin takes 8-VGPR operand tuples (the FP4 form
+        // 32 FP4 values per lane = 4 VGPRs; cbsz = blgp = 4 selects E2M1.  The UNSCALED form of the instruction:
+        // no block scale is applied (bit-exact against the oracle, tests/test_gpu_parity.py) and it saves the
+        // ld_scale half of v_mfma_scale_* (1.235 vs 1.259 ms per 10^6 variants).  Written as inline asm because the builtin takes 8-VGPR operand tuples (the FP4 form
         // reads the low 4): materialising them doubles the fragment registers and the kernel spills.
         // Hazards (cdna_hip_programming.md 5.7): operands come from ds_read (the compiler waits lgkmcnt before
         // the statement since it names them as inputs); D feeds only the next MFMA as its whole C (no wait
         // states needed); the epilogue's first VALU read of D is fenced by s_nops after the main loop.
-        asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] cbsz:4 blgp:4"
+        asm volatile("v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, %0 cbsz:4 blgp:4"
                      : "+v"(acc[mi][ni])
-                     : "v"(f.a[mi]), "v"(f.b[ni]), "v"(0x7f7f7f7f));
+                     : "v"(f.a[mi]), "v"(f.b[ni]));
       }
     }
 }
@@ -821,7 +823,7 @@ __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram
                                           acc, std::make_integer_sequence<int, NST - 1>{});
   }
 
-  if constexpr (FMT == 1) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last asm MFMA -> VALU read of D
+  if constexpr (FMT >= 1) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last asm MFMA -> VALU read of D
   // epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
   // Only the upper triangle (j >= i) is authoritative; pcoa_gram_finalize mirrors it.
 #pragma unroll
@@ -848,7 +850,7 @@ int64_t gram_i8_npad(int32_t n) { return ((int64_t)n + TM - 1) / TM * TM; }
 // k-blocks (16 variants for int8, 32 for FP4; 16 B per sample either way) are padded to a multiple of 24 so
 // that every stage depth (4, 6 or 8 k-blocks) divides the count
 int64_t gram_kb_pad(int64_t nv, int fmt) {
-  const int per = fmt == 1 ? 32 : KB;
+  const int per = fmt >= 1 ? 32 : KB;
   const int64_t nkb = (nv + per - 1) / per;
   return (nkb + 23) / 24 * 24;
 }
