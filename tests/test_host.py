@@ -204,6 +204,30 @@ def test_join_and_merge_follow_the_reference_semantics():
     assert [v["start"] for v in drv.filterDataset(data)] == [1]
 
 
+def test_pack_bits_layout_is_the_one_pcoa_accumulate_bits_documents():
+    """include/pcoa.h: sample i of variant v is bit (i & 31) of word bits[v * ld_words + (i >> 5)]."""
+    ingest = load_pkg("ingest")
+    rng = np.random.default_rng(9)
+    for n in (1, 31, 32, 33, 70, 2504):
+        x = (rng.random((7, n)) < 0.4).astype(np.uint8)
+        for pad in (0, 3):
+            b = ingest.pack_bits(x, pad_words=pad)
+            assert b.dtype == np.dtype("<u4") and b.shape == (7, (n + 31) // 32 + pad)
+            for v in range(7):
+                for i in range(n):
+                    assert ((int(b[v, i >> 5]) >> (i & 31)) & 1) == x[v, i]
+            assert not b[:, (n + 31) // 32:].any()
+            if n % 32:
+                assert not (b[:, (n - 1) >> 5] >> np.uint32(n % 32)).any()   # tail bits of the last word are zero
+    # a carrier bitset is the CSR row of pcoa_accumulate_calls as a set
+    callsets = [[0, 5, 33], [], [69]]
+    dense = np.zeros((3, 70), dtype=np.uint8)
+    for v, c in enumerate(callsets):
+        dense[v, c] = 1
+    b = ingest.pack_bits(dense)
+    assert b[0, 0] == (1 | (1 << 5)) and b[0, 1] == (1 << 1) and not b[1].any() and b[2, 2] == (1 << 5)
+
+
 def test_hot_kernels_do_not_spill_to_scratch():
     """A register spill in a Gram kernel costs an order of magnitude (seen once: 1,632 B/lane of scratch made
     the i8 contraction 45x slower while every parity test stayed green).  hipcc reports it at compile time."""
