@@ -129,59 +129,6 @@ __global__ __launch_bounds__(1024) void lanczos_finish_kernel(double* __restrict
   }
 }
 
-// CGS2 + finish of one Lanczos step in ONE workgroup (n <= kOrthoFusedMaxN): the five kernels above move ~1 MB at
-// N = 2504 and were launch-latency bound (5 x 4-5 us per step against 12.7 us for the matvec).  16 waves: wave c
-// takes basis vectors c, c+16, ... for the dot products (lanes stride over n, coalesced); the update runs one
-// thread per element.  w stays in global memory (L2-resident); __syncthreads orders the block's own global writes.
-constexpr int kOrthoFusedMaxN = 16384;
-constexpr int kOrthoMaxM = 1024;
-
-__global__ __launch_bounds__(1024) void lanczos_ortho_kernel(double* __restrict__ v, int n, int j,
-                                                             double* __restrict__ w, double* __restrict__ alpha,
-                                                             double* __restrict__ beta) {
-  __shared__ double h[kOrthoMaxM];
-  __shared__ double red[24];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double a_j = 0.0;
-  for (int pass = 0; pass < 2; ++pass) {
-    for (int c = wave; c <= j; c += 16) {
-      const double* vc = v + (int64_t)c * n;
-      double p0 = 0.0, p1 = 0.0;
-      int i = lane;
-      for (; i + 64 < n; i += 128) {
-        p0 += vc[i] * w[i];
-        p1 += vc[i + 64] * w[i + 64];
-      }
-      if (i < n) p0 += vc[i] * w[i];
-      const double t = wave_sum(p0 + p1);
-      if (lane == 0) h[c] = t;
-    }
-    __syncthreads();
-    a_j += h[j];
-    for (int i = threadIdx.x; i < n; i += 1024) {
-      double acc0 = 0.0, acc1 = 0.0;
-      int c = 0;
-      for (; c + 1 <= j; c += 2) {
-        acc0 += h[c] * v[(int64_t)c * n + i];
-        acc1 += h[c + 1] * v[(int64_t)(c + 1) * n + i];
-      }
-      if (c <= j) acc0 += h[c] * v[(int64_t)c * n + i];
-      w[i] -= acc0 + acc1;
-    }
-    __syncthreads();
-  }
-  double part = 0.0;
-  for (int i = threadIdx.x; i < n; i += 1024) part += w[i] * w[i];
-  const double nrm = sqrt(block_sum(part, red));
-  const double rn = (nrm > 0.0) ? 1.0 / nrm : 0.0;
-  double* vn = v + (int64_t)(j + 1) * n;
-  for (int i = threadIdx.x; i < n; i += 1024) vn[i] = w[i] * rn;
-  if (threadIdx.x == 0) {
-    alpha[j] = a_j;
-    beta[j] = nrm;
-  }
-}
-
 // u[c][i] = sum_p y[c][p] V[p][i]    (Ritz vectors), grid (ceil(n/256), k)
 __global__ __launch_bounds__(256) void ritz_kernel(const double* __restrict__ v, int n, int m,
                                                    const double* __restrict__ y, double* __restrict__ u) {
@@ -244,7 +191,10 @@ hipError_t lanczos_topk(const EigWorkspace& ws, double* lz, int32_t n, int32_t k
 
   hipLaunchKernelGGL(lanczos_init_kernel, dim3(1), dim3(1024), 0, stream, V, n);
   const unsigned rows4 = (unsigned)((n + 3) / 4), nb = (unsigned)((n + 255) / 256);
-  int next_check = 16;  // first look at the Ritz pairs; then every 8 steps up to 64, then every m / 2
+  // Ritz pairs are examined at m = 12, 16, 20, 24, then every 8 steps up to 64, then every m / 2: a check costs about
+  // four steps (bisection + inverse iteration on T_m + two host round trips), and population structure converges
+  // early (configs[1] stand-in: estimate 1e-14 at m = 12, true relative residual 3.7e-9)
+  int next_check = 12;
   if (const char* fc = std::getenv("PCOA_LANCZOS_FIRST_CHECK")) next_check = std::max(4, std::atoi(fc));
   if (next_check > mmax) next_check = mmax;
   std::vector<double> cand, ylast((size_t)k), hres((size_t)k);
@@ -252,18 +202,16 @@ hipError_t lanczos_topk(const EigWorkspace& ws, double* lz, int32_t n, int32_t k
   for (int j = 0; j < mmax; ++j) {
     const double* vj = V + (size_t)j * n;
     hipLaunchKernelGGL(symv_kernel, dim3(rows4), dim3(256), 0, stream, ws.a, n, vj, w);
-    if (n <= kOrthoFusedMaxN && mmax < kOrthoMaxM) {
-      hipLaunchKernelGGL(lanczos_ortho_kernel, dim3(1), dim3(1024), 0, stream, V, n, j, w, alpha, beta);
-    } else {
+    // (the five small kernels below fused into ONE workgroup were measured slower: 30 vs 24 us per step -- a single
+    // CU cannot stream the ~2 MB of basis vectors a step touches as fast as j+1 workgroups can)
     hipLaunchKernelGGL(cgs_dots_kernel, dim3((unsigned)(j + 1)), dim3(256), 0, stream, V, n, w, h1);
     hipLaunchKernelGGL(cgs_update_kernel, dim3(nb), dim3(256), 0, stream, V, n, j + 1, h1, w);
     hipLaunchKernelGGL(cgs_dots_kernel, dim3((unsigned)(j + 1)), dim3(256), 0, stream, V, n, w, h2);
     hipLaunchKernelGGL(cgs_update_kernel, dim3(nb), dim3(256), 0, stream, V, n, j + 1, h2, w);
     hipLaunchKernelGGL(lanczos_finish_kernel, dim3(1), dim3(1024), 0, stream, V, n, j, w, h1, h2, alpha, beta);
-    }
     const int m = j + 1;
     if (m != next_check && m != mmax) continue;
-    next_check = (m < 64) ? m + 8 : m + m / 2;
+    next_check = (m < 24) ? m + 4 : (m < 64) ? m + 8 : m + m / 2;
     if (next_check > mmax) next_check = mmax;
     if (steps_out) *steps_out = m;
 
