@@ -164,6 +164,26 @@ def main():
     eng.reset()
     for _ in range(args.warmup):
         one_step()
+    if native is not None:
+        # first use of the native communicator: if it fails on ANY rank, every rank moves to torch.distributed
+        ok = 1
+        try:
+            native.allreduce()
+            eng.sync()
+        except Exception as exc:  # noqa: BLE001
+            sys.stderr.write("rank %d: native RCCL all-reduce failed (%s); using torch.distributed\n" % (rank, exc))
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        td.all_reduce(flag, op=td.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            try:
+                native.close()
+            except Exception:  # noqa: BLE001
+                pass
+            native = None
+            allreduce_mode = "torch"
+            eng.reset()
+            one_step()
     finish_job()  # also warms the collective
     fence()
     eng.reset()
