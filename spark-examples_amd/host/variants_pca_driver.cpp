@@ -28,8 +28,11 @@
 #include <memory>
 #include <sstream>
 #include <string>
+#include <string_view>
+#include <thread>
 #include <unordered_map>
 #include <vector>
+#include <chrono>
 
 #include "pcoa.h"
 
@@ -41,6 +44,8 @@ struct Conf {  // PcaConf / GenomicsConf (GenomicsConf.scala:31-101), same flag 
   std::vector<std::string> references{"chr17:41196311:41277499"};
   std::vector<std::string> variant_set_id{"3049512673186936334"};
   bool all_references = false, debug_datasets = false, has_maf = false;
+  bool parse_only = false;  // not a reference flag: ingest + getCallsRdd only, prints the carrier statistics (no GPU)
+  int ingest_threads = 0;   // not a reference flag: 0 = hardware concurrency (local[*]), cf. --spark-master local[k]
   float min_allele_frequency = 0.f;
   int num_pc = 2, num_reduce_partitions = 10, gpu = 0;
   long bases_per_partition = 1000000;
@@ -77,6 +82,8 @@ Conf parse(int argc, char** argv) {
     else if (a == "--client-secrets") c.client_secrets = one(i);
     else if (a == "--spark-master") c.spark_master = one(i);
     else if (a == "--gpu") c.gpu = std::atoi(one(i).c_str());
+    else if (a == "--parse-only") c.parse_only = true;
+    else if (a == "--ingest-threads") c.ingest_threads = std::atoi(one(i).c_str());
     else die("unknown flag " + a);
   }
   return c;
@@ -146,11 +153,14 @@ std::string murmur3_128_hex(const std::string& data) {
 }
 
 // ---- variants -------------------------------------------------------------------------------
-struct CallData { bool has_variation; int32_t callset; };  // case class CallData (:288)
+// case class CallData(hasVariation, callsetId) (:288): everything downstream of extractCallInfo (:56-60) only ever
+// keeps the calls with hasVariation (getCallsRdd :163-167; join / merge concatenate the call lists first, which
+// commutes with the filter because callset indices are global), so a variant stores its CARRIERS: the callset
+// indices with variation, in call order.
 struct Variant {
   std::string key;                 // getVariantKey
   bool has_af = false; float af = 0.f;
-  std::vector<CallData> calls;     // extractCallInfo (:56-60)
+  std::vector<int32_t> carriers;   // extractCallInfo (:56-60) filtered by hasVariation
 };
 struct Dataset {
   std::vector<std::string> ids, names;
@@ -187,22 +197,15 @@ std::vector<Region> parse_references(const std::string& spec) {
   return out;
 }
 
-std::vector<std::string> split(const std::string& s, char sep) {
-  std::vector<std::string> out;
-  size_t b = 0;
-  for (;;) {
-    const size_t e = s.find(sep, b);
-    out.push_back(s.substr(b, e == std::string::npos ? std::string::npos : e - b));
-    if (e == std::string::npos) break;
-    b = e + 1;
-  }
-  return out;
-}
-
-struct LineReader {  // plain file or `gzip -dc` pipe
+// ---- VCF ingest ------------------------------------------------------------------------------------------------
+// The file (or the output of `gzip -dc`) is read in 16 MiB blocks cut at line ends; the data lines of a block are
+// parsed by a pool of threads (contiguous line ranges, results concatenated in file order), in place with
+// string_views: no per-field allocation.  One sample column costs a scan up to the next tab.
+struct BlockReader {  // plain file or `gzip -dc` pipe
   FILE* f = nullptr;
   bool piped = false;
-  explicit LineReader(const std::string& path) {
+  std::string carry;
+  explicit BlockReader(const std::string& path) {
     if (path.size() > 3 && path.substr(path.size() - 3) == ".gz") {
       std::string cmd = "gzip -dc '" + path + "'";
       f = popen(cmd.c_str(), "r");
@@ -212,82 +215,171 @@ struct LineReader {  // plain file or `gzip -dc` pipe
     }
     if (!f) die("cannot open " + path);
   }
-  ~LineReader() { if (f) { if (piped) pclose(f); else std::fclose(f); } }
-  bool next(std::string& line) {
-    line.clear();
-    char buf[1 << 16];
-    while (std::fgets(buf, sizeof(buf), f)) {
-      line += buf;
-      if (!line.empty() && line.back() == '\n') { line.pop_back(); return true; }
+  ~BlockReader() { if (f) { if (piped) pclose(f); else std::fclose(f); } }
+  // next block of whole lines (the last one may lack its newline at end of file); false at end of input
+  bool next(std::string& block, size_t target = (size_t)16 << 20) {
+    block.swap(carry);
+    carry.clear();
+    for (;;) {
+      const size_t old = block.size();
+      block.resize(old + target);
+      const size_t got = std::fread(&block[old], 1, target, f);
+      block.resize(old + got);
+      if (got == 0) return !block.empty();
+      const size_t nl = block.rfind('\n');
+      if (nl != std::string::npos) {
+        carry.assign(block, nl + 1, std::string::npos);
+        block.resize(nl + 1);
+        return true;
+      }
     }
-    return !line.empty();
   }
 };
 
-Dataset load_vcf(const std::string& path, const std::vector<Region>& regions, int32_t index_base, bool debug) {
+inline std::string_view next_field(const char*& p, const char* end, char sep) {
+  const char* b = p;
+  const char* e = static_cast<const char*>(std::memchr(p, sep, (size_t)(end - p)));
+  if (!e) { p = end; return std::string_view(b, (size_t)(end - b)); }
+  p = e + 1;
+  return std::string_view(b, (size_t)(e - b));
+}
+
+struct ParsedLine { bool keep = false; Variant v; std::string debug; };
+double g_ingest_read_s = 0, g_ingest_split_s = 0, g_ingest_parse_s = 0;  // --parse-only breakdown
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+void parse_record(const char* b, const char* e, const std::vector<Region>& regions, int32_t index_base, size_t n_samples,
+                  bool debug, ParsedLine& out) {
+  const char* p = b;
+  std::string_view f[9];
+  for (int i = 0; i < 9; ++i) {
+    if (p >= e) return;  // fewer than 10 columns
+    f[i] = next_field(p, e, '\t');
+  }
+  if (p >= e) return;
+  std::string contig;
+  if (!normalize_contig(std::string(f[0]), contig)) return;  // X, Y, MT ... dropped as in the reference
+  const long start = std::atol(std::string(f[1]).c_str()) - 1;
+  if (!regions.empty()) {
+    bool in_region = false;
+    for (const auto& r : regions) in_region = in_region || (r.contig == contig && r.start <= start && start < r.end);
+    if (!in_region) return;
+  }
+  int gti = -1, k = 0;
+  for (const char *q = f[8].data(), *qe = q + f[8].size(); q < qe; ++k)
+    if (next_field(q, qe, ':') == "GT") gti = k;
+  if (gti < 0) return;
+  Variant& v = out.v;
+  std::string alt;
+  for (const char *q = f[4].data(), *qe = q + f[4].size(); q < qe;) {
+    const std::string_view a = next_field(q, qe, ',');
+    if (a != ".") alt.append(a);
+  }
+  const long end = start + (long)f[3].size();
+  if (debug) {
+    char line[512];
+    std::snprintf(line, sizeof(line), "%s: (%ld, %ld) ref=%.*s alt=%s\n", contig.c_str(), start, end, (int)f[3].size(),
+                  f[3].data(), alt.c_str());
+    out.debug = line;
+  }
+  std::string buf = contig;
+  int64_t s64 = start, e64 = end;
+  buf.append(reinterpret_cast<const char*>(&s64), 8);
+  buf.append(reinterpret_cast<const char*>(&e64), 8);
+  buf.append(f[3]);
+  buf += alt;
+  v.key = murmur3_128_hex(buf);
+  for (const char *q = f[7].data(), *qe = q + f[7].size(); q < qe;) {
+    const std::string_view item = next_field(q, qe, ';');
+    if (item.size() >= 3 && item.compare(0, 3, "AF=") == 0) {
+      v.af = std::strtof(std::string(item.substr(3)).c_str(), nullptr);
+      v.has_af = true;
+    }
+  }
+  // sample columns: one pass over the bytes.  A call has variation iff a digit 1-9 occurs inside its GT sub-field
+  // (sub-field number gti of the ':'-separated column) -- genotype.foldLeft(false)(_ || _ > 0) (:58): "." and "0"
+  // alleles do not count, phasing marks are irrelevant.
+  v.carriers.reserve(64);
+  for (size_t i = 0; i < n_samples && p < e; ++i) {
+    bool var = false;
+    int col = 0;
+    for (; p < e; ++p) {
+      const char c = *p;
+      if (c == '\t') break;
+      if (c == ':') { ++col; continue; }
+      var |= (col == gti) & (c >= '1') & (c <= '9');
+    }
+    if (p < e) ++p;  // past the tab
+    if (var) v.carriers.push_back(index_base + (int32_t)i);
+  }
+  out.keep = true;
+}
+
+Dataset load_vcf(const std::string& path, const std::vector<Region>& regions, int32_t index_base, bool debug,
+                 int n_threads) {
   Dataset d;
   std::string stem = path.substr(path.find_last_of('/') == std::string::npos ? 0 : path.find_last_of('/') + 1);
   stem = stem.substr(0, stem.find('.'));
   std::replace(stem.begin(), stem.end(), '-', '_');
-  LineReader in(path);
-  std::string line;
+  BlockReader in(path);
+  std::string block;
   bool header = false;
-  while (in.next(line)) {
-    if (line.rfind("##", 0) == 0) continue;
-    if (line.rfind("#CHROM", 0) == 0) {
-      auto cols = split(line, '\t');
-      for (size_t i = 9; i < cols.size(); ++i) {
-        d.names.push_back(cols[i]);
-        d.ids.push_back(stem + "-" + std::to_string(i - 9));
-      }
-      header = true;
-      continue;
-    }
-    if (!header) die("VCF header line (#CHROM) missing in " + path);
-    auto rec = split(line, '\t');
-    if (rec.size() < 10) continue;
-    std::string contig;
-    if (!normalize_contig(rec[0], contig)) continue;  // X, Y, MT ... dropped as in the reference
-    const long start = std::atol(rec[1].c_str()) - 1;
-    if (!regions.empty()) {
-      bool in_region = false;
-      for (const auto& r : regions) in_region = in_region || (r.contig == contig && r.start <= start && start < r.end);
-      if (!in_region) continue;
-    }
-    auto fmt = split(rec[8], ':');
-    int gti = -1;
-    for (size_t i = 0; i < fmt.size(); ++i) if (fmt[i] == "GT") gti = (int)i;
-    if (gti < 0) continue;
-    Variant v;
-    std::string alt;
-    for (const auto& a : split(rec[4], ',')) if (a != ".") alt += a;
-    const long end = start + (long)rec[3].size();
-    if (debug) std::printf("%s: (%ld, %ld) ref=%s alt=%s\n", contig.c_str(), start, end, rec[3].c_str(), alt.c_str());
-    std::string buf = contig;
-    int64_t s64 = start, e64 = end;
-    buf.append(reinterpret_cast<const char*>(&s64), 8);
-    buf.append(reinterpret_cast<const char*>(&e64), 8);
-    buf += rec[3];
-    buf += alt;
-    v.key = murmur3_128_hex(buf);
-    for (const auto& item : split(rec[7], ';')) {
-      if (item.rfind("AF=", 0) == 0) { v.af = std::strtof(item.c_str() + 3, nullptr); v.has_af = true; }
-    }
-    for (size_t i = 9; i < rec.size() && i - 9 < d.ids.size(); ++i) {
-      auto parts = split(rec[i], ':');
-      const std::string gt = gti < (int)parts.size() ? parts[(size_t)gti] : ".";
-      bool has_variation = false;  // genotype.foldLeft(false)(_ || _ > 0), :58
-      size_t b = 0;
-      for (size_t p = 0; p <= gt.size(); ++p) {
-        if (p == gt.size() || gt[p] == '/' || gt[p] == '|') {
-          const std::string allele = gt.substr(b, p - b);
-          if (!allele.empty() && allele != "." && std::atoi(allele.c_str()) > 0) has_variation = true;
-          b = p + 1;
+  if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+  for (;;) {
+    double t0 = now_s();
+    if (!in.next(block)) break;
+    g_ingest_read_s += now_s() - t0;
+    t0 = now_s();
+    // line starts of this block; header lines are handled here, data lines go to the pool
+    std::vector<std::pair<const char*, const char*>> lines;
+    const char* p = block.data();
+    const char* bend = p + block.size();
+    while (p < bend) {
+      const char* nl = static_cast<const char*>(std::memchr(p, '\n', (size_t)(bend - p)));
+      const char* le = nl ? nl : bend;
+      const char* lb = p;
+      p = nl ? nl + 1 : bend;
+      if (le > lb && le[-1] == '\r') --le;
+      if (le == lb) continue;
+      if (lb[0] == '#') {
+        if (le - lb >= 6 && std::memcmp(lb, "#CHROM", 6) == 0) {
+          const char* q = lb;
+          for (int i = 0; q < le; ++i) {
+            const std::string_view col = next_field(q, le, '\t');
+            if (i >= 9) {
+              d.names.emplace_back(col);
+              d.ids.push_back(stem + "-" + std::to_string(i - 9));
+            }
+          }
+          header = true;
         }
+        continue;
       }
-      v.calls.push_back({has_variation, index_base + (int32_t)(i - 9)});
+      if (!header) die("VCF header line (#CHROM) missing in " + path);
+      lines.emplace_back(lb, le);
     }
-    d.variants.push_back(std::move(v));
+    g_ingest_split_s += now_s() - t0;
+    t0 = now_s();
+    std::vector<ParsedLine> parsed(lines.size());
+    const size_t nt = std::min<size_t>((size_t)n_threads, std::max<size_t>(1, lines.size() / 64));
+    auto work = [&](size_t t) {
+      const size_t lo = lines.size() * t / nt, hi = lines.size() * (t + 1) / nt;
+      for (size_t i = lo; i < hi; ++i)
+        parse_record(lines[i].first, lines[i].second, regions, index_base, d.ids.size(), debug, parsed[i]);
+    };
+    if (nt <= 1) {
+      work(0);
+    } else {
+      std::vector<std::thread> pool;
+      for (size_t t = 0; t < nt; ++t) pool.emplace_back(work, t);
+      for (auto& th : pool) th.join();
+    }
+    for (auto& pl : parsed) {
+      if (!pl.keep) continue;
+      if (debug) std::fputs(pl.debug.c_str(), stdout);
+      d.variants.push_back(std::move(pl.v));
+    }
+    g_ingest_parse_s += now_s() - t0;
   }
   if (!header) die("no #CHROM header in " + path);
   return d;
@@ -300,6 +392,7 @@ void check(pcoa_ctx* ctx, int rc, const char* what) {
 }  // namespace
 
 int main(int argc, char** argv) {
+  const auto t_start = std::chrono::steady_clock::now();
   Conf conf = parse(argc, argv);
   if (conf.input_path.empty())
     die("--input-path <file.vcf[.gz]> [more files] is required: the Google Genomics API the reference read "
@@ -312,7 +405,7 @@ int main(int argc, char** argv) {
     std::vector<Region> regions;
     if (!conf.all_references && !conf.references.empty())
       regions = parse_references(conf.references[std::min(k, conf.references.size() - 1)]);
-    data.push_back(load_vcf(conf.input_path[k], regions, (int32_t)ids.size(), conf.debug_datasets));
+    data.push_back(load_vcf(conf.input_path[k], regions, (int32_t)ids.size(), conf.debug_datasets, conf.ingest_threads));
     ids.insert(ids.end(), data.back().ids.begin(), data.back().ids.end());
     names.insert(names.end(), data.back().names.begin(), data.back().names.end());
   }
@@ -332,9 +425,9 @@ int main(int argc, char** argv) {
   }
 
   // getCallsRdd (:153-168)
-  std::vector<std::vector<CallData>> callsets;
+  std::vector<std::vector<int32_t>> callsets;
   if (data.size() == 1) {
-    for (auto& v : data[0].variants) callsets.push_back(std::move(v.calls));
+    for (auto& v : data[0].variants) callsets.push_back(std::move(v.carriers));
   } else if (data.size() == 2) {  // joinDatasets
     std::unordered_map<std::string, std::vector<const Variant*>> right;
     for (const auto& v : data[1].variants) right[v.key].push_back(&v);
@@ -342,8 +435,8 @@ int main(int argc, char** argv) {
       auto it = right.find(v.key);
       if (it == right.end()) continue;
       for (const Variant* w : it->second) {
-        std::vector<CallData> joined = v.calls;
-        joined.insert(joined.end(), w->calls.begin(), w->calls.end());
+        std::vector<int32_t> joined = v.carriers;
+        joined.insert(joined.end(), w->carriers.begin(), w->carriers.end());
         callsets.push_back(std::move(joined));
       }
     }
@@ -353,18 +446,31 @@ int main(int argc, char** argv) {
       for (const auto& v : d.variants) groups[v.key].push_back(&v);
     for (const auto& g : groups) {
       if (g.second.size() != data.size()) continue;
-      std::vector<CallData> merged;
-      for (const Variant* v : g.second) merged.insert(merged.end(), v->calls.begin(), v->calls.end());
+      std::vector<int32_t> merged;
+      for (const Variant* v : g.second) merged.insert(merged.end(), v->carriers.begin(), v->carriers.end());
       callsets.push_back(std::move(merged));
     }
   }
   std::vector<int32_t> sample_idx;
   std::vector<int64_t> row_offsets{0};
   for (const auto& calls : callsets) {
-    size_t before = sample_idx.size();
-    for (const auto& c : calls)
-      if (c.has_variation) sample_idx.push_back(c.callset);
-    if (sample_idx.size() > before) row_offsets.push_back((int64_t)sample_idx.size());  // drop empty (:166)
+    if (calls.empty()) continue;  // variants without a varying call are dropped (:166)
+    sample_idx.insert(sample_idx.end(), calls.begin(), calls.end());
+    row_offsets.push_back((int64_t)sample_idx.size());
+  }
+  if (conf.parse_only) {
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    std::printf("Variants with variation: %zu; carriers: %zu; ingest + getCallsRdd %.3f s (read %.3f, split %.3f, "
+                "parse %.3f)\n", row_offsets.size() - 1, sample_idx.size(), secs, g_ingest_read_s, g_ingest_split_s,
+                g_ingest_parse_s);
+    if (!conf.output_path.empty()) {  // the RDD[Seq[Int]] of getCallsRdd, one variant per line
+      std::ofstream out(conf.output_path + "-carriers.txt");
+      for (size_t r = 0; r + 1 < row_offsets.size(); ++r) {
+        for (int64_t q = row_offsets[r]; q < row_offsets[r + 1]; ++q) out << (q > row_offsets[r] ? " " : "") << sample_idx[(size_t)q];
+        out << "\n";
+      }
+    }
+    return 0;
   }
   if (sample_idx.empty()) sample_idx.push_back(0);
 

@@ -228,6 +228,60 @@ def test_pack_bits_layout_is_the_one_pcoa_accumulate_bits_documents():
     assert b[0, 0] == (1 | (1 << 5)) and b[0, 1] == (1 << 1) and not b[1].any() and b[2, 2] == (1 << 5)
 
 
+def test_compiled_host_ingest_matches_python_ingest(tmp_path):
+    """variants_pca_driver --parse-only (no GPU): the zero-allocation, multi-threaded VCF reader of the C++ host yields
+    the same carrier lists (getCallsRdd, VariantsPca.scala:153-168) as the Python mirror, on awkward records."""
+    import gzip
+    import subprocess
+    ingest = load_pkg("ingest")
+    drv = os.path.join(ROOT, "spark-examples_amd", "variants_pca_driver")
+    if not os.path.exists(drv):
+        pytest.skip("compiled host not built")
+    rng = np.random.default_rng(21)
+    n = 37
+    names = ["S%02d" % i for i in range(n)]
+    gts = ["0|0", "0|1", "1|0", "1|1", "./.", ".", "0/2", "10|0", "0", "1", "0|0|0", "0/0/3", ".|1"]
+    lines = ["##fileformat=VCFv4.2", "##contig=<ID=17>",
+             "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names)]
+    for r in range(300):
+        fmt = ["GT", "GT:DP", "DP:GT", "DP:GT:GQ", "DP"][r % 5]
+        cells = []
+        for i in range(n):
+            gt = gts[int(rng.integers(len(gts)))] if rng.random() < 0.4 else "0|0"
+            cell = {"GT": gt, "GT:DP": gt + ":17", "DP:GT": "9:" + gt, "DP:GT:GQ": "31:" + gt + ":99", "DP": "5"}[fmt]
+            if fmt == "DP:GT:GQ" and i % 7 == 0:
+                cell = "31"           # trailing sub-fields dropped: GT missing for this call
+            cells.append(cell)
+        if r % 50 == 49:
+            cells = cells[:n - 5]     # a short record
+        chrom = ["17", "chr17", "X", "17"][r % 4]
+        lines.append("\t".join([chrom, str(41196312 + 13 * r), ".", "A", "G,T" if r % 3 == 0 else "G", "50", "PASS",
+                                "AF=0.1;DP=4", fmt] + cells))
+    text = "\n".join(lines) + "\n"
+    plain = str(tmp_path / "awk-ward.vcf")
+    open(plain, "w").write(text)
+    crlf = str(tmp_path / "crlf.vcf")
+    open(crlf, "w").write(text.replace("\n", "\r\n"))
+    gz = str(tmp_path / "zipped.vcf.gz")
+    with gzip.open(gz, "wt") as f:
+        f.write(text)
+    for path in (plain, crlf, gz):
+        for threads in ("1", "3"):
+            out = str(tmp_path / "o")
+            res = subprocess.run([drv, "--input-path", path, "--all-references", "--parse-only", "--ingest-threads", threads,
+                                  "--output-path", out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                 universal_newlines=True)
+            assert res.returncode == 0, res.stdout
+            assert "Matrix size: %d." % n in res.stdout
+            got = [[int(t) for t in l.split()] for l in open(out + "-carriers.txt").read().splitlines()]
+            ref_path = plain if path == crlf else path   # the Python reader keeps the \r of the last column
+            _, _, parts = ingest.load_vcf(ref_path, None)
+            _, idx, offs = parts[0]
+            want = [idx[offs[k]:offs[k + 1]].tolist() for k in range(len(offs) - 1)]
+            assert got == want, (path, threads)
+            assert len(want) > 100
+
+
 def test_hot_kernels_do_not_spill_to_scratch():
     """A register spill in a Gram kernel costs an order of magnitude (seen once: 1,632 B/lane of scratch made
     the i8 contraction 45x slower while every parity test stayed green).  hipcc reports it at compile time."""
