@@ -381,14 +381,17 @@ def main():
             xh = x[:hv].cpu().numpy()
             xh8 = xh.astype(np.uint8)
             pcie = {}
-            for name, arr, fn in (("host_fp32", xh, eng.accumulate_dense), ("host_uint8", xh8, eng.accumulate_dense_u8)):
+            xhb = pkg("ingest").pack_bits(xh8)
+            for name, arr, fn in (("host_fp32", xh, eng.accumulate_dense), ("host_uint8", xh8, eng.accumulate_dense_u8),
+                                  ("host_bits", xhb, eng.accumulate_bits)):
                 eng.reset(); fn(arr); eng.finalize(); eng.sync()
                 t1 = time.perf_counter()
                 eng.reset(); fn(arr); eng.finalize(); eng.sync()
                 pcie[name + "_variants_per_s"] = hv / (time.perf_counter() - t1)
-            pcie["note"] = "%d variants from pageable host memory, H2D included (pcoa_accumulate_dense_* with is_device_ptr=0)" % hv
+            pcie["note"] = ("%d variants from pageable host memory, H2D included (pcoa_accumulate_dense_f32 / _u8 / "
+                            "pcoa_accumulate_bits with is_device_ptr=0)" % hv)
             out["pcie_inclusive"] = pcie
-            del xh, xh8
+            del xh, xh8, xhb
         if world == 1 and not args.no_cpu_baseline:
             base, s_ref, sample = cpu_baseline(x, n)
             out["cpu_baseline"] = base
