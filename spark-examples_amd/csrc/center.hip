@@ -92,7 +92,19 @@ __global__ __launch_bounds__(256) void center_kernel(const int32_t* __restrict__
   }
 }
 
+__global__ __launch_bounds__(256) void col_means_kernel(const double* __restrict__ row_sums, int32_t n,
+                                                        double* __restrict__ cm) {
+#pragma clang fp contract(off)
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j < n) cm[j] = row_sums[j] / (double)n;
+}
+
 }  // namespace
+
+hipError_t launch_col_means(const double* row_sums, int32_t n, double* cm, hipStream_t stream) {
+  hipLaunchKernelGGL(col_means_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, row_sums, n, cm);
+  return hipGetLastError();
+}
 
 hipError_t launch_center(const int32_t* s32, const int64_t* s64_or_null, int32_t n, double* row_sums,
                          double* stats, int32_t* nz, double* b, hipStream_t stream) {

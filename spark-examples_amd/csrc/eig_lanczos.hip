@@ -89,6 +89,58 @@ __global__ __launch_bounds__(256) void symv_kernel(const double* __restrict__ a,
   if (lane == 0) y[i] = acc;
 }
 
+// y = B x with B evaluated on the fly from the integer similarity matrix (EigWorkspace, implicit form): the same
+// loop structure as symv_kernel, the same per-entry expression as center_kernel (no fused multiply-add in the
+// centring), so the result equals symv_kernel on the materialised B bit for bit -- at 4 (12) instead of 8 bytes per
+// entry and without the N x N fp64 matrix (80 GB at N = 100,000).
+template <bool HAS64>
+__global__ __launch_bounds__(256) void symv_centered_kernel(const int32_t* __restrict__ s32,
+                                                            const int64_t* __restrict__ s64, int n,
+                                                            const double* __restrict__ cm,
+                                                            const double* __restrict__ stats,
+                                                            const double* __restrict__ x, double* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int64_t base = (int64_t)i * n;
+  const double row_mean = cm[i];
+  const double mmean = stats[1];
+  auto entry = [&](int j) -> double {
+#pragma clang fp contract(off)
+    const double data = HAS64 ? (double)((int64_t)s32[base + j] + s64[base + j]) : (double)s32[base + j];
+    double t = data - row_mean;
+    t = t - cm[j];
+    t = t + mmean;
+    return t;
+  };
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+  int j = lane;
+  for (; j + 448 < n; j += 512) {
+    const double r0 = entry(j), r1 = entry(j + 64), r2 = entry(j + 128), r3 = entry(j + 192);
+    const double r4 = entry(j + 256), r5 = entry(j + 320), r6 = entry(j + 384), r7 = entry(j + 448);
+    acc0 += r0 * x[j] + r4 * x[j + 256];
+    acc1 += r1 * x[j + 64] + r5 * x[j + 320];
+    acc2 += r2 * x[j + 128] + r6 * x[j + 384];
+    acc3 += r3 * x[j + 192] + r7 * x[j + 448];
+  }
+  for (; j < n; j += 64) acc0 += entry(j) * x[j];
+  const double acc = wave_sum((acc0 + acc1) + (acc2 + acc3));
+  if (lane == 0) y[i] = acc;
+}
+
+void launch_symv(const EigWorkspace& ws, int n, const double* x, double* y, hipStream_t stream) {
+  const unsigned rows4 = (unsigned)((n + 3) / 4);
+  if (ws.a) {
+    hipLaunchKernelGGL(symv_kernel, dim3(rows4), dim3(256), 0, stream, ws.a, n, x, y);
+  } else if (ws.s64) {
+    hipLaunchKernelGGL(symv_centered_kernel<true>, dim3(rows4), dim3(256), 0, stream, ws.s32, ws.s64, n, ws.colmean,
+                       ws.stats, x, y);
+  } else {
+    hipLaunchKernelGGL(symv_centered_kernel<false>, dim3(rows4), dim3(256), 0, stream, ws.s32, ws.s64, n, ws.colmean,
+                       ws.stats, x, y);
+  }
+}
+
 // h[p] = V[p] . w   for p = 0 .. count-1 (one workgroup per p)
 __global__ __launch_bounds__(256) void cgs_dots_kernel(const double* __restrict__ v, int n,
                                                        const double* __restrict__ w, double* __restrict__ h) {
@@ -169,7 +221,7 @@ size_t lanczos_workspace_doubles(int32_t n, int32_t k, int32_t mmax) {
 
 // Returns hipSuccess on a clean run; *converged tells whether ws.z[0..k) holds verified eigenvectors of
 // B (unnormalised Ritz vectors; the caller normalises) and lam_sel_host[0..k) their eigenvalues
-// (ordered by decreasing magnitude).  B = ws.a is not modified.
+// (ordered by decreasing magnitude).  B (ws.a, or the implicit form when ws.a is null) is not modified.
 hipError_t lanczos_topk(const EigWorkspace& ws, double* lz, int32_t n, int32_t k, int32_t mmax, double tol,
                         double* lam_sel_host, int* converged, int* steps_out, hipStream_t stream) {
   *converged = 0;
@@ -190,7 +242,7 @@ hipError_t lanczos_topk(const EigWorkspace& ws, double* lz, int32_t n, int32_t k
   small.e = beta;
 
   hipLaunchKernelGGL(lanczos_init_kernel, dim3(1), dim3(1024), 0, stream, V, n);
-  const unsigned rows4 = (unsigned)((n + 3) / 4), nb = (unsigned)((n + 255) / 256);
+  const unsigned nb = (unsigned)((n + 255) / 256);
   // Ritz pairs are examined at m = 12, 16, 20, 24, then every 8 steps up to 64, then every m / 2: a check costs about
   // four steps (bisection + inverse iteration on T_m + two host round trips), and population structure converges
   // early (configs[1] stand-in: estimate 1e-14 at m = 12, true relative residual 3.7e-9)
@@ -201,7 +253,7 @@ hipError_t lanczos_topk(const EigWorkspace& ws, double* lz, int32_t n, int32_t k
   std::vector<int32_t> idx;
   for (int j = 0; j < mmax; ++j) {
     const double* vj = V + (size_t)j * n;
-    hipLaunchKernelGGL(symv_kernel, dim3(rows4), dim3(256), 0, stream, ws.a, n, vj, w);
+    launch_symv(ws, n, vj, w, stream);
     // (the five small kernels below fused into ONE workgroup were measured slower: 30 vs 24 us per step -- a single
     // CU cannot stream the ~2 MB of basis vectors a step touches as fast as j+1 workgroups can)
     hipLaunchKernelGGL(cgs_dots_kernel, dim3((unsigned)(j + 1)), dim3(256), 0, stream, V, n, w, h1);
@@ -279,8 +331,7 @@ hipError_t lanczos_topk(const EigWorkspace& ws, double* lz, int32_t n, int32_t k
     if ((e = hipMemcpyAsync(ws.z, bu, sizeof(double) * (size_t)k * n, hipMemcpyDeviceToDevice, stream)) != hipSuccess)
       return e;
     for (int t = 0; t < k; ++t)
-      hipLaunchKernelGGL(symv_kernel, dim3(rows4), dim3(256), 0, stream, ws.a, n, ws.z + (size_t)t * n,
-                         bu + (size_t)t * n);
+      launch_symv(ws, n, ws.z + (size_t)t * n, bu + (size_t)t * n, stream);
     hipLaunchKernelGGL(residual_kernel, dim3((unsigned)k), dim3(1024), 0, stream, bu, ws.z, n, ws.lam, res);
     if ((e = hipMemcpyAsync(hres.data(), res, sizeof(double) * k, hipMemcpyDeviceToHost, stream)) != hipSuccess)
       return e;

@@ -74,6 +74,7 @@ struct pcoa_ctx {
   bool ws_ready = false;
   EigWorkspace ws{};
   double* row_sums = nullptr;      // [n]
+  double* colmean = nullptr;       // [n] rowSums / N (implicit form of B for the Lanczos path)
   double* stats = nullptr;         // [2 + n] (sum, mean, then int64 row sums)
   int32_t* nz = nullptr;           // [1]
   double* out_dev = nullptr;       // [kmax][n]
@@ -373,7 +374,8 @@ int check_device_flags(pcoa_ctx* c) {
 int ensure_workspace(pcoa_ctx* c, int32_t k) {
   const int64_t n = c->n;
   if (!c->ws_ready) {
-    HIP_TRY(c, hipMalloc((void**)&c->ws.a, sizeof(double) * (size_t)(n * n)));
+    // ws.a (the N x N fp64 matrix B) is allocated lazily by ensure_b(): the Lanczos path evaluates B on the fly
+    HIP_TRY(c, hipMalloc((void**)&c->colmean, sizeof(double) * (size_t)n));
     HIP_TRY(c, hipMalloc((void**)&c->ws.d, sizeof(double) * (size_t)n));
     HIP_TRY(c, hipMalloc((void**)&c->ws.e, sizeof(double) * (size_t)n));
     HIP_TRY(c, hipMalloc((void**)&c->ws.tau, sizeof(double) * (size_t)n));
@@ -399,6 +401,13 @@ int ensure_workspace(pcoa_ctx* c, int32_t k) {
     HIP_TRY(c, hipMalloc((void**)&c->out_dev, sizeof(double) * (size_t)((int64_t)k * n)));
     c->kmax = k;
   }
+  return PCOA_OK;
+}
+
+int ensure_b(pcoa_ctx* c) {
+  if (c->ws.a) return PCOA_OK;
+  const int64_t n = c->n;
+  HIP_TRY(c, hipMalloc((void**)&c->ws.a, sizeof(double) * (size_t)(n * n)));
   return PCOA_OK;
 }
 
@@ -513,7 +522,7 @@ void pcoa_destroy(pcoa_ctx* c) {
   for (auto& ev : c->pool) (void)hipEventDestroy(ev);
   void* bufs[] = {c->s32, c->s64, c->zeros, c->err_flag, c->tile, c->csr_idx, c->csr_offs, c->thr_dev,
                   c->sample_pop, c->xfer, c->coll, c->fp4_flag, c->pack_buf, c->lanczos_ws, c->ws.a, c->ws.d, c->ws.e, c->ws.tau, c->ws.q, c->ws.w, c->ws.lam,
-                  c->ws.z, c->ws.scratch, c->ws.iscratch, c->row_sums, c->stats, c->nz,
+                  c->ws.z, c->ws.scratch, c->ws.iscratch, c->row_sums, c->colmean, c->stats, c->nz,
                   c->out_dev};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -916,6 +925,7 @@ int pcoa_center_read_f64(pcoa_ctx* c, double* out_b, double* out_row_sums, int32
   if (rc != PCOA_OK) return rc;
   rc = ensure_workspace(c, 1);
   if (rc != PCOA_OK) return rc;
+  if (out_b && (rc = ensure_b(c)) != PCOA_OK) return rc;
   const size_t n = (size_t)c->n;
   {
     ScopedTimer t(c, T_CENTER);
@@ -955,17 +965,30 @@ int pcoa_compute(pcoa_ctx* c, int32_t num_pc, double* out_components, double* ou
   hipEvent_t w0 = get_event(c), w1 = get_event(c);
   if (w0) (void)hipEventRecord(w0, c->stream);
 
+  const bool force_householder = (c->flags & PCOA_FLAG_EIG_HOUSEHOLDER) != 0;
+  const bool force_lanczos = (c->flags & PCOA_FLAG_EIG_LANCZOS) != 0;
+  const bool try_lanczos = !force_householder && n >= 32;
+  // The Lanczos path evaluates B on the fly inside its matvec (bit-identical entries, half the bytes, no N x N fp64
+  // matrix); B is only materialised for the dense solver.  PCOA_EXPLICIT_CENTER=1 restores the materialised form.
+  static const bool explicit_env = std::getenv("PCOA_EXPLICIT_CENTER") != nullptr;
+  const bool explicit_b = !try_lanczos || explicit_env;
+  if (explicit_b && (rc = ensure_b(c)) != PCOA_OK) return rc;
   {
     ScopedTimer t(c, T_CENTER);
-    HIP_TRY(c, launch_center(c->s32, c->s64, n, c->row_sums, c->stats, c->nz, c->ws.a, c->stream));
+    HIP_TRY(c, launch_center(c->s32, c->s64, n, c->row_sums, c->stats, c->nz, explicit_b ? c->ws.a : nullptr,
+                             c->stream));
+    HIP_TRY(c, launch_col_means(c->row_sums, n, c->colmean, c->stream));
   }
+  c->ws.s32 = c->s32;
+  c->ws.s64 = c->s64;
+  c->ws.colmean = c->colmean;
+  c->ws.stats = c->stats;
+  bool b_ready = explicit_b;
   std::vector<double> sel((size_t)num_pc);
   bool have_vectors = false;
   c->eig_method = 0;
   c->lanczos_steps = 0;
-  const bool force_householder = (c->flags & PCOA_FLAG_EIG_HOUSEHOLDER) != 0;
-  const bool force_lanczos = (c->flags & PCOA_FLAG_EIG_LANCZOS) != 0;
-  if (!force_householder && n >= 32) {
+  if (try_lanczos) {
     // fast path: Lanczos on B for the k wanted pairs, accepted only with a verified residual
     const int32_t mmax = std::min<int32_t>(n, 512);
     const int64_t need = (int64_t)lanczos_workspace_doubles(n, num_pc, mmax);
@@ -974,7 +997,9 @@ int pcoa_compute(pcoa_ctx* c, int32_t num_pc, double* out_components, double* ou
     int conv = 0, steps = 0;
     {
       ScopedTimer t(c, T_LANCZOS);
-      HIP_TRY(c, lanczos_topk(c->ws, c->lanczos_ws, n, num_pc, mmax, 1e-11, sel.data(), &conv, &steps, c->stream));
+      EigWorkspace wl = c->ws;
+      if (!b_ready) wl.a = nullptr;  // implicit form
+      HIP_TRY(c, lanczos_topk(wl, c->lanczos_ws, n, num_pc, mmax, 1e-11, sel.data(), &conv, &steps, c->stream));
     }
     c->lanczos_steps = steps;
     if (conv) {
@@ -991,6 +1016,12 @@ int pcoa_compute(pcoa_ctx* c, int32_t num_pc, double* out_components, double* ou
   if (!have_vectors) {
     // exact, gap-independent path: Householder tridiagonalisation + bisection + inverse iteration
     c->eig_method = 2;
+    if (!b_ready) {  // the dense solver needs B in memory
+      if ((rc = ensure_b(c)) != PCOA_OK) return rc;
+      ScopedTimer t(c, T_CENTER);
+      HIP_TRY(c, launch_center(c->s32, c->s64, n, c->row_sums, c->stats, c->nz, c->ws.a, c->stream));
+      b_ready = true;
+    }
     {
       ScopedTimer t(c, T_TRIDIAG);
       HIP_TRY(c, launch_tridiagonalize(c->ws, n, c->stream));

@@ -65,6 +65,8 @@ hipError_t launch_synth_fill_f32(uint64_t seed, const uint32_t* thresholds_dev, 
 // ---- centring (center.hip) --------------------------------------------------------------------
 // s = s32 + (s64 ? s64 : 0).  row_sums[n] (fp64), stats[0] = matrix sum, stats[1] = matrix mean,
 // nz[0] = #rows with sum > 0.  b = centred matrix fp64 [n][n].
+// cm[j] = rowSums(j) / N (the division center_kernel performs per entry, done once)
+hipError_t launch_col_means(const double* row_sums, int32_t n, double* cm, hipStream_t stream);
 hipError_t launch_center(const int32_t* s32, const int64_t* s64_or_null, int32_t n, double* row_sums,
                          double* stats, int32_t* nz, double* b, hipStream_t stream);
 
@@ -80,6 +82,13 @@ struct EigWorkspace {
   double* z;        // [kmax][n] eigenvectors of T, then of A (column c at z + c*n)
   double* scratch;  // [6][n] LU factors for inverse iteration
   int32_t* iscratch;// [2n + 64] pivots / eigenvalue indices
+  // Implicit form of B for the Lanczos path: B(i,j) = ((S(i,j) - rowmean(i)) - colmean(j)) + mean is evaluated on
+  // the fly from the integer S (the same expression, operation order and rounding as center_kernel, so the matvec sees
+  // bit-identical entries) and the N x N fp64 matrix is never written.  a == nullptr then.
+  const int32_t* s32;     // [n][n]
+  const int64_t* s64;     // [n][n] or nullptr
+  const double* colmean;  // [n] rowSums(j) / N
+  const double* stats;    // stats[1] = matrixMean
 };
 hipError_t launch_tridiagonalize(const EigWorkspace& ws, int32_t n, hipStream_t stream);
 // eigenvalues with ascending indices idx[0..count) of T -> lam_out[0..count) (device)

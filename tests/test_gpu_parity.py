@@ -556,6 +556,39 @@ def test_larger_sample_count_many_tiles(P, O):
           (1e3 * t["compute_total_seconds"], t["eig_method"], t["lanczos_steps"]))
 
 
+def test_implicit_centring_matvec_equals_the_materialised_b(P, O):
+    """The Lanczos path evaluates B(i,j) on the fly from the integer S (no N x N fp64 matrix); with
+    PCOA_EXPLICIT_CENTER=1 it runs on the materialised B.  Same per-entry expression and loop order => the same
+    eigenpairs to the last bit; both within the parity bar of the oracle.  Also with a folded int64 part of S."""
+    rng = np.random.default_rng(31)
+    n, v = 700, 4000
+    x = (rng.random((v, n)) < rng.uniform(0.02, 0.4, size=(v, 1))).astype(np.float32)
+    x[:, :250] *= (rng.random((v, 1)) < 0.7)      # population structure
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r);"
+            "from conftest import load_pkg; P = load_pkg(); x = np.load(sys.argv[1]);"
+            "e = P.PcoaEngine(x.shape[1]); e.accumulate_dense(x); e.accumulate_dense(x[:100]);"
+            "c, l, nz = e.compute(3); t = e.timings(); assert t['eig_method'] == 1;"
+            "np.save(sys.argv[2], np.concatenate([c.ravel(), l]))") % (ROOT, os.path.join(ROOT, "tests"))
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        np.save(os.path.join(td, "x.npy"), x)
+        res = {}
+        for name, extra in (("implicit", {}), ("explicit", {"PCOA_EXPLICIT_CENTER": "1"}),
+                            ("implicit64", {"PCOA_DEBUG_FOLD_THRESHOLD": "1000"}),
+                            ("explicit64", {"PCOA_EXPLICIT_CENTER": "1", "PCOA_DEBUG_FOLD_THRESHOLD": "1000"})):
+            env = dict(os.environ, **extra)
+            subprocess.check_call([sys.executable, "-c", code, os.path.join(td, "x.npy"), os.path.join(td, name + ".npy")],
+                                  env=env)
+            res[name] = np.load(os.path.join(td, name + ".npy"))
+    assert np.array_equal(res["implicit"], res["explicit"])
+    assert np.array_equal(res["implicit64"], res["explicit64"])
+    assert np.abs(res["implicit"] - res["implicit64"]).max() < 1e-9
+    s = O.similarity_from_dense(x, n) + O.similarity_from_dense(x[:100], n)
+    ref = O.compute_pca(s, 3)
+    got = res["implicit"][:3 * n].reshape(n, 3)
+    assert np.abs(align_sign(got, ref["components"]) - ref["components"]).max() < EIG_TOL
+
+
 # ------------------------------------------------------------------------------------------ multi-GPU plumbing
 def test_native_rccl_allreduce_single_rank(P, O):
     rng = np.random.default_rng(4)
