@@ -2,8 +2,8 @@
 """BASELINE configs[3]: biobank-scale N on ONE MI355X -- synthetic 100,000 samples x V variants.
 
 The reference cannot run this at all (Breeze DenseMatrix[Int] needs N^2 < 2^31, N <= 46,340; MLlib RowMatrix
-N <= 65,535 -- BASELINE.md section 1).  Here S (int32, 40 GB), the centred matrix B (fp64, 80 GB) and the int8
-operand workspace live in one 288 GB HBM; genotypes are generated on the device chunk by chunk (the fp32 input,
+N <= 65,535 -- BASELINE.md section 1).  Here S (int32, 40 GB) and the operand workspace live in one 288 GB HBM; the
+centred matrix B (80 GB in fp64) is never written: the Lanczos matvec evaluates it on the fly from S; genotypes are generated on the device chunk by chunk (the fp32 input,
 400 GB for 10^6 variants, never exists as a whole).
 
 Checks (no CPU oracle can hold this):
@@ -12,7 +12,7 @@ Checks (no CPU oracle can hold this):
   * two far-apart off-diagonal blocks are each other's transpose (the mirror of the computed triangle);
   * the eigenpairs come back only after the engine's own on-device residual test ||B u - theta u|| passed.
 Usage: python tools/config4_biobank.py [--samples 100000] [--variants 1000000]
-Not part of pytest: it needs ~125 GB of HBM and ~1 minute.
+Not part of pytest: it needs ~50 GB of HBM and a few seconds.
 """
 import argparse
 import importlib
