@@ -73,7 +73,7 @@ def main():
     t_pcoa = time.perf_counter() - t1
     tim2 = eng.timings()
     out = {
-        "workload": "configs[3]: synthetic %d samples x %d variants, 1x MI355X (Gram + eig on one GPU)" % (n, v),
+        "workload": "biobank scale (configs[3] = 100,000 x 10^6; configs[4] sample count = 250,000): synthetic %d samples x %d variants, 1x MI355X (Gram + eig on one GPU)" % (n, v),
         "device": name, "cu_count": cus,
         "gram_wall_s": t_gram_wall, "host_threshold_generation_s": t_host,
         "gram_kernel_s": tim["gram_kernel_seconds"], "pack_s": tim["pack_seconds"], "synth_s": tim["synth_seconds"],
