@@ -1,37 +1,34 @@
-// gram_i8.hip -- S += X^T X on the int8 matrix cores of gfx950 (v_mfma_i32_32x32x32_i8), exact.
+// gram_packed.hip -- S += X^T X on the low-precision matrix cores of gfx950, exact.
 //
-// Same contraction as gram_f32.hip (reference VariantsPca.scala:184-190), computed in the reference's
-// own arithmetic: int32 counts (`DenseMatrix.zeros[Int]`, :185).  Genotype indicators are 0/1 (carrier
-// multiplicities <= 127 are accepted), so int8 operands lose nothing and the int32 accumulators are
-// exact to 2^31 -- but the i8 MFMA runs at 32x the rate of the fp32 MFMA (~5 POP/s dense vs 157 TF/s).
+// Same contraction as gram_f32.hip (reference VariantsPca.scala:184-190), computed in the reference's own
+// arithmetic: integer counts (`DenseMatrix.zeros[Int]`, :185).  Genotype indicators are 0/1, so nothing is lost in
+// low-precision operands as long as the accumulation is exact:
 //
-// Two kernels:
+//   FMT 1 (default, binary tiles)   MX-FP4 E2M1 operands (0 -> 0x0, 1.0 -> 0x2), v_mfma_f32_32x32x64_f8f6f4 in
+//                                   its unscaled form, fp32 accumulators (exact below 2^24; a launch feeds at most
+//                                   2^20 variants through one chain), ~10 PFLOP/s dense
+//   FMT 0 (carrier multiplicities)  int8 operands (0..127), v_mfma_i32_32x32x32_i8, int32 accumulators, ~5 POP/s
 //
-//  pack_f32_i8_kernel   X fp32 [V][ld]  ->  P int8 [V/16][Npad][16]            (HBM-bound, once per variant)
-//      "k-blocked" layout: the 16 bytes at P[kb][i] are sample i's indicators for variants
-//      16*kb .. 16*kb+15.  That is exactly one lane's operand slice of v_mfma_i32_32x32x32_i8, for the
-//      A operand (row i) and for the B operand (column j) alike -- X^T X uses the same k-slot mapping
-//      on both sides, so any consistent order of the 16 k's inside a block gives the same sum.
-//      Reads 4 B and writes 1 B per genotype: 12.5 GB per 10^6 variants at N = 2504.
+// Operand layout P[kb][Npad][16 B], "k-blocked": the 16 bytes at P[kb][i] are sample i's indicators for the 32 (FP4)
+// or 16 (int8) variants of k-block kb.  That is exactly one lane's operand slice of the MFMA, for the A operand
+// (row i) and for the B operand (column j) alike -- X^T X uses the same k-slot mapping on both sides, so any
+// consistent order of the k's inside a block gives the same sum -- and the LDS image IS the global image.
 //
-//  gram_i8_kernel       P -> S32 (upper-triangular 256x256 tiles, split-K, integer atomics)
-//      512 threads = 8 waves as 2(M) x 4(N), each wave a 128x64 block = 4x2 MFMA tiles
-//      (128 int32 accumulators per lane).  One stage = 64 variants = 4 k-blocks x 2 panels x 256
-//      samples x 16 B = 32 KiB, brought in by 32 global_load_lds_dwordx4 (1 KiB each, the LDS image IS
-//      the global image), 3-stage ring (96 KiB), ONE raw s_barrier per stage, counted vmcnt (two
-//      stages stay in flight).  Operand reads are ds_read_b128 of 32 consecutive 16-B slots per
-//      half-wave: conflict-free.  MFMA-bound: per stage a wave issues 16 MFMAs (512 cycles) against
-//      12 ds_read_b128 and 4 DMA instructions.
+// Pre-passes (HBM-bound, one per boundary of include/pcoa.h; all of them zero the padding):
+//   pack_fp4_kernel<float|uint8>   dense tile -> FP4; verifies that every value is exactly 0 or 1 (flag bit 3)
+//   pack_u8x8_fp4_kernel           uint8 tile, 8-byte loads, byte-gather + spread8
+//   expand_bits_fp4_kernel         carrier bitsets (1 bit per genotype) -> FP4 via v_readlane + lane-mask select
+//   pack_f32_i8_kernel / pack_u8_i8_kernel / densify_csr_i8_kernel    -> int8 (values 0..127, flag bit 2 otherwise)
 //
-// FP4 variant (FMT = 1): binary genotypes are exactly representable in MX-FP4 (E2M1: 0 -> 0x0, 1.0 -> 0x2), and
-// v_mfma_f32_32x32x64_f8f6f4 (the unscaled form: no block scale is applied) runs at twice the i8 rate on HALF the operand
-// bytes: a k-block is then 32 variants (still 16 B per lane), products are 0/1 and the fp32 accumulators are
-// exact below 2^24 (a launch never exceeds that).  The contraction kernel is the same template; only the
-// MFMA instruction, the accumulator type and the pre-pass differ.  Tiles that hold anything but 0/1 are
-// re-run through the int8 path by the host (pcoa_capi.hip).
+// gram_packed_kernel<FMT, ...>      P -> S32: upper-triangular 256x256 tiles x split-K, integer atomics.
+//   512 threads = 8 waves as 2(M) x 4(N), each wave a 128x64 block = 4x2 MFMA tiles (128 accumulators per lane).
+//   One stage = 4 k-blocks x 2 panels x 256 samples x 16 B = 32 KiB, brought in by 32 global_load_lds_dwordx4 (1 KiB
+//   each), 3-stage LDS ring (96 KiB), counted vmcnt (two stages stay in flight), raw s_barrier (never
+//   __syncthreads, which would drain the DMA queue).  Operand reads are ds_read_b128 of 32 consecutive 16-B slots per
+//   half-wave: conflict-free.  Default schedule: ping-pong (two wave groups half a stage apart, see below);
+//   PCOA_GRAM_I8_CFG=43 selects the in-phase ring.
 //
-// Roofline: i8 MFMA, peak ~5 POP/s dense (2x the bf16 rate, MI355X_MICROARCH.md); algorithmic
-// intensity of the packed operands N/0.5 = 5008 op/B, so HBM is irrelevant once packed.
+// Measured, N = 2504, 10^6 variants per launch: FP4 1.24 ms (5.5 PFLOP/s issued), int8 2.20 ms; DESIGN.md 4.0 / 4.0a.
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -745,7 +742,7 @@ __device__ __forceinline__ void tile_coords(int tile, int ntile, int& row_blk, i
 }
 
 template <int FMT, int NWM, int NNI, int SKB, int NST, bool PP>
-__global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram_i8_kernel(
+__global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram_packed_kernel(
     const int8_t* __restrict__ p, int npad, int64_t nstages, int n, int ntile, int ntri, int splitk,
     int64_t stages_per, int32_t* __restrict__ s32, int xcd_map) {
   __shared__ __attribute__((aligned(16))) StageI8<NWM, SKB> lds[NST];
@@ -846,7 +843,7 @@ __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram
 
 }  // namespace
 
-int64_t gram_i8_npad(int32_t n) { return ((int64_t)n + TM - 1) / TM * TM; }
+int64_t gram_packed_npad(int32_t n) { return ((int64_t)n + TM - 1) / TM * TM; }
 // k-blocks (16 variants for int8, 32 for FP4; 16 B per sample either way) are padded to a multiple of 24 so
 // that every stage depth (4, 6 or 8 k-blocks) divides the count
 int64_t gram_kb_pad(int64_t nv, int fmt) {
@@ -854,15 +851,15 @@ int64_t gram_kb_pad(int64_t nv, int fmt) {
   const int64_t nkb = (nv + per - 1) / per;
   return (nkb + 23) / 24 * 24;
 }
-int64_t gram_i8_kb_pad(int64_t nv) { return gram_kb_pad(nv, 0); }
-size_t gram_i8_workspace_bytes(int32_t n, int64_t nv) {  // the int8 size also covers the (half as large) FP4 operand
-  return (size_t)gram_i8_kb_pad(nv) * (size_t)gram_i8_npad(n) * KB;
+int64_t gram_packed_kb_pad_i8(int64_t nv) { return gram_kb_pad(nv, 0); }
+size_t gram_packed_workspace_bytes(int32_t n, int64_t nv) {  // the int8 size also covers the (half as large) FP4 operand
+  return (size_t)gram_packed_kb_pad_i8(nv) * (size_t)gram_packed_npad(n) * KB;
 }
 
 hipError_t launch_pack_fp4(const void* x, int is_u8, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
                            hipStream_t stream) {
   if (nv <= 0) return hipSuccess;
-  const int npad = (int)gram_i8_npad(n);
+  const int npad = (int)gram_packed_npad(n);
   const int64_t nkb_pad = gram_kb_pad(nv, 1);
   const int64_t threads = nkb_pad * (npad >> 2);
   const int64_t blocks = (threads + 255) / 256;
@@ -894,7 +891,7 @@ hipError_t launch_pack_fp4(const void* x, int is_u8, int64_t ld, int64_t nv, int
 hipError_t launch_expand_bits_fp4(const uint32_t* bits, int64_t ld_words, int64_t nv, int32_t n, int8_t* p,
                                   hipStream_t stream) {
   if (nv <= 0) return hipSuccess;
-  const int npad = (int)gram_i8_npad(n);
+  const int npad = (int)gram_packed_npad(n);
   const int64_t nkb_pad = gram_kb_pad(nv, 1);
   const int64_t blocks = nkb_pad * (npad >> 8) / 4;  // nkb_pad is a multiple of 24: whole blocks of 4 waves
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
@@ -911,8 +908,8 @@ hipError_t launch_expand_bits_fp4(const uint32_t* bits, int64_t ld_words, int64_
 hipError_t launch_pack_f32_i8(const float* x, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
                               hipStream_t stream) {
   if (nv <= 0) return hipSuccess;
-  const int npad = (int)gram_i8_npad(n);
-  const int64_t nkb_pad = gram_i8_kb_pad(nv);
+  const int npad = (int)gram_packed_npad(n);
+  const int64_t nkb_pad = gram_packed_kb_pad_i8(nv);
   const int64_t threads = nkb_pad * (npad >> 2);
   const int64_t blocks = (threads + 255) / 256;
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
@@ -929,8 +926,8 @@ hipError_t launch_pack_f32_i8(const float* x, int64_t ld, int64_t nv, int32_t n,
 hipError_t launch_pack_u8_i8(const uint8_t* x, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
                              hipStream_t stream) {
   if (nv <= 0) return hipSuccess;
-  const int npad = (int)gram_i8_npad(n);
-  const int64_t nkb_pad = gram_i8_kb_pad(nv);
+  const int npad = (int)gram_packed_npad(n);
+  const int64_t nkb_pad = gram_packed_kb_pad_i8(nv);
   const int64_t threads = nkb_pad * (npad >> 2);
   const int64_t blocks = (threads + 255) / 256;
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
@@ -943,10 +940,10 @@ hipError_t launch_pack_u8_i8(const uint8_t* x, int64_t ld, int64_t nv, int32_t n
 hipError_t launch_densify_csr_i8(const int32_t* idx_dev, const int64_t* offs_dev, int64_t nv, int64_t offs_base,
                                  int8_t* p, int32_t n, int32_t* flag, hipStream_t stream) {
   if (nv <= 0) return hipSuccess;
-  hipError_t e = hipMemsetAsync(p, 0, gram_i8_workspace_bytes(n, nv), stream);
+  hipError_t e = hipMemsetAsync(p, 0, gram_packed_workspace_bytes(n, nv), stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(densify_csr_i8_kernel, dim3((unsigned)((nv + 3) / 4)), dim3(256), 0, stream, idx_dev, offs_dev,
-                     nv, offs_base, p, (int)gram_i8_npad(n), n, flag);
+                     nv, offs_base, p, (int)gram_packed_npad(n), n, flag);
   return hipGetLastError();
 }
 
@@ -968,7 +965,7 @@ hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, i
     return (t == 43 || t == 44 || t == 144) ? t : 143;  // 1xx = ping-pong schedule (default), xx = in-phase ring
   }();
   const int skb = (cfg % 100) / 10;
-  const int npad = (int)gram_i8_npad(n);
+  const int npad = (int)gram_packed_npad(n);
   const int ntile = npad / TJ;
   const int64_t ntri64 = (int64_t)ntile * (ntile + 1) / 2;
   if (ntri64 > (1 << 28)) return hipErrorInvalidValue;
@@ -997,10 +994,10 @@ hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, i
 #define PCOA_LAUNCH_I8(SKB_, NST_, PP_)                                                                            \
   do {                                                                                                          \
     if (fmt == 1)                                                                                               \
-      hipLaunchKernelGGL((gram_i8_kernel<1, 2, 2, SKB_, NST_, PP_>), grid, block, 0, stream, p, npad, nstages, n, ntile, \
+      hipLaunchKernelGGL((gram_packed_kernel<1, 2, 2, SKB_, NST_, PP_>), grid, block, 0, stream, p, npad, nstages, n, ntile, \
                          ntri, (int)splitk, stages_per, s32, xcd_map);                                          \
     else                                                                                                        \
-      hipLaunchKernelGGL((gram_i8_kernel<0, 2, 2, SKB_, NST_, PP_>), grid, block, 0, stream, p, npad, nstages, n, ntile, \
+      hipLaunchKernelGGL((gram_packed_kernel<0, 2, 2, SKB_, NST_, PP_>), grid, block, 0, stream, p, npad, nstages, n, ntile, \
                          ntri, (int)splitk, stages_per, s32, xcd_map);                                          \
   } while (0)
   switch (cfg) {

@@ -253,7 +253,7 @@ int fold_if_needed(pcoa_ctx* c, int64_t cur) {
 //          multiplicity the chunk is re-packed as int8 and contracted on the i8 MFMA instead;
 //   fp4  : FP4 only, a non-binary value is an error;   i8 : int8 only (values 0..127).
 int packed_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64_t ld) {
-  const int64_t need = (int64_t)gram_i8_workspace_bytes(c->n, cur);
+  const int64_t need = (int64_t)gram_packed_workspace_bytes(c->n, cur);
   int rc = ensure(c, &c->pack_buf, &c->pack_cap, need);
   if (rc != PCOA_OK) return rc;
   const double in_bytes = (is_u8 ? 1.0 : 4.0) * (double)cur * (double)c->n;
@@ -479,7 +479,7 @@ int pcoa_create(pcoa_ctx** out, int32_t n_samples, int32_t device_ordinal, uint3
   c->gram_kind = c->use_i8 ? (c->packed_mode == 2 ? 2 : 3) : 1;
   {
     // keep the int8 workspace at or below ~4 GiB whatever N is (one byte per genotype, Npad columns)
-    const int64_t by_mem = (((int64_t)4 << 30) / gram_i8_npad(n_samples)) / 1536 * 1536;
+    const int64_t by_mem = (((int64_t)4 << 30) / gram_packed_npad(n_samples)) / 1536 * 1536;
     c->pack_chunk = std::max<int64_t>(1536, std::min<int64_t>(c->pack_chunk, by_mem));
   }
   if (const char* pc = std::getenv("PCOA_DEBUG_PACK_CHUNK")) {
@@ -616,7 +616,7 @@ int gram_device_bits(pcoa_ctx* c, const uint32_t* bits_dev, int64_t nv, int64_t 
     const int64_t cur = std::min(nv - done, max_cur);
     int rc = fold_if_needed(c, cur);
     if (rc != PCOA_OK) return rc;
-    const int64_t need = (int64_t)gram_i8_workspace_bytes(c->n, cur);
+    const int64_t need = (int64_t)gram_packed_workspace_bytes(c->n, cur);
     rc = ensure(c, &c->pack_buf, &c->pack_cap, need);
     if (rc != PCOA_OK) return rc;
     {
@@ -709,7 +709,7 @@ int pcoa_accumulate_calls(pcoa_ctx* c, const int32_t* sample_idx, const int64_t*
       // carriers -> k-blocked int8 operand directly (no fp32 tile, no pre-pass), then the i8 contraction
       rc = fold_if_needed(c, rows);
       if (rc != PCOA_OK) return rc;
-      rc = ensure(c, &c->pack_buf, &c->pack_cap, (int64_t)gram_i8_workspace_bytes(c->n, rows));
+      rc = ensure(c, &c->pack_buf, &c->pack_cap, (int64_t)gram_packed_workspace_bytes(c->n, rows));
       if (rc != PCOA_OK) return rc;
       {
         ScopedTimer t(c, T_DENSIFY);

@@ -16,7 +16,7 @@ namespace pcoa {
 constexpr int kWave = 64;     // CDNA wavefront
 constexpr int kNumXcd = 8;    // MI355X: block b is dispatched to XCD b % 8 (speed only, never correctness)
 
-// ---- Gram kernels (gram_f32.hip / gram_i8.hip) ------------------------------------------------
+// ---- Gram kernels (gram_f32.hip / gram_packed.hip) ------------------------------------------------
 struct GramLaunch {
   const float* x;        // device, [nv][ld] carrier multiplicities (0/1)
   int64_t ld;
@@ -29,10 +29,11 @@ struct GramLaunch {
 };
 // Returns hipSuccess or the launch error.  *splitk_out (optional) receives the split-K factor used.
 hipError_t launch_gram_f32(const GramLaunch& g, int* splitk_out);
-// i8 path (gram_i8.hip): pack fp32 -> k-blocked int8 workspace, then the i8-MFMA contraction.
-int64_t gram_i8_npad(int32_t n);
-int64_t gram_i8_kb_pad(int64_t nv);
-size_t gram_i8_workspace_bytes(int32_t n, int64_t nv);
+// packed-operand path (gram_packed.hip): re-layout pre-pass into the k-blocked FP4 / int8 workspace, then the
+// matrix-core contraction.
+int64_t gram_packed_npad(int32_t n);
+int64_t gram_packed_kb_pad_i8(int64_t nv);
+size_t gram_packed_workspace_bytes(int32_t n, int64_t nv);
 hipError_t launch_pack_f32_i8(const float* x, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
                               hipStream_t stream);
 hipError_t launch_pack_u8_i8(const uint8_t* x, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,

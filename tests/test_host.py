@@ -293,7 +293,7 @@ def test_hot_kernels_do_not_spill_to_scratch():
         pytest.skip("hipcc not available")
     csrc = os.path.join(ROOT, "spark-examples_amd", "csrc")
     with tempfile.TemporaryDirectory() as td:
-        for src in ("gram_i8.hip", "gram_f32.hip"):
+        for src in ("gram_packed.hip", "gram_f32.hip"):
             res = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
                                   "-I", csrc, "-c", os.path.join(csrc, src), "-o", os.path.join(td, "x.o"),
                                   "-Rpass-analysis=kernel-resource-usage"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,

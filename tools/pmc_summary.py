@@ -13,13 +13,13 @@ for sub in sorted(glob.glob(os.path.join(out, "pmc_*"))):
         acc = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(set)
         for row in csv.DictReader(open(f)):
             k = row.get("Kernel_Name", "")
-            m = re.search(r"(gram_i8_kernel|gram_f32_kernel|pack_f32_i8_kernel|pack_u8_i8_kernel|pack_fp4_kernel|"
+            m = re.search(r"(gram_packed_kernel|gram_i8_kernel|gram_f32_kernel|pack_u8x8_fp4_kernel|expand_bits_fp4_kernel|pack_f32_i8_kernel|pack_u8_i8_kernel|pack_fp4_kernel|"
                           r"tridiag_update_kernel|symv_kernel)", k)
             if not m:
                 continue
             name = m.group(1)
-            if name == "gram_i8_kernel":   # template: <FMT, ...>, FMT 1 = MX-FP4 operands
-                name = "gram_packed_kernel_fp4" if re.search(r"gram_i8_kernel<1", k) else "gram_packed_kernel_i8"
+            if name in ("gram_i8_kernel", "gram_packed_kernel"):   # template: <FMT, ...>, FMT 1 = MX-FP4 operands
+                name = "gram_packed_kernel_fp4" if re.search(r"gram_(i8|packed)_kernel<1", k) else "gram_packed_kernel_i8"
             acc[name][row["Counter_Name"]] += float(row["Counter_Value"])
             cnt[name].add(row.get("Dispatch_Id"))
         for name, d in acc.items():
