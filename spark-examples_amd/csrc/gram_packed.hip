@@ -503,6 +503,27 @@ __device__ __forceinline__ void mfma_step_i8(const FragsI8<NNI>& f, typename Acc
     }
 }
 
+// MFMAs number LO .. HI-1 of a stage, in the order (k-step, mi, ni) of mfma_step_i8
+template <int FMT, int NNI, int SKB, int LO, int HI>
+__device__ __forceinline__ void mfma_range(const FragsI8<NNI> (&f)[SKB / 2], typename AccType<FMT>::type (&acc)[4][NNI]) {
+#pragma unroll
+  for (int k2 = 0; k2 < SKB / 2; ++k2)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NNI; ++ni) {
+        const int t = (k2 * 4 + mi) * NNI + ni;
+        if (t < LO || t >= HI) continue;
+        if constexpr (FMT == 0) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f[k2].a[mi], f[k2].b[ni], acc[mi][ni], 0, 0, 0);
+        } else {
+          asm volatile("v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, %0 cbsz:4 blgp:4"
+                       : "+v"(acc[mi][ni])
+                       : "v"(f[k2].a[mi]), "v"(f[k2].b[ni]));
+        }
+      }
+}
+
 // One stage of the ring.  Prefetch distance D = NST - 1: when stage s is consumed, stages s+1 .. s+D-1
 // may still be in flight (counted vmcnt), and stage s+D is issued into the buffer stage s-1 used.
 // Inside the stage the fragment reads are software-pipelined one k32-step ahead of the MFMAs
@@ -593,7 +614,7 @@ __device__ __forceinline__ void raw_barrier() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int FMT, int NWM, int NNI, int SKB, int NST, int BUF, int GRP, bool IDLE>
+template <int FMT, int NWM, int NNI, int SKB, int NST, int BUF, int GRP, bool IDLE, int LEFT>
 __device__ __forceinline__ void pp_stage(StageI8<NWM, SKB>* lds, const int8_t* __restrict__ p, int npad,
                                          int64_t kb_begin, int s, int ns, int col_i, int col_j, int wave, int lane,
                                          int wm, int wn, typename AccType<FMT>::type (&acc)[4][NNI],
@@ -602,6 +623,9 @@ __device__ __forceinline__ void pp_stage(StageI8<NWM, SKB>* lds, const int8_t* _
   constexpr int PER_WAVE = SKB * (2 * NWM + 4) / NWAVES;
   constexpr int D = NST - 1;
   static_assert(D >= 1 && D * PER_WAVE < 64, "vmcnt is a 6-bit counter");
+  // LEFT: the last LEFT MFMAs of a group's run are issued AFTER the barrier that ends its phase (at raised
+  // priority), so the matrix pipe has work while the barrier releases and the other group's first MFMA is on its way
+  constexpr int TOT = (SKB / 2) * 4 * NNI;
   const bool more = s + D < ns;  // a DMA is issued during this stage
   if constexpr (GRP == 0) {
     // ---- phase 2s: read stage s, issue the DMA of stage s+D
@@ -618,8 +642,7 @@ __device__ __forceinline__ void pp_stage(StageI8<NWM, SKB>* lds, const int8_t* _
     // ---- phase 2s+1: the MFMAs of stage s
     if constexpr (!IDLE) {
       __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int k2 = 0; k2 < SKB / 2; ++k2) mfma_step_i8<FMT, NNI>(f[k2], acc);
+      mfma_range<FMT, NNI, SKB, 0, TOT - LEFT>(f, acc);
       __builtin_amdgcn_s_setprio(0);
     }
   } else {
@@ -631,14 +654,21 @@ __device__ __forceinline__ void pp_stage(StageI8<NWM, SKB>* lds, const int8_t* _
     if constexpr (!IDLE) {
       if (s > 0) {
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int k2 = 0; k2 < SKB / 2; ++k2) mfma_step_i8<FMT, NNI>(f[k2], acc);
+        mfma_range<FMT, NNI, SKB, 0, TOT - LEFT>(f, acc);
         __builtin_amdgcn_s_setprio(0);
       }
     }
     raw_barrier();
-    // ---- phase 2s+1: read stage s
+    // ---- phase 2s+1: (the leftover MFMAs of stage s-1, then) read stage s
     if constexpr (!IDLE) {
+      if constexpr (LEFT > 0) {
+        if (s > 0) {
+          __builtin_amdgcn_s_setprio(2);
+          mfma_range<FMT, NNI, SKB, TOT - LEFT, TOT>(f, acc);
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
 #pragma unroll
       for (int k2 = 0; k2 < SKB / 2; ++k2) load_frags_i8<NWM, NNI, SKB>(&lds[BUF], k2, wm, wn, lane, f[k2]);
     }
@@ -653,30 +683,36 @@ __device__ __forceinline__ void pp_stage(StageI8<NWM, SKB>* lds, const int8_t* _
   }
   if constexpr (GRP == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   raw_barrier();
+  if constexpr (GRP == 0 && !IDLE && LEFT > 0) {  // group 0's leftover MFMAs of stage s, into phase 2(s+1)
+    __builtin_amdgcn_s_setprio(2);
+    mfma_range<FMT, NNI, SKB, TOT - LEFT, TOT>(f, acc);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
 }
 
-template <int FMT, int NWM, int NNI, int SKB, int NST, int GRP, bool IDLE, int... Is>
+template <int FMT, int NWM, int NNI, int SKB, int NST, int GRP, bool IDLE, int LEFT, int... Is>
 __device__ __forceinline__ void pp_round(StageI8<NWM, SKB>* lds, const int8_t* __restrict__ p, int npad,
                                          int64_t kb_begin, int s, int ns, int count, int col_i, int col_j, int wave,
                                          int lane, int wm, int wn, typename AccType<FMT>::type (&acc)[4][NNI],
                                          FragsI8<NNI> (&f)[SKB / 2], std::integer_sequence<int, Is...>) {
-  ((Is < count ? pp_stage<FMT, NWM, NNI, SKB, NST, Is, GRP, IDLE>(lds, p, npad, kb_begin, s + Is, ns, col_i, col_j, wave,
+  ((Is < count ? pp_stage<FMT, NWM, NNI, SKB, NST, Is, GRP, IDLE, LEFT>(lds, p, npad, kb_begin, s + Is, ns, col_i, col_j, wave,
                                                                   lane, wm, wn, acc, f)
                : (void)0),
    ...);
 }
 
-template <int FMT, int NWM, int NNI, int SKB, int NST, int GRP, bool IDLE>
+template <int FMT, int NWM, int NNI, int SKB, int NST, int GRP, bool IDLE, int LEFT>
 __device__ __forceinline__ void pp_loop(StageI8<NWM, SKB>* lds, const int8_t* __restrict__ p, int npad,
                                         int64_t kb_begin, int ns, int col_i, int col_j, int wave, int lane, int wm,
                                         int wn, typename AccType<FMT>::type (&acc)[4][NNI]) {
   FragsI8<NNI> f[SKB / 2];
   int s = 0;
   for (; s + NST - 1 < ns; s += NST)
-    pp_round<FMT, NWM, NNI, SKB, NST, GRP, IDLE>(lds, p, npad, kb_begin, s, ns, NST, col_i, col_j, wave, lane, wm, wn, acc,
+    pp_round<FMT, NWM, NNI, SKB, NST, GRP, IDLE, LEFT>(lds, p, npad, kb_begin, s, ns, NST, col_i, col_j, wave, lane, wm, wn, acc,
                                                  f, std::make_integer_sequence<int, NST>{});
   if (s < ns)
-    pp_round<FMT, NWM, NNI, SKB, NST, GRP, IDLE>(lds, p, npad, kb_begin, s, ns, ns - s, col_i, col_j, wave, lane, wm, wn,
+    pp_round<FMT, NWM, NNI, SKB, NST, GRP, IDLE, LEFT>(lds, p, npad, kb_begin, s, ns, ns - s, col_i, col_j, wave, lane, wm, wn,
                                                  acc, f, std::make_integer_sequence<int, NST - 1>{});
   if constexpr (GRP == 1 && !IDLE) {  // phase 2*ns: group 1's MFMAs of the last stage, nobody to wait for
 #pragma unroll
@@ -741,7 +777,7 @@ __device__ __forceinline__ void tile_coords(int tile, int ntile, int& row_blk, i
   }
 }
 
-template <int FMT, int NWM, int NNI, int SKB, int NST, bool PP>
+template <int FMT, int NWM, int NNI, int SKB, int NST, bool PP, int LEFT = 0>
 __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram_packed_kernel(
     const int8_t* __restrict__ p, int npad, int64_t nstages, int n, int ntile, int ntri, int splitk,
     int64_t stages_per, int32_t* __restrict__ s32, int xcd_map) {
@@ -794,12 +830,12 @@ __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram
     else wait_vmcnt<0>();
     raw_barrier();
     if (wm == 0) {
-      pp_loop<FMT, NWM, NNI, SKB, NST, 0, false>(lds, p, npad, kb_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
+      pp_loop<FMT, NWM, NNI, SKB, NST, 0, false, LEFT>(lds, p, npad, kb_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
     } else if (idle) {
-      pp_loop<FMT, NWM, NNI, SKB, NST, 1, true>(lds, p, npad, kb_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
+      pp_loop<FMT, NWM, NNI, SKB, NST, 1, true, LEFT>(lds, p, npad, kb_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
       return;
     } else {
-      pp_loop<FMT, NWM, NNI, SKB, NST, 1, false>(lds, p, npad, kb_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
+      pp_loop<FMT, NWM, NNI, SKB, NST, 1, false, LEFT>(lds, p, npad, kb_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
     }
   } else {
   int s = 0;
@@ -962,7 +998,7 @@ hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, i
   static const int cfg = [] {
     const char* v = std::getenv("PCOA_GRAM_I8_CFG");
     const int t = v ? std::atoi(v) : 143;
-    return (t == 43 || t == 44 || t == 144) ? t : 143;  // 1xx = ping-pong schedule (default), xx = in-phase ring
+    return (t == 43 || t == 44 || t == 144 || t == 243 || t == 443) ? t : 143;  // 1xx / 2xx / 4xx = ping-pong with 0 / 2 / 4 MFMAs moved behind the barrier; xx = in-phase ring
   }();
   const int skb = (cfg % 100) / 10;
   const int npad = (int)gram_packed_npad(n);
@@ -991,20 +1027,22 @@ hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, i
   if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
   if (splitk_out) *splitk_out = (int)splitk;
   const dim3 grid((unsigned)nblocks), block(512);
-#define PCOA_LAUNCH_I8(SKB_, NST_, PP_)                                                                            \
+#define PCOA_LAUNCH_I8(SKB_, NST_, PP_, LEFT_)                                                                            \
   do {                                                                                                          \
     if (fmt == 1)                                                                                               \
-      hipLaunchKernelGGL((gram_packed_kernel<1, 2, 2, SKB_, NST_, PP_>), grid, block, 0, stream, p, npad, nstages, n, ntile, \
+      hipLaunchKernelGGL((gram_packed_kernel<1, 2, 2, SKB_, NST_, PP_, LEFT_>), grid, block, 0, stream, p, npad, nstages, n, ntile, \
                          ntri, (int)splitk, stages_per, s32, xcd_map);                                          \
     else                                                                                                        \
-      hipLaunchKernelGGL((gram_packed_kernel<0, 2, 2, SKB_, NST_, PP_>), grid, block, 0, stream, p, npad, nstages, n, ntile, \
+      hipLaunchKernelGGL((gram_packed_kernel<0, 2, 2, SKB_, NST_, PP_, LEFT_>), grid, block, 0, stream, p, npad, nstages, n, ntile, \
                          ntri, (int)splitk, stages_per, s32, xcd_map);                                          \
   } while (0)
   switch (cfg) {
-    case 44: PCOA_LAUNCH_I8(4, 4, false); break;
-    case 144: PCOA_LAUNCH_I8(4, 4, true); break;
-    case 43: PCOA_LAUNCH_I8(4, 3, false); break;
-    default: PCOA_LAUNCH_I8(4, 3, true); break;
+    case 44: PCOA_LAUNCH_I8(4, 4, false, 0); break;
+    case 144: PCOA_LAUNCH_I8(4, 4, true, 0); break;
+    case 43: PCOA_LAUNCH_I8(4, 3, false, 0); break;
+    case 243: PCOA_LAUNCH_I8(4, 3, true, 2); break;
+    case 443: PCOA_LAUNCH_I8(4, 3, true, 4); break;
+    default: PCOA_LAUNCH_I8(4, 3, true, 0); break;
   }
 #undef PCOA_LAUNCH_I8
   return hipGetLastError();
