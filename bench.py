@@ -219,12 +219,12 @@ def main():
                 pmc = {}
         kind = tim["gram_kernel_kind"]          # what actually ran: 1 fp32, 2 int8, 3 MX-FP4
         if kind == 3:
-            tile, peak, kname = 256, PEAK_FP4_MFMA_TFLOPS, "gram_packed_kernel<1, 2, 2, 4, 3, true> (FMT 1 = MX-FP4, ping-pong)"
+            tile, peak, kname = 256, PEAK_FP4_MFMA_TFLOPS, "gram_packed_kernel<1, 2, 2, 4, 3, true, 2> (FMT 1 = MX-FP4, ping-pong)"
             kdesc = ("pack fp32->k-blocked FP4 E2M1 (HBM-bound, verifies values are 0/1) + MX-FP4 MFMA "
                      "v_mfma_f32_32x32x64_f8f6f4 (unscaled form, exact), upper-triangular 256x256 tiles, split-K, "
                      "fp32 accumulators (< 2^24 per launch) -> int32 atomics")
         elif kind == 2:
-            tile, peak, kname = 256, PEAK_I8_MFMA_TOPS, "gram_packed_kernel<0, 2, 2, 4, 3, true> (FMT 0 = int8, ping-pong)"
+            tile, peak, kname = 256, PEAK_I8_MFMA_TOPS, "gram_packed_kernel<0, 2, 2, 4, 3, true, 2> (FMT 0 = int8, ping-pong)"
             kdesc = "pack fp32->k-blocked int8 (HBM-bound) + i8 MFMA v_mfma_i32_32x32x32_i8, upper-triangular 256x256 tiles, split-K, int32 accumulators"
         else:
             tile, peak, kname = 128, PEAK_FP32_MFMA_TFLOPS, "gram_f32_kernel"

@@ -26,7 +26,8 @@
 //   each), 3-stage LDS ring (96 KiB), counted vmcnt (two stages stay in flight), raw s_barrier (never
 //   __syncthreads, which would drain the DMA queue).  Operand reads are ds_read_b128 of 32 consecutive 16-B slots per
 //   half-wave: conflict-free.  Default schedule: ping-pong (two wave groups half a stage apart, see below);
-//   PCOA_GRAM_I8_CFG=43 selects the in-phase ring.
+//   PCOA_GRAM_I8_CFG=43 selects the in-phase ring, 143 the
+//   ping-pong schedule without the two MFMAs issued behind the phase barrier.
 //
 // Measured, N = 2504, 10^6 variants per launch: FP4 1.24 ms (5.5 PFLOP/s issued), int8 2.20 ms; DESIGN.md 4.0 / 4.0a.
 #include <cstdlib>
@@ -994,11 +995,12 @@ hipError_t launch_gram_i8_packed(const int8_t* p, int64_t nv, int32_t n, int32_t
 hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, int32_t* s32, int num_cu,
                               hipStream_t stream, int* splitk_out) {
   if (nv <= 0) return hipSuccess;
-  // PCOA_GRAM_I8_CFG = [1]<k-blocks per stage><ring length>: 143 (default, ping-pong), 144, 43 / 44 (in-phase ring)
+  // PCOA_GRAM_I8_CFG = [h]<k-blocks per stage><ring length>; h = 1 / 2 / 4: ping-pong with 0 / 2 / 4 MFMAs behind the
+  // barrier (243 = default), h absent: in-phase ring (43, 44)
   static const int cfg = [] {
     const char* v = std::getenv("PCOA_GRAM_I8_CFG");
-    const int t = v ? std::atoi(v) : 143;
-    return (t == 43 || t == 44 || t == 144 || t == 243 || t == 443) ? t : 143;  // 1xx / 2xx / 4xx = ping-pong with 0 / 2 / 4 MFMAs moved behind the barrier; xx = in-phase ring
+    const int t = v ? std::atoi(v) : 243;
+    return (t == 43 || t == 44 || t == 143 || t == 144 || t == 443) ? t : 243;  // 1xx / 2xx / 4xx = ping-pong with 0 / 2 / 4 MFMAs moved behind the barrier; xx = in-phase ring
   }();
   const int skb = (cfg % 100) / 10;
   const int npad = (int)gram_packed_npad(n);
@@ -1040,9 +1042,9 @@ hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, i
     case 44: PCOA_LAUNCH_I8(4, 4, false, 0); break;
     case 144: PCOA_LAUNCH_I8(4, 4, true, 0); break;
     case 43: PCOA_LAUNCH_I8(4, 3, false, 0); break;
-    case 243: PCOA_LAUNCH_I8(4, 3, true, 2); break;
+    case 143: PCOA_LAUNCH_I8(4, 3, true, 0); break;
     case 443: PCOA_LAUNCH_I8(4, 3, true, 4); break;
-    default: PCOA_LAUNCH_I8(4, 3, true, 0); break;
+    default: PCOA_LAUNCH_I8(4, 3, true, 2); break;  // measured: 1.218 (LEFT 2) / 1.218 (4) / 1.236 (0) ms per 10^6 variants
   }
 #undef PCOA_LAUNCH_I8
   return hipGetLastError();
