@@ -452,30 +452,6 @@ __device__ __forceinline__ void issue_stage_i8(StageI8<NWM, SKB>* st, const int8
   }
 }
 
-// Ping-pong variant: the 32 DMA instructions of a stage are split DMA0 : 8 - DMA0 per wave between the two groups
-// (4 waves each), so that the group whose turn it is to issue MFMAs carries fewer of them (one LDS-DMA instruction
-// costs ~60 issue cycles).
-template <int NWM, int SKB, int GRP, int DMA0>
-__device__ __forceinline__ void issue_stage_pp(StageI8<NWM, SKB>* st, const int8_t* __restrict__ p, int npad,
-                                               int64_t kb0, int col_i, int col_j, int wave, int lane) {
-  constexpr int QI = 2 * NWM;
-  constexpr int PER_KB = QI + 4;
-  static_assert(SKB * PER_KB == 32 && NWM == 2, "8 waves, 32 DMA instructions per stage");
-  constexpr int COUNT = GRP == 0 ? DMA0 : 8 - DMA0;
-#pragma unroll
-  for (int q = 0; q < COUNT; ++q) {
-    const int id = GRP == 0 ? wave * DMA0 + q : 4 * DMA0 + (wave - 4) * (8 - DMA0) + q;
-    const int kb = id / PER_KB;
-    const int r = id - kb * PER_KB;
-    const bool is_i = r < QI;
-    const int sq = is_i ? r : r - QI;
-    const int c0 = (is_i ? col_i : col_j) + sq * 64;
-    const int8_t* src = p + ((size_t)(kb0 + kb) * npad + c0 + lane) * KB;
-    int8_t* dst = is_i ? &st->pi[kb][sq * 64][0] : &st->pj[kb][sq * 64][0];
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
-  }
-}
-
 // Fragment registers of one k32-step: (4 A + NNI B) x 16 B = 24 VGPRs at NNI = 2.
 template <int NNI>
 struct FragsI8 {
@@ -639,12 +615,13 @@ __device__ __forceinline__ void raw_barrier() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int FMT, int NWM, int NNI, int SKB, int NST, int BUF, int GRP, bool IDLE, int LEFT, int DMA0>
+template <int FMT, int NWM, int NNI, int SKB, int NST, int BUF, int GRP, bool IDLE, int LEFT>
 __device__ __forceinline__ void pp_stage(StageI8<NWM, SKB>* lds, const int8_t* __restrict__ p, int npad,
                                          int64_t kb_begin, int s, int ns, int col_i, int col_j, int wave, int lane,
                                          int wm, int wn, typename AccType<FMT>::type (&acc)[4][NNI],
                                          FragsI8<NNI> (&f)[SKB / 2]) {
-  constexpr int PER_WAVE = GRP == 0 ? DMA0 : 8 - DMA0;  // this wave's DMA instructions per stage
+  constexpr int NWAVES = NWM * (8 / NNI);
+  constexpr int PER_WAVE = SKB * (2 * NWM + 4) / NWAVES;
   constexpr int D = NST - 1;
   static_assert(D >= 1 && D * PER_WAVE < 64, "vmcnt is a 6-bit counter");
   // LEFT: the last LEFT MFMAs of a group's run are issued AFTER the barrier that ends its phase (at raised
@@ -659,8 +636,8 @@ __device__ __forceinline__ void pp_stage(StageI8<NWM, SKB>* lds, const int8_t* _
     }
     __builtin_amdgcn_sched_barrier(0);
     if (more)
-      issue_stage_pp<NWM, SKB, GRP, DMA0>(&lds[(BUF + D) % NST], p, npad, kb_begin + (int64_t)(s + D) * SKB, col_i, col_j,
-                                          wave, lane);
+      issue_stage_i8<NWM, SKB, NWAVES>(&lds[(BUF + D) % NST], p, npad, kb_begin + (int64_t)(s + D) * SKB, col_i, col_j,
+                                       wave, lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     raw_barrier();
     // ---- phase 2s+1: the MFMAs of stage s
@@ -672,8 +649,8 @@ __device__ __forceinline__ void pp_stage(StageI8<NWM, SKB>* lds, const int8_t* _
   } else {
     // ---- phase 2s: issue the DMA of stage s+D, then the MFMAs of stage s-1
     if (more)
-      issue_stage_pp<NWM, SKB, GRP, DMA0>(&lds[(BUF + D) % NST], p, npad, kb_begin + (int64_t)(s + D) * SKB, col_i, col_j,
-                                          wave, lane);
+      issue_stage_i8<NWM, SKB, NWAVES>(&lds[(BUF + D) % NST], p, npad, kb_begin + (int64_t)(s + D) * SKB, col_i, col_j,
+                                       wave, lane);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (!IDLE) {
       if (s > 0) {
@@ -715,36 +692,28 @@ __device__ __forceinline__ void pp_stage(StageI8<NWM, SKB>* lds, const int8_t* _
   }
 }
 
-template <int FMT, int NWM, int NNI, int SKB, int NST, int GRP, bool IDLE, int LEFT, int DMA0, int... Is>
+template <int FMT, int NWM, int NNI, int SKB, int NST, int GRP, bool IDLE, int LEFT, int... Is>
 __device__ __forceinline__ void pp_round(StageI8<NWM, SKB>* lds, const int8_t* __restrict__ p, int npad,
                                          int64_t kb_begin, int s, int ns, int count, int col_i, int col_j, int wave,
                                          int lane, int wm, int wn, typename AccType<FMT>::type (&acc)[4][NNI],
                                          FragsI8<NNI> (&f)[SKB / 2], std::integer_sequence<int, Is...>) {
-  ((Is < count ? pp_stage<FMT, NWM, NNI, SKB, NST, Is, GRP, IDLE, LEFT, DMA0>(lds, p, npad, kb_begin, s + Is, ns, col_i, col_j, wave,
+  ((Is < count ? pp_stage<FMT, NWM, NNI, SKB, NST, Is, GRP, IDLE, LEFT>(lds, p, npad, kb_begin, s + Is, ns, col_i, col_j, wave,
                                                                   lane, wm, wn, acc, f)
                : (void)0),
    ...);
 }
 
-template <int FMT, int NWM, int NNI, int SKB, int NST, int GRP, bool IDLE, int LEFT, int DMA0>
+template <int FMT, int NWM, int NNI, int SKB, int NST, int GRP, bool IDLE, int LEFT>
 __device__ __forceinline__ void pp_loop(StageI8<NWM, SKB>* lds, const int8_t* __restrict__ p, int npad,
                                         int64_t kb_begin, int ns, int col_i, int col_j, int wave, int lane, int wm,
                                         int wn, typename AccType<FMT>::type (&acc)[4][NNI]) {
   FragsI8<NNI> f[SKB / 2];
-  // prologue: stages 0 .. NST-2 go in flight (this group's share), stage 0 must have landed before group 0 reads it
-  constexpr int PER_WAVE = GRP == 0 ? DMA0 : 8 - DMA0;
-#pragma unroll
-  for (int i = 0; i < NST - 1; ++i)
-    if (i < ns) issue_stage_pp<NWM, SKB, GRP, DMA0>(&lds[i], p, npad, kb_begin + (int64_t)i * SKB, col_i, col_j, wave, lane);
-  if (ns > 1 && NST > 2) wait_vmcnt<(NST > 2 ? PER_WAVE : 0)>();
-  else wait_vmcnt<0>();
-  raw_barrier();
   int s = 0;
   for (; s + NST - 1 < ns; s += NST)
-    pp_round<FMT, NWM, NNI, SKB, NST, GRP, IDLE, LEFT, DMA0>(lds, p, npad, kb_begin, s, ns, NST, col_i, col_j, wave, lane, wm, wn, acc,
+    pp_round<FMT, NWM, NNI, SKB, NST, GRP, IDLE, LEFT>(lds, p, npad, kb_begin, s, ns, NST, col_i, col_j, wave, lane, wm, wn, acc,
                                                  f, std::make_integer_sequence<int, NST>{});
   if (s < ns)
-    pp_round<FMT, NWM, NNI, SKB, NST, GRP, IDLE, LEFT, DMA0>(lds, p, npad, kb_begin, s, ns, ns - s, col_i, col_j, wave, lane, wm, wn,
+    pp_round<FMT, NWM, NNI, SKB, NST, GRP, IDLE, LEFT>(lds, p, npad, kb_begin, s, ns, ns - s, col_i, col_j, wave, lane, wm, wn,
                                                  acc, f, std::make_integer_sequence<int, NST - 1>{});
   if constexpr (GRP == 1 && !IDLE) {  // phase 2*ns: group 1's MFMAs of the last stage, nobody to wait for
 #pragma unroll
@@ -809,7 +778,7 @@ __device__ __forceinline__ void tile_coords(int tile, int ntile, int& row_blk, i
   }
 }
 
-template <int FMT, int NWM, int NNI, int SKB, int NST, bool PP, int LEFT = 0, int DMA0 = 4>
+template <int FMT, int NWM, int NNI, int SKB, int NST, bool PP, int LEFT = 0>
 __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram_packed_kernel(
     const int8_t* __restrict__ p, int npad, int64_t nstages, int n, int ntile, int ntri, int splitk,
     int64_t stages_per, int32_t* __restrict__ s32, int xcd_map) {
@@ -852,20 +821,24 @@ __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0;
 
-  if constexpr (PP) {
-    static_assert(!PP || (NWM == 2 && NNI == 2), "ping-pong: 8 waves, group = wave / 4 = wm");
-    if (wm == 0) {
-      pp_loop<FMT, NWM, NNI, SKB, NST, 0, false, LEFT, DMA0>(lds, p, npad, kb_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
-    } else if (idle) {
-      pp_loop<FMT, NWM, NNI, SKB, NST, 1, true, LEFT, DMA0>(lds, p, npad, kb_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
-      return;
-    } else {
-      pp_loop<FMT, NWM, NNI, SKB, NST, 1, false, LEFT, DMA0>(lds, p, npad, kb_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
-    }
-  } else {
   // prologue: stages 0 .. D-1 go in flight
   ring_prologue<NWM, SKB, NST, NWAVES>(lds, p, npad, kb_begin, ns, col_i, col_j, wave, lane,
                                       std::make_integer_sequence<int, NST - 1>{});
+  if constexpr (PP) {
+    static_assert(!PP || (NWM == 2 && NNI == 2), "ping-pong: 8 waves, group = wave / 4 = wm");
+    // stage 0 must have landed before group 0 reads it in phase 0
+    if (ns > 1 && NST > 2) wait_vmcnt<(NST > 2 ? SKB * (2 * NWM + 4) / NWAVES : 0)>();
+    else wait_vmcnt<0>();
+    raw_barrier();
+    if (wm == 0) {
+      pp_loop<FMT, NWM, NNI, SKB, NST, 0, false, LEFT>(lds, p, npad, kb_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
+    } else if (idle) {
+      pp_loop<FMT, NWM, NNI, SKB, NST, 1, true, LEFT>(lds, p, npad, kb_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
+      return;
+    } else {
+      pp_loop<FMT, NWM, NNI, SKB, NST, 1, false, LEFT>(lds, p, npad, kb_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
+    }
+  } else {
   int s = 0;
   if (idle) {  // wave-uniform: a separate loop with no accumulator traffic at all, then nothing to store
     for (; s + NST - 1 < ns; s += NST)
@@ -1027,7 +1000,7 @@ hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, i
   static const int cfg = [] {
     const char* v = std::getenv("PCOA_GRAM_I8_CFG");
     const int t = v ? std::atoi(v) : 243;
-    return (t == 43 || t == 44 || t == 143 || t == 144 || t == 443 || t == 1243 || t == 2243 || t == 3243) ? t : 243;  // 1xx / 2xx / 4xx = ping-pong with 0 / 2 / 4 MFMAs moved behind the barrier; xx = in-phase ring
+    return (t == 43 || t == 44 || t == 143 || t == 144 || t == 443) ? t : 243;  // 1xx / 2xx / 4xx = ping-pong with 0 / 2 / 4 MFMAs moved behind the barrier; xx = in-phase ring
   }();
   const int skb = (cfg % 100) / 10;
   const int npad = (int)gram_packed_npad(n);
@@ -1056,25 +1029,22 @@ hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, i
   if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
   if (splitk_out) *splitk_out = (int)splitk;
   const dim3 grid((unsigned)nblocks), block(512);
-#define PCOA_LAUNCH_I8(SKB_, NST_, PP_, LEFT_, DMA0_)                                                                            \
+#define PCOA_LAUNCH_I8(SKB_, NST_, PP_, LEFT_)                                                                            \
   do {                                                                                                          \
     if (fmt == 1)                                                                                               \
-      hipLaunchKernelGGL((gram_packed_kernel<1, 2, 2, SKB_, NST_, PP_, LEFT_, DMA0_>), grid, block, 0, stream, p, npad, nstages, n, ntile, \
+      hipLaunchKernelGGL((gram_packed_kernel<1, 2, 2, SKB_, NST_, PP_, LEFT_>), grid, block, 0, stream, p, npad, nstages, n, ntile, \
                          ntri, (int)splitk, stages_per, s32, xcd_map);                                          \
     else                                                                                                        \
-      hipLaunchKernelGGL((gram_packed_kernel<0, 2, 2, SKB_, NST_, PP_, LEFT_, DMA0_>), grid, block, 0, stream, p, npad, nstages, n, ntile, \
+      hipLaunchKernelGGL((gram_packed_kernel<0, 2, 2, SKB_, NST_, PP_, LEFT_>), grid, block, 0, stream, p, npad, nstages, n, ntile, \
                          ntri, (int)splitk, stages_per, s32, xcd_map);                                          \
   } while (0)
   switch (cfg) {
-    case 44: PCOA_LAUNCH_I8(4, 4, false, 0, 4); break;
-    case 144: PCOA_LAUNCH_I8(4, 4, true, 0, 4); break;
-    case 43: PCOA_LAUNCH_I8(4, 3, false, 0, 4); break;
-    case 143: PCOA_LAUNCH_I8(4, 3, true, 0, 4); break;
-    case 443: PCOA_LAUNCH_I8(4, 3, true, 4, 4); break;
-    case 1243: PCOA_LAUNCH_I8(4, 3, true, 2, 6); break;
-    case 2243: PCOA_LAUNCH_I8(4, 3, true, 2, 8); break;
-    case 3243: PCOA_LAUNCH_I8(4, 3, true, 2, 2); break;
-    default: PCOA_LAUNCH_I8(4, 3, true, 2, 4); break;  // measured: 1.218 (LEFT 2) / 1.218 (4) / 1.236 (0) ms per 10^6 variants
+    case 44: PCOA_LAUNCH_I8(4, 4, false, 0); break;
+    case 144: PCOA_LAUNCH_I8(4, 4, true, 0); break;
+    case 43: PCOA_LAUNCH_I8(4, 3, false, 0); break;
+    case 143: PCOA_LAUNCH_I8(4, 3, true, 0); break;
+    case 443: PCOA_LAUNCH_I8(4, 3, true, 4); break;
+    default: PCOA_LAUNCH_I8(4, 3, true, 2); break;  // measured: 1.218 (LEFT 2) / 1.218 (4) / 1.236 (0) ms per 10^6 variants
   }
 #undef PCOA_LAUNCH_I8
   return hipGetLastError();
