@@ -369,12 +369,28 @@ def main():
                     c1, l1, _ = e1.compute(2)
                     walls.append(1e3 * (time.perf_counter() - t1))
                 tt1 = e1.timings()
+            # the same job on the CPU restatement at 4 threads (= the reference's local[4]) -- baseline only
+            cpu_c0 = None
+            if not args.no_cpu_baseline:
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                oracle = importlib.import_module("variants_pca_oracle")
+                prev = oracle.num_threads()
+                oracle.set_num_threads(4)
+                t1 = time.perf_counter()
+                s_c0 = oracle.calculate_similarity_matrix((idx1, offs1), n, n_partitions=4)
+                t_gram = time.perf_counter() - t1
+                ref_c0 = oracle.compute_pca(s_c0, 2)
+                t_all = time.perf_counter() - t1
+                oracle.set_num_threads(prev)
+                cpu_c0 = {"threads": 4, "similarity_seconds": t_gram, "total_seconds": t_all, "kind": "port",
+                          "pc_max_abs_diff_vs_gpu": float(np.abs(
+                              np.abs(ref_c0["components"]) - np.abs(c1)).max())}
             out["config0_csr_end_to_end"] = {
                 "workload": "configs[0] stand-in: synthetic BRCA1-sized region, %d variants x %d samples, %d carriers, "
                             "host CSR through pcoa_accumulate_calls" % (x1.shape[0], n, idx1.size),
                 "wall_ms": float(min(walls[1:])), "wall_ms_all": walls,
                 "eig_method": {1: "lanczos", 2: "householder"}.get(tt1["eig_method"], "?"),
-                "eigenvalues": [float(t) for t in l1]}
+                "eigenvalues": [float(t) for t in l1], "cpu_local4": cpu_c0}
         if world == 1 and not args.no_extras:
             # PCIe-inclusive rates (host tiles through the staging path): noted, never `value`
             hv = min(v, 131072)
