@@ -477,8 +477,26 @@ int main(int argc, char** argv) {
   // getSimilarityMatrix (:182-191) and computePca (:198-231) on the GPU
   pcoa_ctx* ctx = nullptr;
   if (pcoa_create(&ctx, n, conf.gpu, PCOA_FLAG_DEFAULT) != PCOA_OK) die(std::string("pcoa_create: ") + pcoa_last_error(nullptr));
-  check(ctx, pcoa_accumulate_calls(ctx, sample_idx.data(), row_offsets.data(), (int64_t)row_offsets.size() - 1),
-        "getSimilarityMatrix");
+  // The RDD[Seq[Int]] rows go over as carrier BITSETS (pcoa_accumulate_bits): a row built from VCF calls never
+  // repeats a callset (join / merge concatenate datasets with disjoint index ranges), so the set form is exact, it is
+  // 316 B per variant at N = 2504 instead of 4 B per carrier, and it runs on the MX-FP4 kernel.  (The Python mirror
+  // sends the same rows through the CSR boundary pcoa_accumulate_calls; a GPU test holds the two to identical output.)
+  {
+    const int64_t n_rows = (int64_t)row_offsets.size() - 1;
+    const int64_t words = ((int64_t)n + 31) / 32;
+    const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(n_rows, ((int64_t)64 << 20) / words));
+    std::vector<uint32_t> bits((size_t)(batch * words));
+    for (int64_t r0 = 0; r0 < n_rows; r0 += batch) {
+      const int64_t rows = std::min(batch, n_rows - r0);
+      std::fill(bits.begin(), bits.begin() + (size_t)(rows * words), 0u);
+      for (int64_t r = 0; r < rows; ++r)
+        for (int64_t q = row_offsets[(size_t)(r0 + r)]; q < row_offsets[(size_t)(r0 + r + 1)]; ++q) {
+          const int32_t c = sample_idx[(size_t)q];
+          bits[(size_t)(r * words + (c >> 5))] |= 1u << (c & 31);
+        }
+      check(ctx, pcoa_accumulate_bits(ctx, bits.data(), rows, words, 0), "getSimilarityMatrix");
+    }
+  }
   check(ctx, pcoa_gram_finalize(ctx), "getSimilarityMatrix");
   if (conf.num_pc < 2)  // the reference reads array(i + pca.numRows) unconditionally (:230)
     die("computePca emits exactly PC1 and PC2 (VariantsPca.scala:229-230); --num-pc must be >= 2");
