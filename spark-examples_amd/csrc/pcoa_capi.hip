@@ -66,6 +66,7 @@ struct pcoa_ctx {
   int packed_mode = 0;             // 0 auto (FP4 for binary tiles, int8 otherwise), 2 int8 only, 3 FP4 only
   int32_t* fp4_flag = nullptr;     // device: raised by the FP4 pre-pass on a value other than 0 / 1
   int64_t fp4_fallbacks = 0;
+  int i8_streak = 0;               // auto mode: chunks still to be sent straight to the int8 kernel after a fallback
   int64_t pack_chunk = (int64_t)1 << 20;  // variants packed + contracted per launch pair
   int64_t pack_launches = 0;
   double pack_bytes = 0;
@@ -258,6 +259,11 @@ int packed_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64
   if (rc != PCOA_OK) return rc;
   const double in_bytes = (is_u8 ? 1.0 : 4.0) * (double)cur * (double)c->n;
   bool fp4 = c->packed_mode != 2;
+  if (fp4 && c->packed_mode == 0 && c->i8_streak > 0) {
+    // the last FP4 attempt met multiplicities: do not pay for a second pre-pass on every chunk of such a cohort
+    c->i8_streak -= 1;
+    fp4 = false;
+  }
   if (fp4) {
     int32_t* flag = c->err_flag;
     if (c->packed_mode == 0) {
@@ -279,6 +285,7 @@ int packed_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64
       if (seen) {  // a multiplicity (or garbage): this chunk takes the int8 path, which validates 0..127
         fp4 = false;
         c->fp4_fallbacks += 1;
+        c->i8_streak = 8;  // then FP4 is tried again
       }
     }
   }
