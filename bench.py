@@ -6,7 +6,7 @@ fp32 (10.0 GB), resident in HBM before the timed region (weak scaling: every ran
 shard of one 1M*N_gpus-variant cohort; the generator is counter-based, so the cohort does not depend on N).
 
 One step = one pass of the hot path over the resident batch: the Gram accumulation of 10^6 variants per GPU
-(pre-pass + i8-MFMA contraction, exact).  The job = K steps, then ONE finalize (mirror) and, for N > 1, ONE RCCL
+(re-layout pre-pass + matrix-core contraction: MX-FP4 for binary tiles, int8 for multiplicities; exact).  The job = K steps, then ONE finalize (mirror) and, for N > 1, ONE RCCL
 all-reduce of S -- the reference reduces once per job too (reduceByKey after all partitions, VariantsPca.scala:190),
 and with --steps 5 this is exactly BASELINE configs[2]'s shape (5M variants per GPU, 40M at 8 GPUs).  The
 finalize/all-reduce is INSIDE the timed region.
