@@ -293,61 +293,6 @@ __global__ __launch_bounds__(256) void pack_fp4_kernel(const T* __restrict__ x, 
   if (bad || badw) atomicOr(flag, 8);
 }
 
-// fp32 input, 32 bytes per lane and row (experiment PCOA_PACK_F32X8): one thread packs 32 variants x 8 samples, so a
-// wave reads 2 KiB contiguous per row instead of 1 KiB.
-__device__ __forceinline__ uint32_t spread8_fp4(uint32_t b);
-
-__global__ __launch_bounds__(256) void pack_f32x8_fp4_kernel(const float* __restrict__ x, int64_t ld, int64_t nv, int n,
-                                                             int npad, int64_t nkb_pad, int8_t* __restrict__ p,
-                                                             int32_t* __restrict__ flag) {
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int gw = npad >> 9;  // waves per k-block (64 lanes x 8 samples = 512 samples; npad % 512 == 0 on this path)
-  const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
-  const int64_t kb = wid / gw;
-  const int g = (int)(wid - kb * gw) * 64 + lane;
-  if (kb >= nkb_pad) return;
-  const int i0 = g * 8;
-  const int64_t col = (i0 < ld) ? i0 : 0;
-  uint32_t live = 0;  // bit s: column i0 + s exists (< n)
-#pragma unroll
-  for (int sidx = 0; sidx < 8; ++sidx) live |= (uint32_t)((i0 + sidx < n) & (i0 < ld)) << sidx;
-  uint32_t o[8][4];
-  uint32_t badw = 0;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    f32x4_t r0[8], r1[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int64_t row = kb * 32 + q * 8 + t;
-      const float* src = x + (row < nv ? row : nv - 1) * ld + col;
-      r0[t] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(src));
-      r1[t] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(src + 4));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    uint32_t a[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // a[s]: bit t = sample s carries at row t of this batch
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int64_t row = kb * 32 + q * 8 + t;
-      const uint32_t rowok = (uint32_t)(row < nv);
-#pragma unroll
-      for (int sidx = 0; sidx < 8; ++sidx) {
-        const float v = sidx < 4 ? r0[t][sidx] : r1[t][sidx - 4];
-        const uint32_t is1 = (uint32_t)(v == 1.0f), is0 = (uint32_t)(v == 0.0f);
-        const uint32_t lv = rowok & ((live >> sidx) & 1u);
-        badw |= lv & ((is1 | is0) ^ 1u);
-        a[sidx] |= (lv & is1) << t;
-      }
-    }
-#pragma unroll
-    for (int sidx = 0; sidx < 8; ++sidx) o[sidx][q] = spread8_fp4(a[sidx]);
-  }
-  uint4* dst = reinterpret_cast<uint4*>(p + ((size_t)kb * npad + i0) * 16);
-#pragma unroll
-  for (int sidx = 0; sidx < 8; ++sidx) dst[sidx] = make_uint4(o[sidx][0], o[sidx][1], o[sidx][2], o[sidx][3]);
-  if (badw) atomicOr(flag, 8);
-}
-
 // uint8 input, 8-byte loads: one thread packs 32 variants x 8 samples (a wave reads 512 contiguous bytes per row
 // instead of the 256 of the generic kernel above: 2504-byte rows are not line-aligned, so short segments pay for an
 // extra 128-B line each).  Four batches of 8 rows; per batch the 0/1 bytes of row t are OR-ed in at bit t, which
@@ -973,13 +918,6 @@ hipError_t launch_pack_fp4(const void* x, int is_u8, int64_t ld, int64_t nv, int
   } else {
     const bool vec = ((ld & 3) == 0) && ((addr & 15) == 0);
     const float* xs = static_cast<const float*>(x);
-    static const bool x8 = std::getenv("PCOA_PACK_F32X8") != nullptr;
-    if (x8 && vec && (npad % 512) == 0 && (ld % 8) == 0 && (addr & 31) == 0) {
-      const int64_t blocks8 = nkb_pad * (npad >> 9) / 4;
-      hipLaunchKernelGGL(pack_f32x8_fp4_kernel, dim3((unsigned)blocks8), block, 0, stream, xs, ld, nv, n, npad, nkb_pad, p,
-                         flag);
-      return hipGetLastError();
-    }
     // the fp32 tile is streamed once: nontemporal loads (measured 2.07 vs 2.15 ms per 10^6 variants)
     if (vec) hipLaunchKernelGGL((pack_fp4_kernel<float, 4, true>), grid, block, 0, stream, xs, ld, nv, n, npad, nkb_pad, p, flag);
     else hipLaunchKernelGGL((pack_fp4_kernel<float, 1>), grid, block, 0, stream, xs, ld, nv, n, npad, nkb_pad, p, flag);
