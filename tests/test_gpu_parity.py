@@ -733,3 +733,30 @@ def test_cpp_driver_matches_python_driver(P, tmp_path, capsys, nsets, extra):
     for r in rows_cpp:
         assert fmt(float(r[2])) == r[2] and fmt(float(r[3])) == r[3]
     assert open(str(tmp_path / "cpp") + "-pca.tsv").read().count("\n") == len(rows_cpp)
+
+
+# ------------------------------------------------------------------------------------------ measurement contract
+def test_bench_emits_one_json_line_with_the_contract_fields(P):
+    """bench.py at a reduced size: ONE JSON line on stdout with the driver's fields, the roofline object of the
+    dominant kernel (live HIP-event timing) and the bounded CPU baseline; the CPU sample doubles as a parity check."""
+    import json
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2",
+                                   "--warmup", "1", "--variants", "50000", "--no-extras", "--pcoa-reps", "1"],
+                                  universal_newlines=True)
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "variants/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 50000 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
+    for r in (d["roofline"], d["roofline_other"]):
+        assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["avg_launch_ms"] > 0 and "traffic" in r
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert d["parity_vs_cpu_sample"] is True
+    assert d["dtype"].startswith("fp4") and d["pcoa_wall_ms"] > 0
