@@ -709,6 +709,8 @@ def _make_cohorts(tmp_path, seed=5):
 @pytest.mark.parametrize("nsets,extra", [(1, []), (2, []), (3, []), (2, ["--min-allele-frequency", "0.1"])])
 def test_cpp_driver_matches_python_driver(P, tmp_path, capsys, nsets, extra):
     exe = os.path.join(ROOT, "spark-examples_amd", "variants_pca_driver")
+    if not os.path.exists(exe):   # normally built by __graft_entry__.build(); g++ exists on the GPU image too
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "spark-examples_amd", "host")])
     assert os.path.exists(exe), "build it with __graft_entry__.build()"
     vp = load_pkg("variants_pca")
     sets = _make_cohorts(tmp_path)[:nsets]
