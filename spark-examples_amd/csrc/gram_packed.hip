@@ -471,6 +471,37 @@ __device__ __forceinline__ void load_frags_i8(const StageI8<NWM, SKB>* st, int k
     f.b[ni] = *reinterpret_cast<const i32x4*>(&st->pj[2 * k2 + hi][wn * 32 * NNI + ni * 32 + l31][0]);
 }
 
+// Diagonal tiles (row block == column block): panel J IS panel I, so only panel I is brought in (16 instead of 32
+// DMA instructions per stage) and the B fragments are read from it.
+template <int NWM, int NNI, int SKB>
+__device__ __forceinline__ void load_frags_diag(const StageI8<NWM, SKB>* st, int k2, int wm, int wn, int lane,
+                                                FragsI8<NNI>& f) {
+  const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+    f.a[mi] = *reinterpret_cast<const i32x4*>(&st->pi[2 * k2 + hi][wm * 128 + mi * 32 + l31][0]);
+#pragma unroll
+  for (int ni = 0; ni < NNI; ++ni)
+    f.b[ni] = *reinterpret_cast<const i32x4*>(&st->pi[2 * k2 + hi][wn * 32 * NNI + ni * 32 + l31][0]);
+}
+
+template <int NWM, int SKB, int NWAVES>
+__device__ __forceinline__ void issue_stage_diag(StageI8<NWM, SKB>* st, const int8_t* __restrict__ p, int npad,
+                                                 int64_t kb0, int col_i, int wave, int lane) {
+  constexpr int QI = 2 * NWM;  // 64-sample quarters in panel I
+  constexpr int TOTAL = SKB * QI;
+  constexpr int PER_WAVE = TOTAL / NWAVES;
+  static_assert(TOTAL % NWAVES == 0, "DMA instructions must divide evenly over the waves");
+#pragma unroll
+  for (int q = 0; q < PER_WAVE; ++q) {
+    const int id = wave * PER_WAVE + q;
+    const int kb = id / QI;
+    const int sq = id - kb * QI;
+    const int8_t* src = p + ((size_t)(kb0 + kb) * npad + col_i + sq * 64 + lane) * KB;
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)&st->pi[kb][sq * 64][0], 16, 0, 0);
+  }
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
@@ -615,13 +646,13 @@ __device__ __forceinline__ void raw_barrier() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int FMT, int NWM, int NNI, int SKB, int NST, int BUF, int GRP, bool IDLE, int LEFT>
+template <int FMT, int NWM, int NNI, int SKB, int NST, int BUF, int GRP, bool IDLE, int LEFT, bool DIAG>
 __device__ __forceinline__ void pp_stage(StageI8<NWM, SKB>* lds, const int8_t* __restrict__ p, int npad,
                                          int64_t kb_begin, int s, int ns, int col_i, int col_j, int wave, int lane,
                                          int wm, int wn, typename AccType<FMT>::type (&acc)[4][NNI],
                                          FragsI8<NNI> (&f)[SKB / 2]) {
   constexpr int NWAVES = NWM * (8 / NNI);
-  constexpr int PER_WAVE = SKB * (2 * NWM + 4) / NWAVES;
+  constexpr int PER_WAVE = SKB * (DIAG ? 2 * NWM : 2 * NWM + 4) / NWAVES;
   constexpr int D = NST - 1;
   static_assert(D >= 1 && D * PER_WAVE < 64, "vmcnt is a 6-bit counter");
   // LEFT: the last LEFT MFMAs of a group's run are issued AFTER the barrier that ends its phase (at raised
@@ -632,12 +663,20 @@ __device__ __forceinline__ void pp_stage(StageI8<NWM, SKB>* lds, const int8_t* _
     // ---- phase 2s: read stage s, issue the DMA of stage s+D
     if constexpr (!IDLE) {
 #pragma unroll
-      for (int k2 = 0; k2 < SKB / 2; ++k2) load_frags_i8<NWM, NNI, SKB>(&lds[BUF], k2, wm, wn, lane, f[k2]);
+      for (int k2 = 0; k2 < SKB / 2; ++k2) {
+        if constexpr (DIAG) load_frags_diag<NWM, NNI, SKB>(&lds[BUF], k2, wm, wn, lane, f[k2]);
+        else load_frags_i8<NWM, NNI, SKB>(&lds[BUF], k2, wm, wn, lane, f[k2]);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (more)
-      issue_stage_i8<NWM, SKB, NWAVES>(&lds[(BUF + D) % NST], p, npad, kb_begin + (int64_t)(s + D) * SKB, col_i, col_j,
-                                       wave, lane);
+    if (more) {
+      if constexpr (DIAG)
+        issue_stage_diag<NWM, SKB, NWAVES>(&lds[(BUF + D) % NST], p, npad, kb_begin + (int64_t)(s + D) * SKB, col_i, wave,
+                                           lane);
+      else
+        issue_stage_i8<NWM, SKB, NWAVES>(&lds[(BUF + D) % NST], p, npad, kb_begin + (int64_t)(s + D) * SKB, col_i, col_j,
+                                         wave, lane);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     raw_barrier();
     // ---- phase 2s+1: the MFMAs of stage s
@@ -648,9 +687,14 @@ __device__ __forceinline__ void pp_stage(StageI8<NWM, SKB>* lds, const int8_t* _
     }
   } else {
     // ---- phase 2s: issue the DMA of stage s+D, then the MFMAs of stage s-1
-    if (more)
-      issue_stage_i8<NWM, SKB, NWAVES>(&lds[(BUF + D) % NST], p, npad, kb_begin + (int64_t)(s + D) * SKB, col_i, col_j,
-                                       wave, lane);
+    if (more) {
+      if constexpr (DIAG)
+        issue_stage_diag<NWM, SKB, NWAVES>(&lds[(BUF + D) % NST], p, npad, kb_begin + (int64_t)(s + D) * SKB, col_i, wave,
+                                           lane);
+      else
+        issue_stage_i8<NWM, SKB, NWAVES>(&lds[(BUF + D) % NST], p, npad, kb_begin + (int64_t)(s + D) * SKB, col_i, col_j,
+                                         wave, lane);
+    }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (!IDLE) {
       if (s > 0) {
@@ -671,7 +715,10 @@ __device__ __forceinline__ void pp_stage(StageI8<NWM, SKB>* lds, const int8_t* _
         }
       }
 #pragma unroll
-      for (int k2 = 0; k2 < SKB / 2; ++k2) load_frags_i8<NWM, NNI, SKB>(&lds[BUF], k2, wm, wn, lane, f[k2]);
+      for (int k2 = 0; k2 < SKB / 2; ++k2) {
+        if constexpr (DIAG) load_frags_diag<NWM, NNI, SKB>(&lds[BUF], k2, wm, wn, lane, f[k2]);
+        else load_frags_i8<NWM, NNI, SKB>(&lds[BUF], k2, wm, wn, lane, f[k2]);
+      }
     }
   }
   // end of phase 2s+1: stage s+1 must have landed (own share), only the DMA of stage s+2.. may stay in flight
@@ -692,28 +739,43 @@ __device__ __forceinline__ void pp_stage(StageI8<NWM, SKB>* lds, const int8_t* _
   }
 }
 
-template <int FMT, int NWM, int NNI, int SKB, int NST, int GRP, bool IDLE, int LEFT, int... Is>
+template <int FMT, int NWM, int NNI, int SKB, int NST, int GRP, bool IDLE, int LEFT, bool DIAG, int... Is>
 __device__ __forceinline__ void pp_round(StageI8<NWM, SKB>* lds, const int8_t* __restrict__ p, int npad,
                                          int64_t kb_begin, int s, int ns, int count, int col_i, int col_j, int wave,
                                          int lane, int wm, int wn, typename AccType<FMT>::type (&acc)[4][NNI],
                                          FragsI8<NNI> (&f)[SKB / 2], std::integer_sequence<int, Is...>) {
-  ((Is < count ? pp_stage<FMT, NWM, NNI, SKB, NST, Is, GRP, IDLE, LEFT>(lds, p, npad, kb_begin, s + Is, ns, col_i, col_j, wave,
+  ((Is < count ? pp_stage<FMT, NWM, NNI, SKB, NST, Is, GRP, IDLE, LEFT, DIAG>(lds, p, npad, kb_begin, s + Is, ns, col_i, col_j, wave,
                                                                   lane, wm, wn, acc, f)
                : (void)0),
    ...);
 }
 
-template <int FMT, int NWM, int NNI, int SKB, int NST, int GRP, bool IDLE, int LEFT>
+template <int FMT, int NWM, int NNI, int SKB, int NST, int GRP, bool IDLE, int LEFT, bool DIAG>
 __device__ __forceinline__ void pp_loop(StageI8<NWM, SKB>* lds, const int8_t* __restrict__ p, int npad,
                                         int64_t kb_begin, int ns, int col_i, int col_j, int wave, int lane, int wm,
                                         int wn, typename AccType<FMT>::type (&acc)[4][NNI]) {
   FragsI8<NNI> f[SKB / 2];
+  // prologue: stages 0 .. NST-2 go in flight; stage 0 must have landed before group 0 reads it in phase 0
+  constexpr int NWAVES = NWM * (8 / NNI);
+  constexpr int PER_WAVE = SKB * (DIAG ? 2 * NWM : 2 * NWM + 4) / NWAVES;
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i) {
+    if (i < ns) {
+      if constexpr (DIAG)
+        issue_stage_diag<NWM, SKB, NWAVES>(&lds[i], p, npad, kb_begin + (int64_t)i * SKB, col_i, wave, lane);
+      else
+        issue_stage_i8<NWM, SKB, NWAVES>(&lds[i], p, npad, kb_begin + (int64_t)i * SKB, col_i, col_j, wave, lane);
+    }
+  }
+  if (ns > 1 && NST > 2) wait_vmcnt<(NST > 2 ? PER_WAVE : 0)>();
+  else wait_vmcnt<0>();
+  raw_barrier();
   int s = 0;
   for (; s + NST - 1 < ns; s += NST)
-    pp_round<FMT, NWM, NNI, SKB, NST, GRP, IDLE, LEFT>(lds, p, npad, kb_begin, s, ns, NST, col_i, col_j, wave, lane, wm, wn, acc,
+    pp_round<FMT, NWM, NNI, SKB, NST, GRP, IDLE, LEFT, DIAG>(lds, p, npad, kb_begin, s, ns, NST, col_i, col_j, wave, lane, wm, wn, acc,
                                                  f, std::make_integer_sequence<int, NST>{});
   if (s < ns)
-    pp_round<FMT, NWM, NNI, SKB, NST, GRP, IDLE, LEFT>(lds, p, npad, kb_begin, s, ns, ns - s, col_i, col_j, wave, lane, wm, wn,
+    pp_round<FMT, NWM, NNI, SKB, NST, GRP, IDLE, LEFT, DIAG>(lds, p, npad, kb_begin, s, ns, ns - s, col_i, col_j, wave, lane, wm, wn,
                                                  acc, f, std::make_integer_sequence<int, NST - 1>{});
   if constexpr (GRP == 1 && !IDLE) {  // phase 2*ns: group 1's MFMAs of the last stage, nobody to wait for
 #pragma unroll
@@ -821,24 +883,26 @@ __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0;
 
+  if constexpr (PP) {
+    static_assert(!PP || (NWM == 2 && NNI == 2), "ping-pong: 8 waves, group = wave / 4 = wm");
+    if (row_blk == col_blk) {  // diagonal tile: one panel, below-diagonal waves idle (workgroup-uniform branch)
+      if (wm == 0) {
+        pp_loop<FMT, NWM, NNI, SKB, NST, 0, false, LEFT, true>(lds, p, npad, kb_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
+      } else if (idle) {
+        pp_loop<FMT, NWM, NNI, SKB, NST, 1, true, LEFT, true>(lds, p, npad, kb_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
+        return;
+      } else {
+        pp_loop<FMT, NWM, NNI, SKB, NST, 1, false, LEFT, true>(lds, p, npad, kb_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
+      }
+    } else if (wm == 0) {
+      pp_loop<FMT, NWM, NNI, SKB, NST, 0, false, LEFT, false>(lds, p, npad, kb_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
+    } else {
+      pp_loop<FMT, NWM, NNI, SKB, NST, 1, false, LEFT, false>(lds, p, npad, kb_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
+    }
+  } else {
   // prologue: stages 0 .. D-1 go in flight
   ring_prologue<NWM, SKB, NST, NWAVES>(lds, p, npad, kb_begin, ns, col_i, col_j, wave, lane,
                                       std::make_integer_sequence<int, NST - 1>{});
-  if constexpr (PP) {
-    static_assert(!PP || (NWM == 2 && NNI == 2), "ping-pong: 8 waves, group = wave / 4 = wm");
-    // stage 0 must have landed before group 0 reads it in phase 0
-    if (ns > 1 && NST > 2) wait_vmcnt<(NST > 2 ? SKB * (2 * NWM + 4) / NWAVES : 0)>();
-    else wait_vmcnt<0>();
-    raw_barrier();
-    if (wm == 0) {
-      pp_loop<FMT, NWM, NNI, SKB, NST, 0, false, LEFT>(lds, p, npad, kb_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
-    } else if (idle) {
-      pp_loop<FMT, NWM, NNI, SKB, NST, 1, true, LEFT>(lds, p, npad, kb_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
-      return;
-    } else {
-      pp_loop<FMT, NWM, NNI, SKB, NST, 1, false, LEFT>(lds, p, npad, kb_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
-    }
-  } else {
   int s = 0;
   if (idle) {  // wave-uniform: a separate loop with no accumulator traffic at all, then nothing to store
     for (; s + NST - 1 < ns; s += NST)
