@@ -957,11 +957,12 @@ size_t gram_packed_workspace_bytes(int32_t n, int64_t nv) {  // the int8 size al
   return (size_t)gram_packed_kb_pad_i8(nv) * (size_t)gram_packed_npad(n) * KB;
 }
 
+// nkb_out: k-blocks to write (the tail beyond nv is zero-filled); 0 = the padded count gram_kb_pad(nv, 1)
 hipError_t launch_pack_fp4(const void* x, int is_u8, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
-                           hipStream_t stream) {
+                           hipStream_t stream, int64_t nkb_out) {
   if (nv <= 0) return hipSuccess;
   const int npad = (int)gram_packed_npad(n);
-  const int64_t nkb_pad = gram_kb_pad(nv, 1);
+  const int64_t nkb_pad = nkb_out > 0 ? nkb_out : gram_kb_pad(nv, 1);
   const int64_t threads = nkb_pad * (npad >> 2);
   const int64_t blocks = (threads + 255) / 256;
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
@@ -990,11 +991,11 @@ hipError_t launch_pack_fp4(const void* x, int is_u8, int64_t ld, int64_t nv, int
 }
 
 hipError_t launch_expand_bits_fp4(const uint32_t* bits, int64_t ld_words, int64_t nv, int32_t n, int8_t* p,
-                                  hipStream_t stream) {
+                                  hipStream_t stream, int64_t nkb_out) {
   if (nv <= 0) return hipSuccess;
   const int npad = (int)gram_packed_npad(n);
-  const int64_t nkb_pad = gram_kb_pad(nv, 1);
-  const int64_t blocks = nkb_pad * (npad >> 8) / 4;  // nkb_pad is a multiple of 24: whole blocks of 4 waves
+  const int64_t nkb_pad = nkb_out > 0 ? nkb_out : gram_kb_pad(nv, 1);
+  const int64_t blocks = (nkb_pad * (npad >> 8) + 3) / 4;  // 4 waves per block, one (k-block, 256 samples) each
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
   const bool vec = ((ld_words & 3) == 0) && ((reinterpret_cast<uintptr_t>(bits) & 15) == 0);
   if (vec)

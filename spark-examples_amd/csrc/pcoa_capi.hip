@@ -67,6 +67,14 @@ struct pcoa_ctx {
   int32_t* fp4_flag = nullptr;     // device: raised by the FP4 pre-pass on a value other than 0 / 1
   int64_t fp4_fallbacks = 0;
   int i8_streak = 0;               // auto mode: chunks still to be sent straight to the int8 kernel after a fallback
+  // FP4 operand buffer: binary chunks are only PACKED when they arrive; the contraction runs once the buffer is
+  // full or S is needed (finalize / read / all-reduce / compute), so that one launch carries up to 2^22 variants
+  // whatever the size of the calls -- its int32-atomic epilogue (one per output tile and launch, 0.11 ms at N = 2504)
+  // is then paid once per buffer, not once per call.
+  int8_t* fp4_buf = nullptr;
+  int64_t fp4_cap_kb = 0;          // capacity in k-blocks of 32 variants (+24 of zero padding behind it)
+  int64_t fp4_kb = 0;              // k-blocks buffered
+  int64_t fp4_vars = 0;            // variants buffered (the last k-block of a chunk may be partly empty)
   int64_t pack_chunk = (int64_t)1 << 20;  // variants packed + contracted per launch pair
   int64_t pack_launches = 0;
   double pack_bytes = 0;
@@ -248,16 +256,67 @@ int fold_if_needed(pcoa_ctx* c, int64_t cur) {
   return PCOA_OK;
 }
 
+constexpr int64_t kBatchVariants = (int64_t)1 << 22;   // variants per FP4 contraction launch (fp32 exact below 2^24)
+constexpr int64_t kBatchBytes = (int64_t)6 << 30;      // cap of the FP4 operand buffer
+
+int64_t fp4_kb_bytes(const pcoa_ctx* c) { return gram_packed_npad(c->n) * 16; }
+
+// Contract what the FP4 operand buffer holds into S32.
+int fp4_flush(pcoa_ctx* c) {
+  if (c->fp4_kb == 0) return PCOA_OK;
+  int rc = fold_if_needed(c, c->fp4_vars);
+  if (rc != PCOA_OK) return rc;
+  const int64_t kb_pad = round_up(c->fp4_kb, 24);
+  if (kb_pad > c->fp4_kb)  // whole stages only: zero k-blocks behind the data
+    HIP_TRY(c, hipMemsetAsync(c->fp4_buf + c->fp4_kb * fp4_kb_bytes(c), 0, (size_t)((kb_pad - c->fp4_kb) * fp4_kb_bytes(c)),
+                              c->stream));
+  {
+    ScopedTimer t(c, T_GRAM);
+    hipError_t e = launch_gram_packed(c->fp4_buf, 1, c->fp4_kb * 32, c->n, c->s32, c->num_cu, c->stream, nullptr);
+    if (e != hipSuccess) return hip_fail(c, e, "packed gram kernel launch");
+  }
+  c->gram_kind = 3;
+  account_gram(c, c->fp4_vars);
+  c->fp4_kb = 0;
+  c->fp4_vars = 0;
+  return PCOA_OK;
+}
+
+// Room for kb more k-blocks at the end of the FP4 operand buffer (flushes / grows as needed).
+int fp4_reserve(pcoa_ctx* c, int64_t kb, int64_t chunk_variants) {
+  const int64_t by_vars = std::min(c->max_launch, kBatchVariants) / 32;
+  int64_t target = std::max<int64_t>(kb, std::min(by_vars, kBatchBytes / fp4_kb_bytes(c)));
+  if (c->max_launch < kBatchVariants) target = std::max<int64_t>(kb, c->max_launch / 32);  // test hook: small launches
+  if (c->fp4_kb + kb <= c->fp4_cap_kb) return PCOA_OK;
+  int rc = fp4_flush(c);
+  if (rc != PCOA_OK) return rc;
+  if (kb <= c->fp4_cap_kb && c->fp4_cap_kb >= target) return PCOA_OK;
+  // grow: straight to the target when the calls are large, geometrically when they are small
+  int64_t want = (chunk_variants >= ((int64_t)1 << 18)) ? target : std::min(target, std::max(kb, 2 * c->fp4_cap_kb));
+  if (want <= c->fp4_cap_kb) return PCOA_OK;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->fp4_buf) (void)hipFree(c->fp4_buf);
+  c->fp4_buf = nullptr;
+  c->fp4_cap_kb = 0;
+  for (;;) {
+    hipError_t e = hipMalloc((void**)&c->fp4_buf, (size_t)((want + 24) * fp4_kb_bytes(c)));
+    if (e == hipSuccess) break;
+    (void)hipGetLastError();
+    if (want <= kb) return hip_fail(c, e, "hipMalloc(FP4 operand buffer)");
+    want = std::max(kb, want / 2);  // less room, more launches
+  }
+  c->fp4_cap_kb = want;
+  return PCOA_OK;
+}
+
 // One chunk (<= pack_chunk variants) of a dense tile resident on the device: re-layout pre-pass into the
 // packed operand workspace, then the matrix-core contraction.
 //   auto : FP4 pre-pass (it also verifies that every value is exactly 0 or 1); if a tile holds a
 //          multiplicity the chunk is re-packed as int8 and contracted on the i8 MFMA instead;
 //   fp4  : FP4 only, a non-binary value is an error;   i8 : int8 only (values 0..127).
 int packed_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64_t ld) {
-  const int64_t need = (int64_t)gram_packed_workspace_bytes(c->n, cur);
-  int rc = ensure(c, &c->pack_buf, &c->pack_cap, need);
-  if (rc != PCOA_OK) return rc;
   const double in_bytes = (is_u8 ? 1.0 : 4.0) * (double)cur * (double)c->n;
+  int rc = PCOA_OK;
   bool fp4 = c->packed_mode != 2;
   if (fp4 && c->packed_mode == 0 && c->i8_streak > 0) {
     // the last FP4 attempt met multiplicities: do not pay for a second pre-pass on every chunk of such a cohort
@@ -265,6 +324,11 @@ int packed_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64
     fp4 = false;
   }
   if (fp4) {
+    // binary tile (to be verified by the pre-pass): packed behind what the FP4 operand buffer already holds; the
+    // contraction is deferred (fp4_flush)
+    const int64_t kb = (cur + 31) / 32;
+    if ((rc = fp4_reserve(c, kb, cur)) != PCOA_OK) return rc;
+    int8_t* dst = c->fp4_buf + c->fp4_kb * fp4_kb_bytes(c);
     int32_t* flag = c->err_flag;
     if (c->packed_mode == 0) {
       if (!c->fp4_flag) HIP_TRY(c, hipMalloc((void**)&c->fp4_flag, 16));
@@ -273,23 +337,34 @@ int packed_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64
     }
     {
       ScopedTimer t(c, T_PACK);
-      hipError_t e = launch_pack_fp4(x_chunk, is_u8, ld, cur, c->n, c->pack_buf, flag, c->stream);
+      hipError_t e = launch_pack_fp4(x_chunk, is_u8, ld, cur, c->n, dst, flag, c->stream, kb);
       if (e != hipSuccess) return hip_fail(c, e, "pack(fp4) kernel launch");
     }
     c->pack_launches += 1;
-    c->pack_bytes += in_bytes + 0.5 * (double)need;
+    c->pack_bytes += in_bytes + (double)(kb * fp4_kb_bytes(c));
     if (c->packed_mode == 0) {
       int32_t seen = 0;
       HIP_TRY(c, hipMemcpyAsync(&seen, c->fp4_flag, sizeof(seen), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
       if (seen) {  // a multiplicity (or garbage): this chunk takes the int8 path, which validates 0..127
-        fp4 = false;
+        fp4 = false;  // (what was just written behind the buffered k-blocks is simply not kept)
         c->fp4_fallbacks += 1;
         c->i8_streak = 8;  // then FP4 is tried again
       }
     }
+    if (fp4) {
+      c->fp4_kb += kb;
+      c->fp4_vars += cur;
+      c->gram_kind = 3;
+      c->dirty = true;
+      return PCOA_OK;
+    }
   }
-  if (!fp4) {
+  // int8 path: pre-pass into the workspace and contraction at once
+  if ((rc = fold_if_needed(c, cur)) != PCOA_OK) return rc;
+  const int64_t need = (int64_t)gram_packed_workspace_bytes(c->n, cur);
+  if ((rc = ensure(c, &c->pack_buf, &c->pack_cap, need)) != PCOA_OK) return rc;
+  {
     ScopedTimer t(c, T_PACK);
     hipError_t e = is_u8 ? launch_pack_u8_i8(static_cast<const uint8_t*>(x_chunk), ld, cur, c->n, c->pack_buf,
                                              c->err_flag, c->stream)
@@ -301,10 +376,11 @@ int packed_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64
   }
   {
     ScopedTimer t(c, T_GRAM);
-    hipError_t e = launch_gram_packed(c->pack_buf, fp4 ? 1 : 0, cur, c->n, c->s32, c->num_cu, c->stream, nullptr);
+    hipError_t e = launch_gram_packed(c->pack_buf, 0, cur, c->n, c->s32, c->num_cu, c->stream, nullptr);
     if (e != hipSuccess) return hip_fail(c, e, "packed gram kernel launch");
   }
-  c->gram_kind = fp4 ? 3 : 2;
+  c->gram_kind = 2;
+  account_gram(c, cur);
   return PCOA_OK;
 }
 
@@ -314,11 +390,8 @@ int gram_device_u8(pcoa_ctx* c, const uint8_t* x_dev, int64_t nv, int64_t ld) {
   const int64_t max_cur = std::min(c->max_launch, c->pack_chunk);
   while (done < nv) {
     const int64_t cur = std::min(nv - done, max_cur);
-    int rc = fold_if_needed(c, cur);
+    int rc = packed_chunk(c, x_dev + done * ld, 1, cur, ld);
     if (rc != PCOA_OK) return rc;
-    rc = packed_chunk(c, x_dev + done * ld, 1, cur, ld);
-    if (rc != PCOA_OK) return rc;
-    account_gram(c, cur);
     done += cur;
   }
   return PCOA_OK;
@@ -330,18 +403,16 @@ int gram_device(pcoa_ctx* c, const float* x_dev, int64_t nv, int64_t ld) {
   const int64_t max_cur = c->use_i8 ? std::min(c->max_launch, c->pack_chunk) : c->max_launch;
   while (done < nv) {
     const int64_t cur = std::min(nv - done, max_cur);
-    {
-      int rc = fold_if_needed(c, cur);
-      if (rc != PCOA_OK) return rc;
-    }
     if (c->use_i8) {
-      // fp32 tile -> packed operand (HBM-bound pre-pass), then the matrix-core contraction, back to back on
-      // one stream.  (Running the pre-pass on a second stream beside the contraction was measured
-      // SLOWER, 5.45 vs 5.09 ms per 10^6 variants: both kernels want all 256 CUs and the resident
-      // pre-pass waves block placement of the 96 KiB-LDS contraction workgroups.)
+      // fp32 tile -> packed operand (HBM-bound pre-pass); the matrix-core contraction follows at once (int8) or when
+      // the FP4 operand buffer is full / S is needed (packed_chunk accounts for itself)
       int rc = packed_chunk(c, x_dev + done * ld, 0, cur, ld);
       if (rc != PCOA_OK) return rc;
+      done += cur;
+      continue;
     } else {
+      int rc = fold_if_needed(c, cur);
+      if (rc != PCOA_OK) return rc;
       GramLaunch g;
       g.x = x_dev + done * ld;
       g.ld = ld;
@@ -419,6 +490,8 @@ int ensure_b(pcoa_ctx* c) {
 }
 
 int finalize_impl(pcoa_ctx* c) {
+  int rc0 = fp4_flush(c);  // deferred FP4 contractions land in S32 now
+  if (rc0 != PCOA_OK) return rc0;
   if (c->dirty) {
     ScopedTimer t(c, T_FINALIZE);
     HIP_TRY(c, launch_symmetrize_i32(c->s32, c->n, c->stream));
@@ -528,7 +601,7 @@ void pcoa_destroy(pcoa_ctx* c) {
   for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto& ev : c->pool) (void)hipEventDestroy(ev);
   void* bufs[] = {c->s32, c->s64, c->zeros, c->err_flag, c->tile, c->csr_idx, c->csr_offs, c->thr_dev,
-                  c->sample_pop, c->xfer, c->coll, c->fp4_flag, c->pack_buf, c->lanczos_ws, c->ws.a, c->ws.d, c->ws.e, c->ws.tau, c->ws.q, c->ws.w, c->ws.lam,
+                  c->sample_pop, c->xfer, c->coll, c->fp4_flag, c->fp4_buf, c->pack_buf, c->lanczos_ws, c->ws.a, c->ws.d, c->ws.e, c->ws.tau, c->ws.q, c->ws.w, c->ws.lam,
                   c->ws.z, c->ws.scratch, c->ws.iscratch, c->row_sums, c->colmean, c->stats, c->nz,
                   c->out_dev};
   for (void* b : bufs)
@@ -562,6 +635,8 @@ int pcoa_reset(pcoa_ctx* c) {
   if (c->s64) HIP_TRY(c, hipMemsetAsync(c->s64, 0, sizeof(int64_t) * nn, c->stream));
   HIP_TRY(c, hipMemsetAsync(c->err_flag, 0, 16, c->stream));
   c->variants_in_s32 = 0;
+  c->fp4_kb = 0;  // buffered, not yet contracted operands belong to the old S
+  c->fp4_vars = 0;
   c->dirty = false;
   return PCOA_OK;
 }
@@ -621,25 +696,21 @@ int gram_device_bits(pcoa_ctx* c, const uint32_t* bits_dev, int64_t nv, int64_t 
   const int64_t max_cur = std::min(c->max_launch, c->pack_chunk);
   while (done < nv) {
     const int64_t cur = std::min(nv - done, max_cur);
-    int rc = fold_if_needed(c, cur);
-    if (rc != PCOA_OK) return rc;
-    const int64_t need = (int64_t)gram_packed_workspace_bytes(c->n, cur);
-    rc = ensure(c, &c->pack_buf, &c->pack_cap, need);
+    const int64_t kb = (cur + 31) / 32;
+    int rc = fp4_reserve(c, kb, cur);  // bitsets are binary by construction: straight into the FP4 operand buffer
     if (rc != PCOA_OK) return rc;
     {
       ScopedTimer t(c, T_PACK);
-      hipError_t e = launch_expand_bits_fp4(bits_dev + done * ld_words, ld_words, cur, c->n, c->pack_buf, c->stream);
+      hipError_t e = launch_expand_bits_fp4(bits_dev + done * ld_words, ld_words, cur, c->n,
+                                            c->fp4_buf + c->fp4_kb * fp4_kb_bytes(c), c->stream, kb);
       if (e != hipSuccess) return hip_fail(c, e, "expand(bits) kernel launch");
     }
     c->pack_launches += 1;
-    c->pack_bytes += 4.0 * (double)((c->n + 31) / 32) * (double)cur + 0.5 * (double)need;
-    {
-      ScopedTimer t(c, T_GRAM);
-      hipError_t e = launch_gram_packed(c->pack_buf, 1, cur, c->n, c->s32, c->num_cu, c->stream, nullptr);
-      if (e != hipSuccess) return hip_fail(c, e, "packed gram kernel launch");
-    }
+    c->pack_bytes += 4.0 * (double)((c->n + 31) / 32) * (double)cur + (double)(kb * fp4_kb_bytes(c));
+    c->fp4_kb += kb;
+    c->fp4_vars += cur;
     c->gram_kind = 3;
-    account_gram(c, cur);
+    c->dirty = true;
     done += cur;
   }
   return PCOA_OK;
@@ -812,6 +883,8 @@ int pcoa_gram_import_device_i64(pcoa_ctx* c, const int64_t* src_dev) {
   HIP_TRY(c, hipMemcpyAsync(c->s64, src_dev, sizeof(int64_t) * nn, hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(c, hipMemsetAsync(c->s32, 0, sizeof(int32_t) * nn, c->stream));
   c->variants_in_s32 = 0;
+  c->fp4_kb = 0;  // S is replaced: what was buffered for the old S goes with it
+  c->fp4_vars = 0;
   c->dirty = false;
   return PCOA_OK;
 }
