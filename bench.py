@@ -231,7 +231,12 @@ def main():
             kdesc = "fp32 MFMA v_mfma_f32_32x32x2_f32, upper-triangular 128x128 tiles, split-K"
         frac_syrk = syrk_fraction(n, tile)
         roof_gram = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                     "frac": achieved / peak, "traffic": pmc.get("gram_hbm_bytes_per_launch"),
+                     "frac": achieved / peak,
+                     # PMC traffic is stored per 10^6 variants (launch sizes differ: the FP4 contraction runs once per
+                     # <= 2^22 buffered variants) and scaled to this run's average launch, like `achieved`
+                     "traffic": (pmc["gram_hbm_bytes_per_mvariants"] * (tim["gram_variants"] / launches) / 1e6
+                                 if "gram_hbm_bytes_per_mvariants" in pmc else pmc.get("gram_hbm_bytes_per_launch")),
+                     "variants_per_launch": tim["gram_variants"] / launches,
                      "kernel": kname, "avg_launch_ms": 1e3 * kern_s, "launches": launches,
                      "flops_convention": "algorithmic 2*V*N^2 per launch (integer MACs count 2 ops); the kernel "
                                          "issues the SYRK half (upper-triangular tiles only: %.3f of the MFMA work)"
@@ -243,7 +248,9 @@ def main():
             pack_s = tim["pack_seconds"] / pl
             pack_gbs = tim["pack_bytes"] / pl / pack_s / 1e9 if pack_s > 0 else 0.0
             roof_pack = {"bound": "hbm", "achieved": pack_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": pack_gbs / PEAK_HBM_GBS, "traffic": pmc.get("pack_hbm_bytes_per_launch"),
+                         "frac": pack_gbs / PEAK_HBM_GBS,
+                         "traffic": (pmc["pack_hbm_bytes_per_mvariants"] * (tim["gram_variants"] / pl) / 1e6
+                                     if "pack_hbm_bytes_per_mvariants" in pmc else pmc.get("pack_hbm_bytes_per_launch")),
                          "kernel": "pack_fp4_kernel<float, 4, true>" if kind == 3 else "pack_f32_i8_kernel<4>",
                          "avg_launch_ms": 1e3 * pack_s, "launches": pl,
                          "bytes_convention": "algorithmic 4*V*N read + V*Npad%s written per launch"
