@@ -245,6 +245,47 @@ def test_auto_mode_picks_fp4_per_chunk_and_falls_back_to_int8_on_multiplicities(
         assert t["fp4_fallbacks"] == 0 and t["gram_kernel_kind"] == 3
 
 
+def test_deferred_fp4_contraction_flushes_where_s_is_needed(P, O):
+    """Binary chunks are only packed when they arrive; the contraction runs when the operand buffer is full or S is
+    needed.  Many small calls -> one launch; reset / load_gram drop what was buffered for the old S; int8 chunks in
+    between run at once; every reader of S sees the buffered calls."""
+    rng = np.random.default_rng(91)
+    n = 130
+    xs = [(rng.random((v, n)) < 0.3).astype(np.float32) for v in (1, 31, 32, 33, 100, 7, 64)]
+    want = sum(O.similarity_from_dense(x, n) for x in xs)
+    with P.PcoaEngine(n) as eng:
+        eng.reset_timings()
+        for x in xs:
+            eng.accumulate_dense(x)
+        t = eng.timings()
+        assert t["gram_kernel_launches"] == 0 and t["pack_launches"] == len(xs)     # nothing contracted yet
+        assert np.array_equal(eng.gram(), want)                                      # the read flushes
+        assert eng.timings()["gram_kernel_launches"] == 1
+        assert np.array_equal(eng.gram_block(3, 5, 20, 30), want[3:23, 5:35])
+        # buffered operands belong to the S they were accumulated for
+        eng.accumulate_dense(xs[4])
+        eng.reset()
+        assert not eng.gram().any()
+        eng.accumulate_dense(xs[4])
+        eng.load_gram(want)
+        eng.accumulate_dense(xs[0])
+        assert np.array_equal(eng.gram(), want + O.similarity_from_dense(xs[0], n))
+        # an int8 chunk between FP4 chunks, bitsets and uint8 on top, then the PCA consumes all of it
+        eng.reset()
+        xm = xs[3].copy()
+        xm[2, 7] = 5.0
+        eng.accumulate_dense(xs[4])
+        eng.accumulate_dense(xm)
+        eng.accumulate_dense_u8(xs[5].astype(np.uint8))
+        eng.accumulate_bits(load_pkg("ingest").pack_bits(xs[6]))
+        s_all = (O.similarity_from_dense(xs[4], n) + (xm.T.astype(np.int64) @ xm.astype(np.int64))
+                 + O.similarity_from_dense(xs[5], n) + O.similarity_from_dense(xs[6], n))
+        comps, lam, nz = eng.compute(2)                                              # compute flushes too
+        ref = O.compute_pca(s_all, 2)
+        assert np.abs(align_sign(comps, ref["components"]) - ref["components"]).max() < EIG_TOL
+        assert np.array_equal(eng.gram(), s_all)
+
+
 def test_empty_and_ragged_inputs(P):
     with P.PcoaEngine(7) as eng:
         eng.accumulate_calls(np.zeros(0, dtype=np.int32), np.zeros(1, dtype=np.int64))       # no variants
