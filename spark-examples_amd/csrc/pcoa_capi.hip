@@ -282,29 +282,41 @@ int fp4_flush(pcoa_ctx* c) {
   return PCOA_OK;
 }
 
-// Room for kb more k-blocks at the end of the FP4 operand buffer (flushes / grows as needed).
+// Room for kb more k-blocks at the end of the FP4 operand buffer.  The buffer grows (contents kept) until it reaches
+// its target size -- straight away when the calls are large, geometrically when they are small -- and is only
+// contracted (fp4_flush) once that is full.
 int fp4_reserve(pcoa_ctx* c, int64_t kb, int64_t chunk_variants) {
-  const int64_t by_vars = std::min(c->max_launch, kBatchVariants) / 32;
-  int64_t target = std::max<int64_t>(kb, std::min(by_vars, kBatchBytes / fp4_kb_bytes(c)));
-  if (c->max_launch < kBatchVariants) target = std::max<int64_t>(kb, c->max_launch / 32);  // test hook: small launches
   if (c->fp4_kb + kb <= c->fp4_cap_kb) return PCOA_OK;
-  int rc = fp4_flush(c);
-  if (rc != PCOA_OK) return rc;
-  if (kb <= c->fp4_cap_kb && c->fp4_cap_kb >= target) return PCOA_OK;
-  // grow: straight to the target when the calls are large, geometrically when they are small
-  int64_t want = (chunk_variants >= ((int64_t)1 << 18)) ? target : std::min(target, std::max(kb, 2 * c->fp4_cap_kb));
-  if (want <= c->fp4_cap_kb) return PCOA_OK;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (c->fp4_buf) (void)hipFree(c->fp4_buf);
-  c->fp4_buf = nullptr;
-  c->fp4_cap_kb = 0;
+  const int64_t per_kb = fp4_kb_bytes(c);
+  int64_t target = std::min(std::min(c->max_launch, kBatchVariants) / 32, kBatchBytes / per_kb);
+  target = std::max<int64_t>(target, kb);
+  if (c->fp4_cap_kb >= target || c->fp4_kb + kb > target) {  // full: contract what is there
+    int rc = fp4_flush(c);
+    if (rc != PCOA_OK) return rc;
+    if (kb <= c->fp4_cap_kb) return PCOA_OK;
+  }
+  const int64_t floor_kb = std::max<int64_t>(1, std::min<int64_t>(1024, ((int64_t)256 << 20) / per_kb));
+  int64_t want = (chunk_variants >= ((int64_t)1 << 18))
+                     ? target
+                     : std::min(target, std::max(std::max(c->fp4_kb + kb, floor_kb), 2 * c->fp4_cap_kb));
+  int8_t* fresh = nullptr;
   for (;;) {
-    hipError_t e = hipMalloc((void**)&c->fp4_buf, (size_t)((want + 24) * fp4_kb_bytes(c)));
+    hipError_t e = hipMalloc((void**)&fresh, (size_t)((want + 24) * per_kb));
     if (e == hipSuccess) break;
     (void)hipGetLastError();
-    if (want <= kb) return hip_fail(c, e, "hipMalloc(FP4 operand buffer)");
-    want = std::max(kb, want / 2);  // less room, more launches
+    if (want <= c->fp4_kb + kb) {       // no room to grow: contract, then make do with what fits
+      int rc = fp4_flush(c);
+      if (rc != PCOA_OK) return rc;
+      if (kb <= c->fp4_cap_kb) return PCOA_OK;
+      if (want <= kb) return hip_fail(c, e, "hipMalloc(FP4 operand buffer)");
+    }
+    want = std::max(c->fp4_kb + kb, want / 2);
   }
+  if (c->fp4_kb > 0)
+    HIP_TRY(c, hipMemcpyAsync(fresh, c->fp4_buf, (size_t)(c->fp4_kb * per_kb), hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // the old buffer may still be read by queued kernels
+  if (c->fp4_buf) (void)hipFree(c->fp4_buf);
+  c->fp4_buf = fresh;
   c->fp4_cap_kb = want;
   return PCOA_OK;
 }
