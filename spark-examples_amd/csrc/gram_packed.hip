@@ -29,7 +29,7 @@
 //   PCOA_GRAM_I8_CFG=43 selects the in-phase ring, 143 the
 //   ping-pong schedule without the two MFMAs issued behind the phase barrier.
 //
-// Measured, N = 2504, 10^6 variants per launch: FP4 1.24 ms (5.5 PFLOP/s issued), int8 2.20 ms; DESIGN.md 4.0 / 4.0a.
+// Measured at N = 2504 per 10^6 variants: FP4 1.13-1.16 ms (6 PFLOP/s issued), int8 2.14 ms; DESIGN.md 4.1 / 4.2.
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
