@@ -170,9 +170,12 @@ int pcoa_accumulate_synthetic(pcoa_ctx* ctx, const pcoa_synth_params* params, in
 int pcoa_synth_fill_f32(pcoa_ctx* ctx, const pcoa_synth_params* params, int64_t first_variant,
                         int64_t n_variants, float* x_dev, int64_t ld);
 
-/* Completes the local accumulation: mirrors the computed triangle, folds int32 partials.
+/* Completes the local accumulation: contracts what the accumulate calls have only packed so far (binary tiles
+ * are re-laid out into the FP4 operand buffer when they arrive and contracted once per <= 2^22 buffered variants,
+ * or here -- every reader of S below does the same), mirrors the computed triangle, folds int32 partials.
  * After it the full symmetric S of THIS ctx is readable.  Accumulation may continue afterwards
- * (S is additive: a natural checkpoint/resume point).
+ * (S is additive: a natural checkpoint/resume point).  Inputs of the accumulate calls are consumed by their
+ * pre-pass: a device pointer has to stay valid until the next synchronising call, not until the contraction.
  * Replaces (single GPU): reduceByKey(_ + _) (VariantsPca.scala:190). */
 int pcoa_gram_finalize(pcoa_ctx* ctx);
 
