@@ -187,6 +187,30 @@ __global__ __launch_bounds__(256) void densify_csr_i8_kernel(const int32_t* __re
   }
 }
 
+// CSR carrier lists WITHOUT repeats (the host checks) straight into the FP4 operand: one wave per variant row, the
+// nibble of variant (row % 32) in sample c's 16-byte slot of k-block row / 32 is set to 0x2 through a 32-bit atomic
+// OR (the 32 rows of a k-block share the slots).  The region must be zero-filled beforehand.
+__global__ __launch_bounds__(256) void densify_csr_fp4_kernel(const int32_t* __restrict__ idx,
+                                                              const int64_t* __restrict__ offs, int64_t nv,
+                                                              int64_t offs_base, int8_t* __restrict__ p, int npad,
+                                                              int32_t n, int32_t* __restrict__ flag) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nv) return;
+  const int64_t b = offs[row] - offs_base, e = offs[row + 1] - offs_base;
+  const int64_t kb = row / 32;
+  const int t = (int)(row % 32);
+  for (int64_t q = b + lane; q < e; q += 64) {
+    const int32_t c = idx[q];
+    if (c < 0 || c >= n) {
+      atomicOr(flag, 1);
+      continue;
+    }
+    uint32_t* word = reinterpret_cast<uint32_t*>(p + ((size_t)kb * npad + c) * 16) + (t >> 3);
+    atomicOr(word, 2u << (4 * (t & 7)));
+  }
+}
+
 // ---- FP4 pre-pass: X (fp32 or uint8, values exactly 0 / 1) -> P4 [V/32][Npad][16 B], 32 nibbles per lane slice.
 // One thread: 32 variants x 4 samples, in two halves of 16 variants (8 bytes of each sample's slice per half).
 // flag bit 3 (value 8) is raised for a value that is not exactly 0 or 1.
@@ -1051,6 +1075,18 @@ hipError_t launch_densify_csr_i8(const int32_t* idx_dev, const int64_t* offs_dev
 
 hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, int32_t* s32, int num_cu,
                               hipStream_t stream, int* splitk_out);
+
+// carrier lists without repeated callsets -> nkb_out = ceil(nv / 32) k-blocks of FP4 operand at p
+hipError_t launch_densify_csr_fp4(const int32_t* idx_dev, const int64_t* offs_dev, int64_t nv, int64_t offs_base,
+                                  int8_t* p, int32_t n, int32_t* flag, hipStream_t stream, int64_t nkb_out) {
+  if (nv <= 0) return hipSuccess;
+  const int npad = (int)gram_packed_npad(n);
+  hipError_t e = hipMemsetAsync(p, 0, (size_t)nkb_out * (size_t)npad * 16, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(densify_csr_fp4_kernel, dim3((unsigned)((nv + 3) / 4)), dim3(256), 0, stream, idx_dev, offs_dev, nv,
+                     offs_base, p, npad, n, flag);
+  return hipGetLastError();
+}
 
 hipError_t launch_gram_i8_packed(const int8_t* p, int64_t nv, int32_t n, int32_t* s32, int num_cu,
                                  hipStream_t stream, int* splitk_out) {

@@ -775,6 +775,25 @@ int pcoa_accumulate_calls(pcoa_ctx* c, const int32_t* sample_idx, const int64_t*
       return fail(c, PCOA_ERR_INDEX_RANGE, buf);
     }
   }
+  // Does any carrier list repeat a callset?  The reference's double loop counts a repeat with multiplicity
+  // (VariantsPca.scala:187), which only the int8 / fp32 kernels can express; lists that are SETS go to the FP4 operand.
+  bool any_repeat = false;
+  if (c->use_i8 && c->packed_mode != 2) {
+    std::vector<uint32_t> seen(((size_t)c->n + 31) / 32, 0u);
+    for (int64_t v = 0; v < n_variants && !any_repeat; ++v) {
+      const int64_t b = row_offsets[v], e = row_offsets[v + 1];
+      for (int64_t p = b; p < e; ++p) {
+        const uint32_t s = (uint32_t)sample_idx[p], bit = 1u << (s & 31);
+        if (seen[s >> 5] & bit) { any_repeat = true; break; }
+        seen[s >> 5] |= bit;
+      }
+      for (int64_t p = b; p < e; ++p) seen[(uint32_t)sample_idx[p] >> 5] = 0u;
+    }
+    if (any_repeat && c->packed_mode == 3)
+      return fail(c, PCOA_ERR_INVALID_ARG,
+                  "a carrier list repeats a callset (multiplicity > 1) and PCOA_FLAG_GRAM_FP4_MFMA was forced");
+  }
+  const bool csr_fp4 = c->use_i8 && c->packed_mode != 2 && !any_repeat;
   const int64_t ld4 = round_up(c->n, 4);
   const int64_t rows_cap = staging_rows(n_variants, ld4);
   int rc = PCOA_OK;
@@ -795,6 +814,21 @@ int pcoa_accumulate_calls(pcoa_ctx* c, const int32_t* sample_idx, const int64_t*
                               c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->csr_offs, row_offsets + v0, sizeof(int64_t) * (size_t)(rows + 1),
                               hipMemcpyHostToDevice, c->stream));
+    if (csr_fp4) {
+      // carrier SETS -> FP4 operand, appended to the operand buffer; the contraction is deferred (fp4_flush)
+      const int64_t kb = (rows + 31) / 32;
+      if ((rc = fp4_reserve(c, kb, rows)) != PCOA_OK) return rc;
+      {
+        ScopedTimer t(c, T_DENSIFY);
+        HIP_TRY(c, launch_densify_csr_fp4(c->csr_idx, c->csr_offs, rows, b, c->fp4_buf + c->fp4_kb * fp4_kb_bytes(c),
+                                          c->n, c->err_flag, c->stream, kb));
+      }
+      c->fp4_kb += kb;
+      c->fp4_vars += rows;
+      c->gram_kind = 3;
+      c->dirty = true;
+      continue;
+    }
     if (c->use_i8) {
       // carriers -> k-blocked int8 operand directly (no fp32 tile, no pre-pass), then the i8 contraction
       rc = fold_if_needed(c, rows);
@@ -810,7 +844,7 @@ int pcoa_accumulate_calls(pcoa_ctx* c, const int32_t* sample_idx, const int64_t*
         ScopedTimer t(c, T_GRAM);
         HIP_TRY(c, launch_gram_i8_packed(c->pack_buf, rows, c->n, c->s32, c->num_cu, c->stream, nullptr));
       }
-      c->gram_kind = 2;  // carrier lists may repeat a callset: always the int8 kernel
+      c->gram_kind = 2;  // a carrier list repeats a callset (or int8 was forced)
       account_gram(c, rows);
       continue;
     }

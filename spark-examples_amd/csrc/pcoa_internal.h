@@ -42,6 +42,8 @@ hipError_t launch_densify_csr_i8(const int32_t* idx_dev, const int64_t* offs_dev
                                  int8_t* p, int32_t n, int32_t* flag, hipStream_t stream);
 // FP4 (MX E2M1) variant: fmt 1 = 32 variants per 16-byte lane slice, values must be exactly 0 / 1
 int64_t gram_kb_pad(int64_t nv, int fmt);
+hipError_t launch_densify_csr_fp4(const int32_t* idx_dev, const int64_t* offs_dev, int64_t nv, int64_t offs_base,
+                                  int8_t* p, int32_t n, int32_t* flag, hipStream_t stream, int64_t nkb_out);
 hipError_t launch_expand_bits_fp4(const uint32_t* bits, int64_t ld_words, int64_t nv, int32_t n, int8_t* p,
                                   hipStream_t stream, int64_t nkb_out = 0);
 hipError_t launch_pack_fp4(const void* x, int is_u8, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,

@@ -114,8 +114,17 @@ def test_repeated_indices_count_with_multiplicity_like_the_reference_double_loop
     want = O.similarity_matrix_python_loops(callsets, 4)
     assert want[0, 0] == 4 and want[2, 2] == 10
     with P.PcoaEngine(4, gram_kernel=kernel) as eng:
+        if kernel == "fp4":   # a repeated callset is a multiplicity: the forced FP4 engine refuses it
+            with pytest.raises(P.PcoaError):
+                eng.accumulate_callsets(callsets)
+            return
         eng.accumulate_callsets(callsets)
         assert np.array_equal(eng.gram(), want)
+        assert eng.timings()["gram_kernel_kind"] == (1 if kernel == "f32" else 2)   # never the FP4 kernel
+        eng.reset()
+        eng.accumulate_callsets([sorted(set(c)) for c in callsets])                 # the same lists as SETS
+        assert np.array_equal(eng.gram(), O.similarity_matrix_python_loops([sorted(set(c)) for c in callsets], 4))
+        assert eng.timings()["gram_kernel_kind"] == {"f32": 1, "i8": 2}.get(kernel, 3)
 
 
 @pytest.mark.parametrize("n,v", [(5, 3), (64, 100), (300, 777), (1030, 200)])
