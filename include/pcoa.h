@@ -130,7 +130,9 @@ int pcoa_sync(pcoa_ctx* ctx);
  * Replaces: the mapPartitions body of getSimilarityMatrix (VariantsPca.scala:184-189) and
  * sum_similarity (variants_pca.py:67-72).  Empty rows are legal (they add nothing; the reference
  * filters them at :166).  Repeated indices within a row count with multiplicity, as the
- * reference's double loop does.  An index outside [0, N) -> PCOA_ERR_INDEX_RANGE, S unchanged by
+ * reference's double loop does (such a call runs on the int8 kernel; a call whose rows are sets --
+ * everything a VCF yields -- goes to the MX-FP4 kernel; PCOA_FLAG_GRAM_FP4_MFMA turns a repeat into
+ * PCOA_ERR_INVALID_ARG).  An index outside [0, N) -> PCOA_ERR_INDEX_RANGE, S unchanged by
  * that call's remaining chunks (reported at the next synchronising call at the latest). */
 int pcoa_accumulate_calls(pcoa_ctx* ctx, const int32_t* sample_idx, const int64_t* row_offsets,
                           int64_t n_variants);
