@@ -765,29 +765,27 @@ int pcoa_accumulate_calls(pcoa_ctx* c, const int32_t* sample_idx, const int64_t*
   // validate before touching S: the reference throws on an unknown callset (VariantsPca.scala:59)
   for (int64_t v = 0; v < n_variants; ++v)
     if (row_offsets[v + 1] < row_offsets[v]) return fail(c, PCOA_ERR_INVALID_ARG, "row_offsets not monotone");
-  const int64_t base0 = row_offsets[0];
-  for (int64_t p = 0; p < nnz_total; ++p) {
-    const int32_t s = sample_idx[base0 + p];
-    if (s < 0 || s >= c->n) {
-      char buf[160];
-      std::snprintf(buf, sizeof(buf), "callset index %d out of range [0, %d) at entry %lld", s, c->n,
-                    (long long)(base0 + p));
-      return fail(c, PCOA_ERR_INDEX_RANGE, buf);
-    }
-  }
-  // Does any carrier list repeat a callset?  The reference's double loop counts a repeat with multiplicity
-  // (VariantsPca.scala:187), which only the int8 / fp32 kernels can express; lists that are SETS go to the FP4 operand.
+  // One pass over the entries: range check, and -- for the packed engines -- whether any carrier list repeats a
+  // callset (last[s] remembers the last row that named s).  The reference's double loop counts a repeat with
+  // multiplicity (VariantsPca.scala:187), which only the int8 / fp32 kernels can express; lists that are SETS go to the
+  // FP4 operand.
   bool any_repeat = false;
-  if (c->use_i8 && c->packed_mode != 2) {
-    std::vector<uint32_t> seen(((size_t)c->n + 31) / 32, 0u);
-    for (int64_t v = 0; v < n_variants && !any_repeat; ++v) {
-      const int64_t b = row_offsets[v], e = row_offsets[v + 1];
-      for (int64_t p = b; p < e; ++p) {
-        const uint32_t s = (uint32_t)sample_idx[p], bit = 1u << (s & 31);
-        if (seen[s >> 5] & bit) { any_repeat = true; break; }
-        seen[s >> 5] |= bit;
+  {
+    const bool want_repeats = c->use_i8 && c->packed_mode != 2;
+    std::vector<int64_t> last(want_repeats ? (size_t)c->n : 0, (int64_t)-1);
+    for (int64_t v = 0; v < n_variants; ++v) {
+      for (int64_t p = row_offsets[v]; p < row_offsets[v + 1]; ++p) {
+        const int32_t s = sample_idx[p];
+        if (s < 0 || s >= c->n) {
+          char buf[160];
+          std::snprintf(buf, sizeof(buf), "callset index %d out of range [0, %d) at entry %lld", s, c->n, (long long)p);
+          return fail(c, PCOA_ERR_INDEX_RANGE, buf);
+        }
+        if (want_repeats) {
+          any_repeat |= (last[(size_t)s] == v);
+          last[(size_t)s] = v;
+        }
       }
-      for (int64_t p = b; p < e; ++p) seen[(uint32_t)sample_idx[p] >> 5] = 0u;
     }
     if (any_repeat && c->packed_mode == 3)
       return fail(c, PCOA_ERR_INVALID_ARG,
