@@ -235,6 +235,16 @@ def main():
     ids, variants = make_variants(np.random.default_rng(3), 6, 1, with_edges=False)
     variants[0]["calls"][2]["genotype"] = [1, 0]
     run_case(ns, "single6", ids, variants, 1)
+    # 5. wider than one 64-sample MFMA column block, five partitions, ragged records, a triploid call
+    rng = np.random.default_rng(70)
+    ids, variants = make_variants(rng, 70, 300)
+    variants[3]["calls"][0]["genotype"] = [0, 2, 1]
+    run_case(ns, "wide70", ids, variants, 5)
+    # 6. dense carriers, a single partition, N just over a 32-sample MFMA tile
+    rng = np.random.default_rng(33)
+    ids, variants = make_variants(rng, 33, 400, pop_freq=np.stack([np.full(33, 0.8), np.full(33, 0.45)]),
+                                  with_edges=False)
+    run_case(ns, "dense33", ids, variants, 1)
 
 
 if __name__ == "__main__":
