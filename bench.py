@@ -241,7 +241,9 @@ def main():
                      "flops_convention": "algorithmic 2*V*N^2 per launch (integer MACs count 2 ops); the kernel "
                                          "issues the SYRK half (upper-triangular tiles only: %.3f of the MFMA work)"
                                          % frac_syrk,
-                     "issued_tflops": achieved * frac_syrk, "issued_frac": achieved * frac_syrk / peak}
+                     "issued_tflops": achieved * frac_syrk, "issued_frac": achieved * frac_syrk / peak,
+                     "frac_note": "frac follows the algorithmic convention (both triangles of S credited) and can exceed 1; "
+                                  "issued_frac is the share of the matrix-core peak the kernel actually issues"}
         roof_pack = None
         if kind != 1 and tim["pack_launches"] > 0:
             pl = int(tim["pack_launches"])
