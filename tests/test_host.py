@@ -24,6 +24,39 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert b"gfx950" in lib.pcoa_version()
 
 
+def test_header_is_plain_c_and_a_c_client_links_against_the_library(tmp_path):
+    """include/pcoa.h is the drop-in boundary: it must compile as strict C99 (no C++ types in the signatures) and a
+    plain C program must link against libpcoa_hip.so -- what a cgo / JNI / FFI binding does.  Without a GPU the
+    client sees PCOA_ERR_NO_DEVICE and a message, never a crash or a CPU fallback."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("gcc not available")
+    src = tmp_path / "client.c"
+    src.write_text(
+        '#include <stdio.h>\n#include "pcoa.h"\n'
+        "int main(void) {\n"
+        "  pcoa_ctx* ctx = NULL;\n"
+        "  pcoa_timings t; pcoa_synth_params sp; (void)t; (void)sp;\n"
+        '  printf("%s\\n", pcoa_version());\n'
+        "  int rc = pcoa_create(&ctx, 8, 0, PCOA_FLAG_DEFAULT);\n"
+        '  printf("rc=%d %s\\n", rc, pcoa_last_error(NULL));\n'
+        "  if (rc == PCOA_OK) { pcoa_destroy(ctx); return 0; }\n"
+        "  return (rc == PCOA_ERR_NO_DEVICE && ctx == NULL) ? 0 : 1;\n"
+        "}\n")
+    libdir = os.path.join(ROOT, "spark-examples_amd")
+    exe = str(tmp_path / "client")
+    res = subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                          str(src), "-o", exe, "-L", libdir, "-lpcoa_hip", "-Wl,-rpath," + libdir,
+                          "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    assert res.returncode == 0, res.stdout
+    run = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    assert run.returncode == 0, run.stdout
+    assert "gfx950" in run.stdout
+
+
 def test_no_cpu_fallback_without_a_gpu():
     import torch
     if torch.cuda.is_available():
