@@ -267,6 +267,14 @@ def java_double_to_string(d, shortest=None):
 
 
 # --------------------------------------------------------------------------------------------- driver
+def similarity_entries_nonzero(s):
+    """RDD[((Int, Int), Int)] of getSimilarityMatrixStream (VariantsPca.scala:262-279) from a dense S: the keys whose
+    count is non-zero, both triangles (the reference emits the pairs c1 <= c2 and mirrors the strict upper ones)."""
+    s = np.asarray(s)
+    rows, cols = np.nonzero(s)
+    return [((int(i), int(j)), int(s[i, j])) for i, j in zip(rows, cols)]
+
+
 class VariantsPcaDriver(object):
     """class VariantsPcaDriver (VariantsPca.scala:81-286) over a local dataset.
 
@@ -319,6 +327,12 @@ class VariantsPcaDriver(object):
     def getSimilarityMatrix(self, callsets):
         self.engine = calculate_similarity_matrix(callsets, len(self.indexes), device=self.conf.gpu)
         return self.engine
+
+    # getSimilarityMatrixStream, VariantsPca.scala:262-279 (not called by the reference's main): the same S through
+    # upper-triangle pair emission + mirror, i.e. only the keys with a non-zero count exist
+    def getSimilarityMatrixStream(self, callsets):
+        self.engine = calculate_similarity_matrix(callsets, len(self.indexes), device=self.conf.gpu)
+        return similarity_entries_nonzero(self.engine.gram())
 
     # computePca, VariantsPca.scala:198-231
     def computePca(self, sim_matrix):

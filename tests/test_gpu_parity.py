@@ -712,6 +712,21 @@ def test_driver_main_end_to_end(P, O, tmp_path, capsys):
     assert len(saved) == 40 and saved[0].split("\t")[0] == sorted(names)[0]
 
 
+def test_driver_similarity_matrix_stream_has_the_nonzero_keys_of_the_full_matrix(P, O):
+    vp = load_pkg("variants_pca")
+    g = load_golden("zerorow9")          # sample 4 never varies: its row and column are absent from the stream form
+    n = int(g["n_samples"])
+    ids = [str(s) for s in g["callset_ids"]]
+    conf = vp.PcaConf([])
+    drv = vp.VariantsPcaDriver(conf, dict((c, i) for i, c in enumerate(ids)), dict(zip(ids, ids)), [])
+    offs = g["row_offsets"]
+    callsets = [list(g["sample_idx"][offs[k]:offs[k + 1]]) for k in range(len(offs) - 1)]
+    entries = dict(drv.getSimilarityMatrixStream(callsets))
+    s = g["similarity"]
+    assert entries == dict(((i, j), int(s[i, j])) for i in range(n) for j in range(n) if s[i, j] != 0)
+    assert all(4 not in k for k in entries) and len(entries) < n * n
+
+
 # ------------------------------------------------------------------------------------------ compiled host
 def _write_vcf(path, sample_names, records, gz=False):
     import gzip

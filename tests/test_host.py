@@ -237,6 +237,29 @@ def test_join_and_merge_follow_the_reference_semantics():
     assert [v["start"] for v in drv.filterDataset(data)] == [1]
 
 
+def test_similarity_matrix_stream_form_keeps_only_nonzero_keys():
+    """getSimilarityMatrixStream (VariantsPca.scala:262-279): pairs c1 <= c2 emitted per variant, reduced, strict upper
+    entries mirrored -- the same counts as getSimilarityMatrix, keys with a zero count absent."""
+    vp = load_pkg("variants_pca")
+    callsets = [[0, 1], [0, 1, 2], [4], [0, 0, 1]]         # sample 3 never appears; the last row repeats a callset
+    n = 5
+    full = np.zeros((n, n), dtype=np.int64)
+    stream = {}
+    for c in callsets:
+        for c1 in c:
+            for c2 in c:
+                full[c1, c2] += 1                           # :187
+                if c1 <= c2:
+                    stream[(c1, c2)] = stream.get((c1, c2), 0) + 1   # :267-268
+    mirrored = dict(stream)
+    for (i, j), v in stream.items():
+        if i < j:
+            mirrored[(j, i)] = v                            # :272-278
+    got = dict(vp.similarity_entries_nonzero(full))
+    assert got == mirrored
+    assert all(3 not in k for k in got) and (0, 0) in got and got[(0, 0)] == 6
+
+
 def test_pack_bits_layout_is_the_one_pcoa_accumulate_bits_documents():
     """include/pcoa.h: sample i of variant v is bit (i & 31) of word bits[v * ld_words + (i >> 5)]."""
     ingest = load_pkg("ingest")
