@@ -245,6 +245,18 @@ def main():
     ids, variants = make_variants(rng, 33, 400, pop_freq=np.stack([np.full(33, 0.8), np.full(33, 0.45)]),
                                   with_edges=False)
     run_case(ns, "dense33", ids, variants, 1)
+    # 7. / 8. tile-edge cases: N crosses the 128- and 256-sample tile edges of the Gram kernels,
+    # the variant count crosses k-block / stage edges (32-, 128-variant) and the split-K path; >= 3 partitions
+    rng = np.random.default_rng(260)
+    pops = np.repeat(np.arange(4), [70, 65, 65, 60])
+    freqs = np.stack([np.where(pops == k, 0.5, 0.06) for k in range(4)] + [np.full(260, 0.15)])
+    ids, variants = make_variants(rng, 260, 600, pop_freq=freqs)
+    run_case(ns, "tile260", ids, variants, 3)
+    rng = np.random.default_rng(130)
+    pops = np.repeat(np.arange(2), [66, 64])
+    freqs = np.stack([np.where(pops == k, 0.4, 0.05) for k in range(2)] + [np.full(130, 0.1), np.full(130, 0.01)])
+    ids, variants = make_variants(rng, 130, 2100, pop_freq=freqs)
+    run_case(ns, "tile130", ids, variants, 4)
 
 
 if __name__ == "__main__":
