@@ -317,6 +317,140 @@ __global__ __launch_bounds__(256) void pack_fp4_kernel(const T* __restrict__ x, 
   if (bad || badw) atomicOr(flag, 8);
 }
 
+// ---- persistent FP4 pre-pass fed by an LDS-DMA ring (fp32 tiles with ld % 4 == 0) -----------------------------------
+// Same output as pack_fp4_kernel<float, 4>, built to run BESIDE the contraction: 256 threads (one wave per SIMD),
+// <= 64 VGPRs and 64 KiB of LDS, i.e. exactly what gram_packed_kernel (2 waves per SIMD x 224 VGPRs, 96 KiB) leaves free
+// on a CU, and a fixed grid of ~one workgroup per CU that lives for the whole launch (a stream of short-lived small
+// workgroups takes the wave slots a finishing contraction workgroup frees before its successor fits: r01ov1).
+// A wave owns units of (k-block, 256 samples) = 32 rows x 1 KiB.  The rows travel HBM -> LDS by global_load_lds_dwordx4
+// (1 KiB per instruction, no VGPR staging) into the wave's private ring of R one-row slots; per row the wave reads its
+// 16 B back (ds_read_b128, conflict-free), converts 4 values and re-issues the slot R rows ahead, so R - 1 KiB stay in
+// flight per wave whatever the registers hold.  Stores share the in-order vmcnt queue with the ring: every wait is
+// vmcnt(R - 1), which is correct wherever the four stores of a finished k-block sit in the queue.
+// Per value: the nibble is bit 29 of the fp32 pattern (set for 1.0f, clear for 0.0f) shifted into place, and
+// fma(f, f, -f) is +0 exactly for f in {0, -0, 1} and non-zero (or NaN) for everything else: 4 VALU ops.
+// The 32 rows of one unit.  `a` holds row 0 on entry and row 0 of the wave's next unit on exit.  bad4[s] collects the
+// 0/1 check of sample column s; dead columns are masked once per unit by the caller, rows beyond the tile (they re-read
+// its last row) are skipped by a wave-uniform branch.
+template <int R, int AUX>
+__device__ __forceinline__ void ring_unit(const char* xb, int64_t ldb, int nv, int kb, uint32_t voff, int kbn, uint32_t voffn,
+                                          uint8_t* myring, int lane, f32x4_t& a, uint32_t (&w)[4][4], uint32_t (&bad4)[4]) {
+  auto issue = [&](int kbq, uint32_t vo, int t, int slot) {
+    int row = kbq * 32 + t;
+    row = row < nv ? row : nv - 1;
+    const char* src = xb + (int64_t)row * ldb + vo;
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(myring + slot * 1024), 16, 0, AUX);
+  };
+#pragma unroll
+  for (int t = 0; t < 32; ++t) {
+    // (1) row t is in `a` once the ds_read has returned; its slot is free then.  The builtin, not inline asm: the
+    // compiler's own wait-count pass sees it and does not add an lgkmcnt(0) of its own in front of the conversion
+    // (which would also wait for the NEXT row's read issued in (4))
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0), vmcnt / expcnt untouched
+    __builtin_amdgcn_sched_barrier(0);
+    // (2) refill the slot with the row R ahead (of this unit, or of the wave's next unit)
+    if (t + R < 32) issue(kb, voff, t + R, t % R);
+    else issue(kbn, voffn, t + R - 32, t % R);
+    // (3) row t+1 has landed when at most R - 1 operations are outstanding
+    wait_vmcnt<R - 1>();
+    __builtin_amdgcn_sched_barrier(0);
+    // (4) its 16 B start on their way from LDS while row t is converted
+    const f32x4_t b = *reinterpret_cast<const f32x4_t*>(myring + ((t + 1) % R) * 1024 + lane * 16);
+    __builtin_amdgcn_sched_barrier(0);
+    // (5) row t
+    if (kb * 32 + t < nv) {
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        const float f = a[s2];
+        bad4[s2] |= __float_as_uint(__builtin_fmaf(f, f, -f));
+        const uint32_t bits = __float_as_uint(f) >> (28 - 4 * (t & 7));
+        w[s2][t >> 3] |= bits & (2u << (4 * (t & 7)));
+      }
+      // pin the conversion here: without a consumer the optimiser sinks all 32 rows' arithmetic behind the loop and
+      // keeps every row live in registers
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) asm volatile("" : "+v"(w[s2][t >> 3]), "+v"(bad4[s2]));
+    }
+    a = b;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int R, int AUX>
+__global__ __launch_bounds__(256, 8) void pack_fp4_ring_kernel(const float* __restrict__ x, int64_t ld, int nv, int n,
+                                                               int npad, int n_units, int8_t* __restrict__ p,
+                                                               int32_t* __restrict__ flag) {
+  static_assert(R == 16 || R == 32, "the slot of row t must be a compile-time constant of the 32-row unrolled body");
+  // dynamic LDS (4 * R KiB, passed at launch): with a static 64 KiB array the compiler sees an LDS-limited occupancy
+  // of 2 and lets the register allocator spread to 145 VGPRs; the launch bound (8 waves per SIMD = 64 VGPRs) only binds
+  // when the LDS size is unknown to it
+  extern __shared__ __attribute__((aligned(16))) uint8_t ring_dyn[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gw = npad >> 8;  // 256-sample groups per k-block
+  const int stride = (int)gridDim.x * 4;
+  const int stride_kb = stride / gw, stride_g = stride - stride_kb * gw;
+  int u = (int)blockIdx.x * 4 + wave;
+  if (u >= n_units) return;  // no workgroup barrier anywhere below
+  int kb = u / gw, G = u - kb * gw;
+  uint8_t* const myring = ring_dyn + wave * (R * 1024);
+  const char* const xb = reinterpret_cast<const char*>(x);
+  const int64_t ldb = ld * 4;
+  uint32_t bad = 0;
+
+  // per-lane byte offset inside a row (columns beyond ld read column 0 and are masked later); the row address is
+  // wave-uniform
+  auto lane_off = [&](int Gq) -> uint32_t {
+    const int col = Gq * 256 + lane * 4;
+    return col < ld ? (uint32_t)col * 4u : 0u;
+  };
+  uint32_t voff = lane_off(G);
+#pragma unroll
+  for (int t = 0; t < R; ++t) {
+    int row = kb * 32 + t;
+    row = row < nv ? row : nv - 1;
+    __builtin_amdgcn_global_load_lds((gptr_t)(xb + (int64_t)row * ldb + voff), (lptr_t)(myring + t * 1024), 16, 0, AUX);
+  }
+  wait_vmcnt<R - 1>();
+  f32x4_t a = *reinterpret_cast<const f32x4_t*>(myring + lane * 16);  // row 0 of the first unit
+  for (;;) {
+    // the wave's next unit; past the end a harmless re-read of this one keeps the queue depth (and vmcnt) uniform
+    int kbn = kb + stride_kb, Gn = G + stride_g;
+    if (Gn >= gw) { Gn -= gw; kbn += 1; }
+    const bool last = u + stride >= n_units;
+    if (last) { kbn = kb; Gn = G; }
+    const uint32_t voffn = lane_off(Gn);
+    const int col = G * 256 + lane * 4;
+    uint32_t w[4][4], bad4[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      bad4[s2] = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[s2][q] = 0;
+    }
+    ring_unit<R, AUX>(xb, ldb, nv, kb, voff, kbn, voffn, myring, lane, a, w, bad4);
+    // samples >= n (padding columns of the tile, or of the operand) may hold anything: dropped here, once per unit
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      const uint32_t cm = (col + s2 < n) ? 0xffffffffu : 0u;
+      bad |= bad4[s2] & cm;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[s2][q] &= cm;
+    }
+    uint4* dst = reinterpret_cast<uint4*>(p + ((size_t)kb * npad + col) * 16);
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) dst[s2] = make_uint4(w[s2][0], w[s2][1], w[s2][2], w[s2][3]);
+    if (last) break;
+    u += stride;
+    kb = kbn;
+    G = Gn;
+    voff = voffn;
+  }
+  wait_vmcnt<0>();  // the ring's tail must have landed before the LDS can belong to another workgroup
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (bad) atomicOr(flag, 8);
+}
+
 // uint8 input, 8-byte loads: one thread packs 32 variants x 8 samples (a wave reads 512 contiguous bytes per row
 // instead of the 256 of the generic kernel above: 2504-byte rows are not line-aligned, so short segments pay for an
 // extra 128-B line each).  Four batches of 8 rows; per batch the 0/1 bytes of row t are OR-ed in at bit t, which
@@ -1011,6 +1145,29 @@ hipError_t launch_pack_fp4(const void* x, int is_u8, int64_t ld, int64_t nv, int
     if (vec) hipLaunchKernelGGL((pack_fp4_kernel<float, 4, true>), grid, block, 0, stream, xs, ld, nv, n, npad, nkb_pad, p, flag);
     else hipLaunchKernelGGL((pack_fp4_kernel<float, 1>), grid, block, 0, stream, xs, ld, nv, n, npad, nkb_pad, p, flag);
   }
+  return hipGetLastError();
+}
+
+// Persistent LDS-ring twin of the fp32 FP4 pre-pass (pack_fp4_ring_kernel): `wgs` workgroups of 4 waves walk the
+// nkb_out x (Npad / 256) units.  Needs ld % 4 == 0 and a 16-byte aligned tile (the caller falls back to launch_pack_fp4).
+bool pack_fp4_ring_ok(const void* x, int64_t ld) {
+  return ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+}
+hipError_t launch_pack_fp4_ring(const float* x, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
+                                hipStream_t stream, int64_t nkb_out, int wgs, int nt) {
+  if (nv <= 0) return hipSuccess;
+  const int npad = (int)gram_packed_npad(n);
+  const int64_t nkb = nkb_out > 0 ? nkb_out : gram_kb_pad(nv, 1);
+  const int64_t n_units = nkb * (npad >> 8);
+  if (n_units > 0x3fffffffLL || nv > 0x3fffffffLL) return hipErrorInvalidValue;  // 32-bit unit / row indices in the kernel
+  int64_t blocks = (n_units + 3) / 4;
+  if (wgs > 0 && blocks > wgs) blocks = wgs;
+  if (nt)
+    hipLaunchKernelGGL((pack_fp4_ring_kernel<16, 2>), dim3((unsigned)blocks), dim3(256), 4 * 16 * 1024, stream, x, ld, (int)nv, n, npad,
+                       (int)n_units, p, flag);
+  else
+    hipLaunchKernelGGL((pack_fp4_ring_kernel<16, 0>), dim3((unsigned)blocks), dim3(256), 4 * 16 * 1024, stream, x, ld, (int)nv, n, npad,
+                       (int)n_units, p, flag);
   return hipGetLastError();
 }
 

@@ -48,6 +48,9 @@ hipError_t launch_expand_bits_fp4(const uint32_t* bits, int64_t ld_words, int64_
                                   hipStream_t stream, int64_t nkb_out = 0);
 hipError_t launch_pack_fp4(const void* x, int is_u8, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
                            hipStream_t stream, int64_t nkb_out = 0);
+bool pack_fp4_ring_ok(const void* x, int64_t ld);
+hipError_t launch_pack_fp4_ring(const float* x, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
+                                hipStream_t stream, int64_t nkb_out, int wgs, int nt);
 hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, int32_t* s32, int num_cu,
                               hipStream_t stream, int* splitk_out);
 hipError_t launch_gram_i8_packed(const int8_t* p, int64_t nv, int32_t n, int32_t* s32, int num_cu,

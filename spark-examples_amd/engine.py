@@ -104,6 +104,13 @@ class PcoaEngine(object):
         offs = np.ascontiguousarray(row_offsets, dtype=np.int64)
         if offs.ndim != 1 or offs.size < 1:
             raise ValueError("row_offsets must have n_variants + 1 entries")
+        # the C side walks sample_idx[row_offsets[0] .. row_offsets[n]) through raw pointers: inconsistent arrays
+        # must fail here, not as an out-of-bounds read
+        if idx.ndim != 1:
+            raise ValueError("sample_idx must be one-dimensional")
+        if offs[0] < 0 or offs[-1] > idx.size or (offs.size > 1 and np.any(np.diff(offs) < 0)):
+            raise ValueError("row_offsets must be non-decreasing, start at >= 0 and end at <= len(sample_idx) = %d"
+                             % idx.size)
         if idx.size == 0:
             idx = np.zeros(1, dtype=np.int32)
         self._check(self._lib.pcoa_accumulate_calls(self._ctx, _ptr(idx), _ptr(offs), offs.size - 1))

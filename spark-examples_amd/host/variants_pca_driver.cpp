@@ -11,7 +11,7 @@
 //   getCallsRdd (:153-168)   carriers per variant; variants without a varying call dropped
 //   emitResult (:233-246)    name \t dataset \t pc1 \t pc2 sorted by name (+ <output-path>-pca.tsv)
 //
-// The data source is local: one VCF (plain or .gz via `gzip -dc`) per variant set -- the Google
+// The data source is local: one VCF (plain or .gz via a spawned `gzip -dc`) per variant set -- the Google
 // Genomics API the reference streamed from (VariantsRDD.scala) has been shut down.  Callset index =
 // position in the concatenated sample lists (VariantsCommon.scala:44-45), callset id =
 // "<file stem>-<i>", so `dataset` = id up to the first '-' (:235) is the file stem.
@@ -33,6 +33,13 @@
 #include <unordered_map>
 #include <vector>
 #include <chrono>
+#include <set>
+
+#include <spawn.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+extern char** environ;
 
 #include "pcoa.h"
 
@@ -45,6 +52,7 @@ struct Conf {  // PcaConf / GenomicsConf (GenomicsConf.scala:31-101), same flag 
   std::vector<std::string> variant_set_id{"3049512673186936334"};
   bool all_references = false, debug_datasets = false, has_maf = false;
   bool parse_only = false;  // not a reference flag: ingest + getCallsRdd only, prints the carrier statistics (no GPU)
+  std::string dump_similarity;  // not a reference flag: writes S (N x N int64, little-endian, row-major) for parity tests
   int ingest_threads = 0;   // not a reference flag: 0 = hardware concurrency (local[*]), cf. --spark-master local[k]
   float min_allele_frequency = 0.f;
   int num_pc = 2, num_reduce_partitions = 10, gpu = 0;
@@ -83,6 +91,7 @@ Conf parse(int argc, char** argv) {
     else if (a == "--spark-master") c.spark_master = one(i);
     else if (a == "--gpu") c.gpu = std::atoi(one(i).c_str());
     else if (a == "--parse-only") c.parse_only = true;
+    else if (a == "--dump-similarity") c.dump_similarity = one(i);
     else if (a == "--ingest-threads") c.ingest_threads = std::atoi(one(i).c_str());
     else die("unknown flag " + a);
   }
@@ -201,21 +210,36 @@ std::vector<Region> parse_references(const std::string& spec) {
 // The file (or the output of `gzip -dc`) is read in 16 MiB blocks cut at line ends; the data lines of a block are
 // parsed by a pool of threads (contiguous line ranges, results concatenated in file order), in place with
 // string_views: no per-field allocation.  One sample column costs a scan up to the next tab.
-struct BlockReader {  // plain file or `gzip -dc` pipe
+struct BlockReader {  // plain file, or the output of `gzip -dc -- <path>` started with posix_spawn (no shell: the
+                      // path is one argv entry, whatever characters it holds)
   FILE* f = nullptr;
-  bool piped = false;
+  pid_t child = -1;
   std::string carry;
   explicit BlockReader(const std::string& path) {
     if (path.size() > 3 && path.substr(path.size() - 3) == ".gz") {
-      std::string cmd = "gzip -dc '" + path + "'";
-      f = popen(cmd.c_str(), "r");
-      piped = true;
+      int fds[2];
+      if (pipe(fds) != 0) die("pipe() failed for " + path);
+      posix_spawn_file_actions_t fa;
+      posix_spawn_file_actions_init(&fa);
+      posix_spawn_file_actions_adddup2(&fa, fds[1], STDOUT_FILENO);
+      posix_spawn_file_actions_addclose(&fa, fds[0]);
+      posix_spawn_file_actions_addclose(&fa, fds[1]);
+      std::string a0 = "gzip", a1 = "-dc", a2 = "--", a3 = path;
+      char* argv[] = {a0.data(), a1.data(), a2.data(), a3.data(), nullptr};
+      const int rc = posix_spawnp(&child, "gzip", &fa, nullptr, argv, environ);
+      posix_spawn_file_actions_destroy(&fa);
+      close(fds[1]);
+      if (rc != 0) { close(fds[0]); die("cannot start gzip for " + path); }
+      f = fdopen(fds[0], "r");
     } else {
       f = std::fopen(path.c_str(), "r");
     }
     if (!f) die("cannot open " + path);
   }
-  ~BlockReader() { if (f) { if (piped) pclose(f); else std::fclose(f); } }
+  ~BlockReader() {
+    if (f) std::fclose(f);
+    if (child > 0) { int st = 0; (void)waitpid(child, &st, 0); }
+  }
   // next block of whole lines (the last one may lack its newline at end of file); false at end of input
   bool next(std::string& block, size_t target = (size_t)16 << 20) {
     block.swap(carry);
@@ -315,12 +339,21 @@ void parse_record(const char* b, const char* e, const std::vector<Region>& regio
   out.keep = true;
 }
 
-Dataset load_vcf(const std::string& path, const std::vector<Region>& regions, int32_t index_base, bool debug,
-                 int n_threads) {
-  Dataset d;
+// Set id of a VCF = its file name up to the first '.', '-' replaced (the id is split at '-' for the dataset column,
+// :235).  Two files with the same stem (a/cohort.chr17.vcf + b/cohort.chr17.vcf, ALL.chr17.phase1 + ALL.chr17.phase3)
+// would collide: the later one gets "<stem>_<ordinal>" -- the same rule as the Python mirror (load_dataset).
+std::string set_id_of(const std::string& path, size_t ordinal, std::set<std::string>& used) {
   std::string stem = path.substr(path.find_last_of('/') == std::string::npos ? 0 : path.find_last_of('/') + 1);
   stem = stem.substr(0, stem.find('.'));
   std::replace(stem.begin(), stem.end(), '-', '_');
+  if (used.count(stem)) stem += "_" + std::to_string(ordinal);
+  used.insert(stem);
+  return stem;
+}
+
+Dataset load_vcf(const std::string& path, const std::string& stem, const std::vector<Region>& regions, int32_t index_base,
+                 bool debug, int n_threads) {
+  Dataset d;
   BlockReader in(path);
   std::string block;
   bool header = false;
@@ -400,12 +433,14 @@ int main(int argc, char** argv) {
   // VariantsCommon (VariantsCommon.scala:33-66): callset index/name maps + one dataset per variant set
   std::vector<Dataset> data;
   std::vector<std::string> ids, names;
+  std::set<std::string> used_stems;
   if (conf.input_path.size() > 1) std::printf("Running PCA on %zu datasets.\n", conf.input_path.size());
   for (size_t k = 0; k < conf.input_path.size(); ++k) {
     std::vector<Region> regions;
     if (!conf.all_references && !conf.references.empty())
       regions = parse_references(conf.references[std::min(k, conf.references.size() - 1)]);
-    data.push_back(load_vcf(conf.input_path[k], regions, (int32_t)ids.size(), conf.debug_datasets, conf.ingest_threads));
+    data.push_back(load_vcf(conf.input_path[k], set_id_of(conf.input_path[k], k, used_stems), regions, (int32_t)ids.size(),
+                            conf.debug_datasets, conf.ingest_threads));
     ids.insert(ids.end(), data.back().ids.begin(), data.back().ids.end());
     names.insert(names.end(), data.back().names.begin(), data.back().names.end());
   }
@@ -477,11 +512,26 @@ int main(int argc, char** argv) {
   // getSimilarityMatrix (:182-191) and computePca (:198-231) on the GPU
   pcoa_ctx* ctx = nullptr;
   if (pcoa_create(&ctx, n, conf.gpu, PCOA_FLAG_DEFAULT) != PCOA_OK) die(std::string("pcoa_create: ") + pcoa_last_error(nullptr));
-  // The RDD[Seq[Int]] rows go over as carrier BITSETS (pcoa_accumulate_bits): a row built from VCF calls never
-  // repeats a callset (join / merge concatenate datasets with disjoint index ranges), so the set form is exact, it is
-  // 316 B per variant at N = 2504 instead of 4 B per carrier, and it runs on the MX-FP4 kernel.  (The Python mirror
-  // sends the same rows through the CSR boundary pcoa_accumulate_calls; a GPU test holds the two to identical output.)
-  {
+  // The RDD[Seq[Int]] rows go over as carrier BITSETS (pcoa_accumulate_bits) when every row is a SET: 316 B per variant
+  // at N = 2504 instead of 4 B per carrier, straight onto the MX-FP4 kernel.  A row can only repeat a callset when
+  // mergeDatasets groups a key that occurs twice inside one VCF (the group size still equals the number of sets when
+  // another set lacks the key); the reference's double loop counts such a repeat with multiplicity (:187), which a
+  // bitset cannot express, so any repeat sends the job through the CSR boundary (pcoa_accumulate_calls), as the Python
+  // mirror always does.
+  bool any_repeat = false;
+  if (data.size() > 2) {
+    std::vector<int64_t> last((size_t)n, -1);
+    for (size_t r = 0; r + 1 < row_offsets.size() && !any_repeat; ++r)
+      for (int64_t q = row_offsets[r]; q < row_offsets[r + 1]; ++q) {
+        const size_t cidx = (size_t)sample_idx[(size_t)q];
+        if (last[cidx] == (int64_t)r) { any_repeat = true; break; }
+        last[cidx] = (int64_t)r;
+      }
+  }
+  if (any_repeat) {
+    check(ctx, pcoa_accumulate_calls(ctx, sample_idx.data(), row_offsets.data(), (int64_t)row_offsets.size() - 1),
+          "getSimilarityMatrix");
+  } else {
     const int64_t n_rows = (int64_t)row_offsets.size() - 1;
     const int64_t words = ((int64_t)n + 31) / 32;
     const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(n_rows, ((int64_t)64 << 20) / words));
@@ -498,6 +548,13 @@ int main(int argc, char** argv) {
     }
   }
   check(ctx, pcoa_gram_finalize(ctx), "getSimilarityMatrix");
+  if (!conf.dump_similarity.empty()) {  // all N^2 entries, as matrix.iterator emits them (:189)
+    std::vector<int64_t> sim((size_t)n * (size_t)n);
+    check(ctx, pcoa_gram_read_i64(ctx, sim.data()), "dump-similarity");
+    std::ofstream out(conf.dump_similarity, std::ios::binary);
+    out.write(reinterpret_cast<const char*>(sim.data()), (std::streamsize)(sim.size() * sizeof(int64_t)));
+    if (!out) die("cannot write " + conf.dump_similarity);
+  }
   if (conf.num_pc < 2)  // the reference reads array(i + pca.numRows) unconditionally (:230)
     die("computePca emits exactly PC1 and PC2 (VariantsPca.scala:229-230); --num-pc must be >= 2");
   std::vector<double> comps((size_t)conf.num_pc * (size_t)n), lam((size_t)conf.num_pc);

@@ -37,6 +37,18 @@ def parse_references(refs):
     return out
 
 
+def set_id_of(path, ordinal=0, used=None):
+    """Set id of a VCF = its file name up to the first '.', '-' replaced ('-' separates the dataset name from the
+    callset number in an id, VariantsPca.scala:235).  A stem already taken by an earlier variant set of the same run
+    (a/cohort.chr17.vcf + b/cohort.chr17.vcf) gets '_<ordinal>' appended -- the rule of the compiled host."""
+    stem = os.path.basename(path).split(".")[0].replace("-", "_")
+    if used is not None:
+        if stem in used:
+            stem = "%s_%d" % (stem, ordinal)
+        used.add(stem)
+    return stem
+
+
 def load_npz(path):
     z = np.load(path, allow_pickle=False)
     ids = [str(s) for s in z["callset_ids"]]
@@ -74,7 +86,7 @@ def load_vcf(path, references=None):
     columns; ~40x the per-cell Python loop it replaced, same carriers as the compiled host, tests/test_host.py)."""
     regions = parse_references(references)
     opener = gzip.open if path.endswith(".gz") else open
-    set_id = os.path.basename(path).split(".")[0].replace("-", "_")
+    set_id = set_id_of(path)
     samples = None
     idx_chunks, offs = [], [0]
     with opener(path, "rb") as f:
@@ -111,13 +123,14 @@ def load_vcf(path, references=None):
     return indexes, dict(zip(ids, samples)), [("csr", idx, np.asarray(offs, dtype=np.int64))]
 
 
-def load_vcf_records(path, references=None):
+def load_vcf_records(path, references=None, set_id=None):
     """VCF -> variant records shaped like the reference's Variant case class (VariantsRDD.scala:46-54):
     contig, start, end, referenceBases, alternateBases, info, calls[{callSetId, genotype}].
     Returns (callset ids in file order, id -> name, [variant dict])."""
     regions = parse_references(references)
     opener = gzip.open if path.endswith(".gz") else open
-    set_id = os.path.basename(path).split(".")[0].replace("-", "_")
+    if set_id is None:
+        set_id = set_id_of(path)
     samples, ids, variants = None, [], []
     with opener(path, "rt") as f:
         for line in f:

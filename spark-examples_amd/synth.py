@@ -82,19 +82,24 @@ def thresholds(seed, first_variant, n_variants, n_pops=5, fst=0.1):
     return out
 
 
-def genotypes(seed, first_variant, thr, offsets, dtype=np.float32):
-    """Host twin of synth_fill_kernel: dense [n_variants][n_samples] 0/1 matrix."""
+def genotypes(seed, first_variant, thr, offsets, dtype=np.float32, cols=None):
+    """Host twin of synth_fill_kernel: dense [n_variants][n_samples] 0/1 matrix.
+    cols = (c0, c1): only sample columns [c0, c1) (the Philox counter is (variant, column // 4), so a column block of a
+    very wide cohort -- N = 100,000 -- can be produced without the rest)."""
     thr = np.asarray(thr, dtype=np.uint32)
     offsets = np.asarray(offsets, dtype=np.int64)
     nv = thr.shape[0]
     n = int(offsets[-1])
-    ngroups = (n + 3) // 4
+    c0, c1 = (0, n) if cols is None else (int(cols[0]), int(cols[1]))
+    if not (0 <= c0 <= c1 <= n):
+        raise ValueError("cols outside [0, n_samples]")
+    g0, g1 = c0 // 4, (c1 + 3) // 4
     v = (np.arange(nv, dtype=np.uint64) + np.uint64(first_variant))[:, None]
-    g = np.arange(ngroups, dtype=np.uint32)[None, :]
+    g = np.arange(g0, g1, dtype=np.uint32)[None, :]
     w = philox4x32_10((v & _MASK).astype(np.uint32), (v >> np.uint64(32)).astype(np.uint32), g, np.uint32(0),
                       int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF)
-    words = np.stack(w, axis=-1).reshape(nv, ngroups * 4)[:, :n]
+    words = np.stack(w, axis=-1).reshape(nv, (g1 - g0) * 4)[:, c0 - 4 * g0:c1 - 4 * g0]
     pop = np.zeros(n, dtype=np.int64)
     for p in range(len(offsets) - 1):
         pop[offsets[p]:offsets[p + 1]] = p
-    return (words < thr[:, pop]).astype(dtype)
+    return (words < thr[:, pop[c0:c1]]).astype(dtype)

@@ -218,6 +218,8 @@ class PcaConf(object):
         # additions of this engine
         p.add_argument("--synthetic", type=str, default=None, help="V,N,seed: synthetic Balding-Nichols input")
         p.add_argument("--gpu", type=int, default=0)
+        p.add_argument("--dump-similarity", type=str, default=None,
+                       help="write S (N x N int64, little-endian, row-major) to this file (parity tests)")
         a = p.parse_args(list(arguments))
         self.__dict__.update(vars(a))
         self.numPc = a.num_pc
@@ -292,8 +294,13 @@ class VariantsPcaDriver(object):
     # filterDataset, VariantsPca.scala:96-108
     def filterDataset(self, data):
         maf = self.conf.minAlleleFrequency
-        if maf is None or isinstance(data, tuple):
+        if maf is None:
             return data
+        if isinstance(data, tuple):
+            # carrier-only inputs (.npz CSR, --synthetic) carry no INFO/AF: the filter cannot be applied, and ignoring
+            # it silently would change the result
+            raise ValueError("--min-allele-frequency needs variant records with INFO/AF (a VCF input), "
+                             "not pre-extracted carriers (.npz / --synthetic)")
         print("Min allele frequency %s." % java_float_to_string(maf))
         out = []
         for variant in data:
@@ -389,12 +396,22 @@ def load_dataset(conf):
             return ingest.load_npz(paths[0])
         return ingest.load_vcf(paths[0], refs)
     # several variant sets (or the AF filter): full variant records are needed for keys and INFO/AF
+    if any(p.endswith(".npz") for p in paths):
+        raise SystemExit("joining variant sets or filtering by allele frequency needs VCF inputs: a .npz dataset holds "
+                         "carriers only (no contig/start/end/ref/alt keys, no INFO/AF)")
     print("Running PCA on %d datasets." % len(paths))  # VariantsCommon.scala:57
     indexes, names, data = {}, {}, []
+    used = set()
     for k, path in enumerate(paths):
-        ids, nm, variants = ingest.load_vcf_records(path, parse_refs(refs, k))
-        for cid in ids:
-            indexes[cid] = len(indexes)
+        set_id = ingest.set_id_of(path, k, used)
+        ids, nm, variants = ingest.load_vcf_records(path, parse_refs(refs, k), set_id=set_id)
+        # callset index = position in the concatenated callset lists (VariantsCommon.scala:44-45), as the compiled
+        # host assigns them; the ids are unique by construction (set_id_of), so nothing is overwritten
+        base = len(indexes)
+        for i, cid in enumerate(ids):
+            if cid in indexes:
+                raise ValueError("duplicate callset id %r" % cid)
+            indexes[cid] = base + i
         names.update(nm)
         data.append(variants)
     return indexes, names, data
@@ -415,6 +432,8 @@ def main(args):
     filtered = [driver.filterDataset(d) for d in driver.data]
     calls_rdd = driver.getCallsRdd(filtered)
     sim_matrix = driver.getSimilarityMatrix(calls_rdd)
+    if conf.dump_similarity:
+        sim_matrix.gram().astype("<i8").tofile(conf.dump_similarity)
     result = driver.computePca(sim_matrix)
     driver.emitResult(result)
     driver.reportIoStats(sys.stderr)

@@ -65,3 +65,25 @@ def planted_callsets(rng, n, v, k=3, hi=0.5, lo=0.05):
         p = np.where(pops == which, hi, lo) if which < k else np.full(n, rng.uniform(0.02, 0.4))
         x[row] = rng.random(n) < p
     return x
+
+
+def write_golden_vcf(g, path, gz=False):
+    """The variant records a golden fixture was generated from (`variants_json`: the dicts the reference's
+    prepare_call_data consumed) as a VCF: one column per callset in callset-list order, a missing call as './.', a
+    haploid / triploid genotype as is.  Lets the hosts' ingest be held to the reference's own outputs."""
+    import gzip
+    import json
+    ids = [str(s) for s in g["callset_ids"]]
+    col = dict((cid, i) for i, cid in enumerate(ids))
+    variants = json.loads(str(g["variants_json"]))
+    opener = gzip.open if gz else open
+    with opener(path, "wt") as f:
+        f.write("##fileformat=VCFv4.2\n")
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" +
+                "\t".join("S%04d" % i for i in range(len(ids))) + "\n")
+        for k, var in enumerate(variants):
+            cells = ["./."] * len(ids)
+            for call in var.get("calls", []):
+                cells[col[call["callSetId"]]] = ("|" if k % 2 else "/").join(str(a) for a in call["genotype"])
+            f.write("chr17\t%d\t.\tA\tC\t.\tPASS\t.\tGT\t%s\n" % (41196312 + 7 * k, "\t".join(cells)))
+    return len(ids)

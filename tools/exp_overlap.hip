@@ -1,0 +1,248 @@
+// exp_overlap.hip -- A/B harness for the fp32 boundary of the Gram path.
+//
+// Measures, on one MI355X and on the kernels of spark-examples_amd/csrc/gram_packed.hip themselves (the file is
+// included, so the anonymous-namespace kernels are visible):
+//   1. pack_fp4_kernel (shipped pre-pass) vs pack_fp4_ring_kernel (persistent, LDS-DMA ring, <= 64 VGPRs, 64 KiB LDS):
+//      bit-identical operand? time per 10^6 variants at several grid sizes, nt / default cache policy;
+//   2. the contraction alone;
+//   3. a step = pre-pass + contraction, serial on one stream (what ships) vs pipelined on two streams with ping-pong
+//      operand buffers: pre-pass of chunk k+1 beside the contraction of chunk k, for both pre-pass kernels, with and
+//      without stream priorities, and on disjoint CU masks.
+// Not part of the product; build: make -C tools exp_overlap (hipcc, gfx950).  Prints one line per measurement.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../spark-examples_amd/csrc/gram_packed.hip"
+
+using namespace pcoa;
+
+#define CK(expr)                                                                                  \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      std::fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+      std::exit(1);                                                                               \
+    }                                                                                             \
+  } while (0)
+
+__global__ void fill_kernel(float* x, int64_t count, uint32_t seed, uint32_t thr) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t h = (uint32_t)i * 2654435761u ^ (uint32_t)(i >> 32) * 40503u ^ seed;
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    x[i] = (h < thr) ? 1.0f : 0.0f;
+  }
+}
+
+__global__ void diff_kernel(const uint32_t* a, const uint32_t* b, int64_t words, unsigned long long* out) {
+  unsigned long long d = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (int64_t)gridDim.x * blockDim.x)
+    d += (a[i] != b[i]);
+  if (d) atomicAdd(out, d);
+}
+
+static double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct Ctx {
+  int n = 2504, npad = 0, num_cu = 256;
+  int64_t v = 1000000, ld = 2504, nkb = 0;
+  float* x = nullptr;
+  int8_t* p[2] = {nullptr, nullptr};
+  int32_t *s32 = nullptr, *flag = nullptr;
+  unsigned long long* cnt = nullptr;
+};
+
+enum PackKind { PACK_OLD = 0, PACK_RING = 1 };
+struct PackCfg {
+  PackKind kind;
+  int wgs;  // ring: grid size
+  int nt;
+  std::string name() const {
+    if (kind == PACK_OLD) return "old";
+    return "ring(wgs=" + std::to_string(wgs) + (nt ? ",nt)" : ",dflt)");
+  }
+};
+
+static void pack(const Ctx& c, const PackCfg& k, int buf, hipStream_t s, int64_t nv = -1) {
+  if (nv < 0) nv = c.v;
+  if (k.kind == PACK_OLD) CK(launch_pack_fp4(c.x, 0, c.ld, nv, c.n, c.p[buf], c.flag, s, c.nkb));
+  else CK(launch_pack_fp4_ring(c.x, c.ld, nv, c.n, c.p[buf], c.flag, s, c.nkb, k.wgs, k.nt));
+}
+static void contract(const Ctx& c, int buf, hipStream_t s, int num_cu = 0) {
+  CK(launch_gram_packed(c.p[buf], 1, c.nkb * 32, c.n, c.s32, num_cu ? num_cu : c.num_cu, s, nullptr));
+}
+
+static float time_events(hipStream_t s, int reps, const std::function<void()>& body) {
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b));
+  body();  // warm-up
+  CK(hipStreamSynchronize(s));
+  CK(hipEventRecord(a, s));
+  for (int i = 0; i < reps; ++i) body();
+  CK(hipEventRecord(b, s));
+  CK(hipStreamSynchronize(s));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, a, b));
+  CK(hipEventDestroy(a));
+  CK(hipEventDestroy(b));
+  return ms / reps;
+}
+
+// pipelined job: K chunks, pre-pass on sp, contraction on sg, ping-pong operand buffers
+static double pipelined(const Ctx& c, const PackCfg& k, hipStream_t sp, hipStream_t sg, int K, int gram_cus = 0) {
+  hipEvent_t ev_p[2], ev_g[2];
+  for (int b = 0; b < 2; ++b) {
+    CK(hipEventCreateWithFlags(&ev_p[b], hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&ev_g[b], hipEventDisableTiming));
+  }
+  auto run = [&](int chunks) {
+    for (int i = 0; i < chunks; ++i) {
+      const int b = i & 1;
+      if (i >= 2) CK(hipStreamWaitEvent(sp, ev_g[b], 0));  // the contraction that read this buffer has finished
+      pack(c, k, b, sp);
+      CK(hipEventRecord(ev_p[b], sp));
+      CK(hipStreamWaitEvent(sg, ev_p[b], 0));
+      contract(c, b, sg, gram_cus);
+      CK(hipEventRecord(ev_g[b], sg));
+    }
+    CK(hipStreamSynchronize(sp));
+    CK(hipStreamSynchronize(sg));
+  };
+  run(3);
+  const double t0 = now_ms();
+  run(K);
+  const double dt = now_ms() - t0;
+  for (int b = 0; b < 2; ++b) {
+    CK(hipEventDestroy(ev_p[b]));
+    CK(hipEventDestroy(ev_g[b]));
+  }
+  return dt / K;
+}
+
+int main(int argc, char** argv) {
+  Ctx c;
+  if (argc > 1) c.v = std::atoll(argv[1]);
+  const int K = argc > 2 ? std::atoi(argv[2]) : 12;
+  CK(hipSetDevice(0));
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  c.num_cu = prop.multiProcessorCount;
+  c.npad = (int)gram_packed_npad(c.n);
+  c.nkb = gram_kb_pad(c.v, 1);
+  std::printf("device %s, %d CUs; N = %d, V = %lld per chunk, %lld k-blocks\n", prop.gcnArchName, c.num_cu, c.n,
+              (long long)c.v, (long long)c.nkb);
+  const size_t pbytes = (size_t)(c.nkb + 24) * c.npad * 16;
+  CK(hipMalloc((void**)&c.x, sizeof(float) * (size_t)c.v * c.ld + 4096));
+  for (int b = 0; b < 2; ++b) CK(hipMalloc((void**)&c.p[b], pbytes));
+  CK(hipMalloc((void**)&c.s32, sizeof(int32_t) * (size_t)c.n * c.n));
+  CK(hipMalloc((void**)&c.flag, 64));
+  CK(hipMalloc((void**)&c.cnt, 64));
+  CK(hipMemset(c.s32, 0, sizeof(int32_t) * (size_t)c.n * c.n));
+  CK(hipMemset(c.flag, 0, 64));
+  hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, c.x, (int64_t)c.v * c.ld, 12345u, 0x1C000000u);  // ~11 % carriers
+  CK(hipDeviceSynchronize());
+
+  hipStream_t s0;
+  CK(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking));
+
+  // ---- 1. bit-identity of the two pre-passes (full tile, and a ragged variant count: rows beyond nv in the last k-block)
+  for (int64_t nv : {c.v, c.v - 13}) {
+    CK(hipMemsetAsync(c.p[0], 0xAB, pbytes, s0));
+    CK(hipMemsetAsync(c.p[1], 0xCD, pbytes, s0));
+    pack(c, PackCfg{PACK_OLD, 0, 0}, 0, s0, nv);
+    pack(c, PackCfg{PACK_RING, c.num_cu, 1}, 1, s0, nv);
+    CK(hipMemsetAsync(c.cnt, 0, 8, s0));
+    hipLaunchKernelGGL(diff_kernel, dim3(2048), dim3(256), 0, s0, (const uint32_t*)c.p[0], (const uint32_t*)c.p[1],
+                       (int64_t)c.nkb * c.npad * 4, c.cnt);
+    unsigned long long d = 0;
+    int32_t fl = 0;
+    CK(hipMemcpyAsync(&d, c.cnt, 8, hipMemcpyDeviceToHost, s0));
+    CK(hipMemcpyAsync(&fl, c.flag, 4, hipMemcpyDeviceToHost, s0));
+    CK(hipStreamSynchronize(s0));
+    std::printf("identity nv=%lld: %llu differing words of %lld, flag=%d  %s\n", (long long)nv, d,
+                (long long)c.nkb * c.npad * 4, fl, (d == 0 && fl == 0) ? "OK" : "MISMATCH");
+  }
+  {  // a non-binary value must raise flag bit 3 in both kernels
+    const float two = 2.0f;
+    CK(hipMemcpy(c.x + (size_t)77777 * c.ld + 1234, &two, 4, hipMemcpyHostToDevice));
+    for (int kind = 0; kind < 2; ++kind) {
+      CK(hipMemsetAsync(c.flag, 0, 64, s0));
+      pack(c, kind ? PackCfg{PACK_RING, c.num_cu, 1} : PackCfg{PACK_OLD, 0, 0}, 0, s0);
+      int32_t fl = 0;
+      CK(hipMemcpyAsync(&fl, c.flag, 4, hipMemcpyDeviceToHost, s0));
+      CK(hipStreamSynchronize(s0));
+      std::printf("non-binary value, %s: flag=%d %s\n", kind ? "ring" : "old", fl, fl == 8 ? "OK" : "MISSED");
+    }
+    const float one = 1.0f;
+    CK(hipMemcpy(c.x + (size_t)77777 * c.ld + 1234, &one, 4, hipMemcpyHostToDevice));
+    CK(hipMemset(c.flag, 0, 64));
+  }
+
+  // ---- 2. kernels alone
+  const double gb = (4.0 * c.v * c.n + (double)c.nkb * c.npad * 16) / 1e9;
+  std::vector<PackCfg> packs = {{PACK_OLD, 0, 0}};
+  for (int nt : {1, 0})
+    for (int mult : {1, 2, 3, 4}) packs.push_back({PACK_RING, c.num_cu * mult, nt});
+  for (const auto& k : packs) {
+    const float ms = time_events(s0, 6, [&] { pack(c, k, 0, s0); });
+    std::printf("alone  pack %-22s %.3f ms  %.0f GB/s (read+write, algorithmic)\n", k.name().c_str(), ms, gb / ms * 1e3);
+  }
+  pack(c, packs[0], 0, s0);
+  pack(c, packs[0], 1, s0);
+  const float gram_ms = time_events(s0, 6, [&] { contract(c, 0, s0); });
+  std::printf("alone  contraction             %.3f ms per launch of %lld variants\n", gram_ms, (long long)c.v);
+
+  // ---- 3. the step: serial vs pipelined
+  for (const auto& k : {packs[0], packs[1], packs[2]}) {
+    const float ms = time_events(s0, K, [&] { pack(c, k, 0, s0); contract(c, 0, s0); });
+    std::printf("serial step, pack %-22s %.3f ms/step\n", k.name().c_str(), ms);
+  }
+  int least = 0, greatest = 0;
+  CK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  hipStream_t sp, sg, sp_lo, sg_hi;
+  CK(hipStreamCreateWithFlags(&sp, hipStreamNonBlocking));
+  CK(hipStreamCreateWithFlags(&sg, hipStreamNonBlocking));
+  CK(hipStreamCreateWithPriority(&sp_lo, hipStreamNonBlocking, least));
+  CK(hipStreamCreateWithPriority(&sg_hi, hipStreamNonBlocking, greatest));
+  for (const auto& k : packs) {
+    std::printf("pipelined, pack %-22s %.3f ms/step (equal priority)", k.name().c_str(), pipelined(c, k, sp, sg, K));
+    std::printf("   %.3f ms/step (contraction stream high, pre-pass low)\n", pipelined(c, k, sp_lo, sg_hi, K));
+    std::fflush(stdout);
+  }
+  // the same job with the contraction FIRST in every pair does not exist (it depends on the pre-pass); what can differ
+  // is which kernel reaches an empty chip first: repeat the best candidates with 2-chunk look-ahead disabled
+  // ---- disjoint CU masks: the pre-pass on m CUs per 32, the contraction on the rest
+  if (c.num_cu == 256) {
+    for (int m : {8, 12, 16}) {
+      uint32_t mp[8], mg[8];
+      for (int j = 0; j < 8; ++j) {
+        mp[j] = (m >= 32) ? 0xffffffffu : ((1u << m) - 1u);
+        mg[j] = ~mp[j];
+      }
+      hipStream_t smp, smg;
+      if (hipExtStreamCreateWithCUMask(&smp, 8, mp) != hipSuccess || hipExtStreamCreateWithCUMask(&smg, 8, mg) != hipSuccess) {
+        std::printf("CU-mask streams unavailable\n");
+        (void)hipGetLastError();
+        break;
+      }
+      for (const auto& k : {packs[0], PackCfg{PACK_RING, 8 * m, 1}, PackCfg{PACK_RING, 16 * m, 1}, PackCfg{PACK_RING, 32 * m, 1}}) {
+        const float alone = time_events(smp, 3, [&] { pack(c, k, 0, smp); });
+        const double step = pipelined(c, k, smp, smg, K, 256 - 8 * m);
+        std::printf("CU masks %3d + %3d CUs, pack %-22s alone %.3f ms (%.0f GB/s, %.1f GB/s per CU)   pipelined %.3f ms/step\n",
+                    8 * m, 256 - 8 * m, k.name().c_str(), alone, gb / alone * 1e3, gb / alone * 1e3 / (8 * m), step);
+        std::fflush(stdout);
+      }
+      CK(hipStreamDestroy(smp));
+      CK(hipStreamDestroy(smg));
+    }
+  }
+  std::printf("done\n");
+  return 0;
+}
