@@ -1,0 +1,93 @@
+/*
+ * VariantsPcaNative.scala -- the two stages of VariantsPcaDriver that run on the GPUs.
+ *
+ * Replaces the BODIES of
+ *   VariantsPcaDriver.getSimilarityMatrix   (VariantsPca.scala:182-191: per-partition DenseMatrix[Int] + reduceByKey)
+ *   VariantsPcaDriver.computePca            (VariantsPca.scala:198-231: row sums, centring, MLlib RowMatrix PCA)
+ * and leaves everything else of the driver (flags, getData, filterDataset, getCallsRdd, emitResult, main) as it is.
+ * The driver's members `sc` and `common` are private, so the stages live here as functions of what they need and the
+ * two methods of the class become forwards (the complete patch is in INTEGRATION.md, section 1):
+ *
+ *   def getSimilarityMatrix(callsets: RDD[Seq[Int]]) =
+ *     VariantsPcaNative.getSimilarityMatrix(sc, callsets, common.indexes.size, conf.numGpus())
+ *   def computePca(handles: Array[Long]) =
+ *     VariantsPcaNative.computePca(handles, common.indexes, conf.numPc())
+ *
+ * Deployment: one JVM per node, `--spark-master local[k]` with k >= numGpus -- a pcoa handle is a pointer of this
+ * process, and the RCCL communicator needs all numGpus tasks alive at the same time (ncclCommInitRank is collective).
+ */
+package com.google.cloud.genomics.spark.examples
+
+import org.apache.spark.SparkContext
+import org.apache.spark.rdd.RDD
+
+object VariantsPcaNative {
+
+  /** Records per pcoa_accumulate_calls batch (the engine buffers them; one matrix-core launch per <= 2^22 variants). */
+  val BatchRecords = 65536
+
+  /**
+   * getSimilarityMatrix.  The RDD[Seq[Int]] of getCallsRdd (VariantsPca.scala:153-168) is coalesced to one partition
+   * per GPU; each task streams its records to its GPU as CSR batches, then the partial N x N matrices are summed over
+   * xGMI (== reduceByKey(_ + _), :190).  Returns one engine handle per GPU; every one of them holds the full S in HBM.
+   */
+  def getSimilarityMatrix(sc: SparkContext, callsets: RDD[Seq[Int]], size: Int, nGpus: Int): Array[Long] = {
+    val uid = sc.broadcast(NativePcoa.commUniqueId()) // rank 0's RCCL id, shipped by Spark
+    require(uid.value != null, "pcoa_comm_unique_id failed")
+    callsets.coalesce(nGpus).mapPartitionsWithIndex { (rank, callsInPartition) =>
+      val ctx = NativePcoa.create(size, rank, NativePcoa.FlagDefault)
+      callsInPartition.grouped(BatchRecords).foreach { batch =>
+        val nnz = batch.iterator.map(_.size.toLong).sum
+        val offs = NativePcoa.direct(8L * (batch.size + 1))
+        val idx = NativePcoa.direct(4L * math.max(nnz, 1L))
+        var o = 0L
+        offs.putLong(0L)
+        batch.foreach { calls =>
+          calls.foreach(c => idx.putInt(c))
+          o += calls.size
+          offs.putLong(o)
+        }
+        // an index outside [0, size) is the NoSuchElementException of mapping(call.callsetId) (:59)
+        NativePcoa.check(ctx, NativePcoa.accumulateCalls(ctx, idx, offs, batch.size))
+      }
+      NativePcoa.check(ctx, NativePcoa.gramFinalize(ctx))
+      if (nGpus > 1) {
+        val comm = NativePcoa.commInit(ctx, uid.value, rank, nGpus)
+        if (comm == 0L) throw new IllegalStateException(NativePcoa.lastError(ctx))
+        NativePcoa.check(ctx, NativePcoa.gramAllreduce(ctx, comm))
+        NativePcoa.commDestroy(comm)
+      }
+      Iterator((rank, ctx))
+    }.collect().sortBy(_._1).map(_._2)
+  }
+
+  /**
+   * computePca on rank 0's engine: row sums, double centring and the numPc principal components on the GPU.
+   * Prints the reference's "Non zero rows" line (:208) and returns its (callsetId, PC1, PC2) tuples (:228-230);
+   * like the reference it reads components 0 and 1 unconditionally.
+   */
+  def computePca(handles: Array[Long], indexes: Map[String, Int], numPc: Int): Seq[(String, Double, Double)] = {
+    val n = indexes.size
+    val ctx = handles(0)
+    val comps = NativePcoa.direct(8L * n * numPc)
+    val lam = NativePcoa.direct(8L * numPc)
+    val nz = new Array[Int](1)
+    NativePcoa.check(ctx, NativePcoa.compute(ctx, numPc, comps, lam, nz)) // numPc outside (0, n]: IllegalArgumentException
+    println(s"Non zero rows in matrix: ${nz(0)} / $n.")
+    val array = comps.asDoubleBuffer() // N x numPc column-major == pca.toArray (:227)
+    val reverse = indexes.map(_.swap)
+    for (i <- 0 until n) yield (reverse(i), array.get(i), array.get(i + n))
+  }
+
+  /** reportIoStats' line for the native stages, and release of the engines (VariantsPcaDriver.stop, :283-285). */
+  def reportAndStop(handles: Array[Long]): Unit = {
+    if (handles.nonEmpty) {
+      val t = NativePcoa.direct(24)
+      if (NativePcoa.timings(handles(0), t) == NativePcoa.Ok) {
+        val d = t.asDoubleBuffer()
+        println(f"Variants accumulated: ${d.get(0).toLong}%d; Gram kernels ${1e3 * d.get(1)}%.3f ms; PCoA ${1e3 * d.get(2)}%.3f ms")
+      }
+    }
+    handles.foreach(NativePcoa.destroy)
+  }
+}

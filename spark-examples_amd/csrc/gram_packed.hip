@@ -380,7 +380,7 @@ template <int R, int AUX>
 __global__ __launch_bounds__(256, 8) void pack_fp4_ring_kernel(const float* __restrict__ x, int64_t ld, int nv, int n,
                                                                int npad, int n_units, int8_t* __restrict__ p,
                                                                int32_t* __restrict__ flag) {
-  static_assert(R == 16 || R == 32, "the slot of row t must be a compile-time constant of the 32-row unrolled body");
+  static_assert(R == 8 || R == 16 || R == 32, "the slot of row t must be a compile-time constant of the 32-row unrolled body");
   // dynamic LDS (4 * R KiB, passed at launch): with a static 64 KiB array the compiler sees an LDS-limited occupancy
   // of 2 and lets the register allocator spread to 145 VGPRs; the launch bound (8 waves per SIMD = 64 VGPRs) only binds
   // when the LDS size is unknown to it
@@ -1012,7 +1012,17 @@ __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram
 
   int tile, ks;
   const int b = blockIdx.x;
-  if (xcd_map) {
+  if (xcd_map == 2) {
+    // lock-step layout: the chip holds ALL tiles of `splitk` k-streams at once, one workgroup per CU for the whole
+    // launch.  A k-stream's tiles live on a group of 8 / splitk XCDs, so every operand row is fetched into those L2s
+    // once and shared by workgroups that move through k together (no second round that re-reads the slice).
+    const int g = kNumXcd / splitk;               // XCDs per k-stream
+    const int per = (ntri + g - 1) / g;           // tiles per XCD
+    const int xcd = b & 7, slot = b >> 3;
+    tile = (xcd % g) * per + slot;
+    ks = xcd / g;
+    if (slot >= per || tile >= ntri) return;
+  } else if (xcd_map) {
     const int q = b >> 3;
     ks = (b & 7) + kNumXcd * (q / ntri);
     tile = q % ntri;
@@ -1162,12 +1172,14 @@ hipError_t launch_pack_fp4_ring(const float* x, int64_t ld, int64_t nv, int32_t 
   if (n_units > 0x3fffffffLL || nv > 0x3fffffffLL) return hipErrorInvalidValue;  // 32-bit unit / row indices in the kernel
   int64_t blocks = (n_units + 3) / 4;
   if (wgs > 0 && blocks > wgs) blocks = wgs;
-  if (nt)
-    hipLaunchKernelGGL((pack_fp4_ring_kernel<16, 2>), dim3((unsigned)blocks), dim3(256), 4 * 16 * 1024, stream, x, ld, (int)nv, n, npad,
-                       (int)n_units, p, flag);
-  else
-    hipLaunchKernelGGL((pack_fp4_ring_kernel<16, 0>), dim3((unsigned)blocks), dim3(256), 4 * 16 * 1024, stream, x, ld, (int)nv, n, npad,
-                       (int)n_units, p, flag);
+  // nt: 0 default cache policy, 1 nontemporal; bit 1 of `nt` selects the 8-slot ring (32 KiB of LDS instead of 64)
+  const bool small = (nt & 2) != 0;
+#define PCOA_RING(R_, AUX_)                                                                                              \
+  hipLaunchKernelGGL((pack_fp4_ring_kernel<R_, AUX_>), dim3((unsigned)blocks), dim3(256), 4 * R_ * 1024, stream, x, ld, \
+                     (int)nv, n, npad, (int)n_units, p, flag)
+  if (small) { if (nt & 1) PCOA_RING(8, 2); else PCOA_RING(8, 0); }
+  else { if (nt & 1) PCOA_RING(16, 2); else PCOA_RING(16, 0); }
+#undef PCOA_RING
   return hipGetLastError();
 }
 
@@ -1248,6 +1260,39 @@ hipError_t launch_densify_csr_fp4(const int32_t* idx_dev, const int64_t* offs_de
 hipError_t launch_gram_i8_packed(const int8_t* p, int64_t nv, int32_t n, int32_t* s32, int num_cu,
                                  hipStream_t stream, int* splitk_out) {
   return launch_gram_packed(p, 0, nv, n, s32, num_cu, stream, splitk_out);
+}
+
+// Lock-step launch of the FP4 / int8 contraction (gram_packed_kernel with xcd_map = 2): ntri * splitk <= #CUs
+// persistent workgroups, splitk in {1, 2, 4, 8} k-streams, each on 8 / splitk XCDs.  Returns hipErrorInvalidValue when
+// the shape does not fit the chip (the caller then uses launch_gram_packed).
+hipError_t launch_gram_packed_lockstep(const int8_t* p, int fmt, int64_t nv, int32_t n, int32_t* s32, int num_cu,
+                                       hipStream_t stream) {
+  if (nv <= 0) return hipSuccess;
+  const int npad = (int)gram_packed_npad(n);
+  const int ntile = npad / TJ;
+  const int64_t ntri64 = (int64_t)ntile * (ntile + 1) / 2;
+  const int cus = num_cu > 0 ? num_cu : 256;
+  int splitk = 0;
+  for (int k : {8, 4, 2, 1}) {
+    const int g = kNumXcd / k;
+    const int64_t per = (ntri64 + g - 1) / g;
+    if (per * kNumXcd <= cus) { splitk = k; break; }   // one workgroup per CU, 32 CUs per XCD
+  }
+  if (splitk == 0) return hipErrorInvalidValue;
+  const int ntri = (int)ntri64;
+  const int skb = 4;
+  const int64_t nstages = gram_kb_pad(nv, fmt) / skb;
+  const int64_t stages_per = (nstages + splitk - 1) / splitk;
+  const int g = kNumXcd / splitk;
+  const int per = (ntri + g - 1) / g;
+  const dim3 grid((unsigned)(per * kNumXcd)), block(512);
+  if (fmt == 1)
+    hipLaunchKernelGGL((gram_packed_kernel<1, 2, 2, 4, 3, true, 2>), grid, block, 0, stream, p, npad, nstages, n, ntile, ntri,
+                       splitk, stages_per, s32, 2);
+  else
+    hipLaunchKernelGGL((gram_packed_kernel<0, 2, 2, 4, 3, true, 2>), grid, block, 0, stream, p, npad, nstages, n, ntile, ntri,
+                       splitk, stages_per, s32, 2);
+  return hipGetLastError();
 }
 
 hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, int32_t* s32, int num_cu,

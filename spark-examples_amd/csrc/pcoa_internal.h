@@ -53,6 +53,8 @@ hipError_t launch_pack_fp4_ring(const float* x, int64_t ld, int64_t nv, int32_t 
                                 hipStream_t stream, int64_t nkb_out, int wgs, int nt);
 hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, int32_t* s32, int num_cu,
                               hipStream_t stream, int* splitk_out);
+hipError_t launch_gram_packed_lockstep(const int8_t* p, int fmt, int64_t nv, int32_t n, int32_t* s32, int num_cu,
+                                       hipStream_t stream);
 hipError_t launch_gram_i8_packed(const int8_t* p, int64_t nv, int32_t n, int32_t* s32, int num_cu,
                                  hipStream_t stream, int* splitk_out);
 

@@ -1,0 +1,123 @@
+// jni_replay.cpp -- plays the Scala host (scala/.../VariantsPcaNative.scala) against the REAL JNI shim
+// (jni/pcoa_jni.cpp, compiled with tests/jni_stub/jni.h) and libpcoa_hip.so, without a JVM.
+//
+// Same call sequence as VariantsPcaNative.getSimilarityMatrix / computePca for one GPU task:
+//   create -> [per batch of <= `batch` records: direct CSR buffers -> accumulateCalls] -> gramFinalize ->
+//   commUniqueId -> commInit(rank 0 of 1) -> gramAllreduce -> commDestroy -> gramRead (parity only) -> compute ->
+//   timings -> destroy
+// Input : <prefix>.idx (int32 LE), <prefix>.offs (int64 LE, n_variants + 1 entries)
+// Output: <prefix>.s (int64 N x N), <prefix>.pc (double N x numPc column-major), <prefix>.lam, stdout "nonzero <k>"
+// Usage : jni_replay <prefix> <n_samples> <num_pc> [batch = 65536]
+// Also checks the error mapping the Scala side relies on: an index >= N gives PCOA_ERR_INDEX_RANGE and a message,
+// a heap (non-direct) buffer gives PCOA_ERR_INVALID_ARG, num_pc = 0 gives PCOA_ERR_INVALID_ARG.
+#include <jni.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "pcoa.h"
+
+#define FN(name) Java_com_google_cloud_genomics_spark_examples_NativePcoa_00024_##name
+extern "C" {
+jlong FN(create)(JNIEnv*, jobject, jint, jint, jint);
+void FN(destroy)(JNIEnv*, jobject, jlong);
+jstring FN(lastError)(JNIEnv*, jobject, jlong);
+jint FN(reset)(JNIEnv*, jobject, jlong);
+jint FN(accumulateCalls)(JNIEnv*, jobject, jlong, jobject, jobject, jlong);
+jint FN(accumulateBits)(JNIEnv*, jobject, jlong, jobject, jlong, jlong);
+jint FN(gramFinalize)(JNIEnv*, jobject, jlong);
+jbyteArray FN(commUniqueId)(JNIEnv*, jobject);
+jlong FN(commInit)(JNIEnv*, jobject, jlong, jbyteArray, jint, jint);
+jint FN(commDestroy)(JNIEnv*, jobject, jlong);
+jint FN(gramAllreduce)(JNIEnv*, jobject, jlong, jlong);
+jint FN(gramRead)(JNIEnv*, jobject, jlong, jobject);
+jint FN(compute)(JNIEnv*, jobject, jlong, jint, jobject, jobject, jintArray);
+jint FN(timings)(JNIEnv*, jobject, jlong, jobject);
+}
+
+template <typename T>
+static std::vector<T> slurp(const std::string& path) {
+  std::ifstream f(path, std::ios::binary | std::ios::ate);
+  if (!f) { std::fprintf(stderr, "cannot read %s\n", path.c_str()); std::exit(2); }
+  const std::streamsize bytes = f.tellg();
+  f.seekg(0);
+  std::vector<T> v((size_t)bytes / sizeof(T));
+  f.read(reinterpret_cast<char*>(v.data()), bytes);
+  return v;
+}
+template <typename T>
+static void dump(const std::string& path, const std::vector<T>& v) {
+  std::ofstream f(path, std::ios::binary);
+  f.write(reinterpret_cast<const char*>(v.data()), (std::streamsize)(v.size() * sizeof(T)));
+}
+#define EXPECT(cond)                                                                  \
+  do {                                                                                \
+    if (!(cond)) { std::fprintf(stderr, "%s:%d EXPECT(%s) failed\n", __FILE__, __LINE__, #cond); return 1; } \
+  } while (0)
+
+int main(int argc, char** argv) {
+  if (argc < 4) { std::fprintf(stderr, "usage: jni_replay <prefix> <n_samples> <num_pc> [batch]\n"); return 2; }
+  const std::string prefix = argv[1];
+  const jint n = std::atoi(argv[2]), num_pc = std::atoi(argv[3]);
+  const int64_t batch = argc > 4 ? std::atoll(argv[4]) : 65536;
+  std::vector<int32_t> idx = slurp<int32_t>(prefix + ".idx");
+  std::vector<int64_t> offs = slurp<int64_t>(prefix + ".offs");
+  const int64_t nv = (int64_t)offs.size() - 1;
+  JNIEnv env;
+  jobject self = nullptr;  // the NativePcoa$ module instance: unused by the natives
+
+  const jlong ctx = FN(create)(&env, self, n, 0, 0);
+  if (ctx == 0) {
+    std::fprintf(stderr, "create threw %s: %s\n", env.pending_exception_class.c_str(), env.pending_exception_message.c_str());
+    return 3;
+  }
+  // ---- error mapping first (S stays empty: a rejected call leaves it unchanged)
+  {
+    int32_t bad_idx[2] = {0, n};
+    int64_t bad_offs[2] = {0, 2};
+    const jint rc = FN(accumulateCalls)(&env, self, ctx, env.wrapDirect(bad_idx, sizeof(bad_idx)), env.wrapDirect(bad_offs, sizeof(bad_offs)), 1);
+    EXPECT(rc == PCOA_ERR_INDEX_RANGE);
+    EXPECT(!FN(lastError)(&env, self, ctx)->text.empty());
+    EXPECT(FN(accumulateCalls)(&env, self, ctx, env.heapBuffer(), env.heapBuffer(), 1) == PCOA_ERR_INVALID_ARG);
+    std::vector<double> c1((size_t)n);
+    EXPECT(FN(compute)(&env, self, ctx, 0, env.wrapDirect(c1.data(), 8 * n), nullptr, nullptr) == PCOA_ERR_INVALID_ARG);
+    EXPECT(FN(reset)(&env, self, ctx) == PCOA_OK);
+  }
+  // ---- getSimilarityMatrix: CSR batches exactly as VariantsPcaNative builds them (offsets restart at 0 per batch)
+  for (int64_t v0 = 0; v0 < nv; v0 += batch) {
+    const int64_t rows = std::min(batch, nv - v0);
+    std::vector<int64_t> bo((size_t)rows + 1);
+    for (int64_t r = 0; r <= rows; ++r) bo[(size_t)r] = offs[(size_t)(v0 + r)] - offs[(size_t)v0];
+    const int64_t nnz = bo[(size_t)rows];
+    std::vector<int32_t> bi(idx.begin() + offs[(size_t)v0], idx.begin() + offs[(size_t)v0] + nnz);
+    if (bi.empty()) bi.push_back(0);
+    EXPECT(FN(accumulateCalls)(&env, self, ctx, env.wrapDirect(bi.data(), 4 * (jlong)bi.size()),
+                               env.wrapDirect(bo.data(), 8 * (jlong)bo.size()), rows) == PCOA_OK);
+  }
+  EXPECT(FN(gramFinalize)(&env, self, ctx) == PCOA_OK);
+  jbyteArray uid = FN(commUniqueId)(&env, self);
+  EXPECT(uid != nullptr && env.GetArrayLength(uid) == 128);
+  const jlong comm = FN(commInit)(&env, self, ctx, uid, 0, 1);
+  EXPECT(comm != 0);
+  EXPECT(FN(gramAllreduce)(&env, self, ctx, comm) == PCOA_OK);
+  EXPECT(FN(commDestroy)(&env, self, comm) == PCOA_OK);
+  std::vector<int64_t> s((size_t)n * (size_t)n);
+  EXPECT(FN(gramRead)(&env, self, ctx, env.wrapDirect(s.data(), 8 * (jlong)s.size())) == PCOA_OK);
+  dump(prefix + ".s", s);
+  // ---- computePca
+  std::vector<double> comps((size_t)n * (size_t)num_pc), lam((size_t)num_pc);
+  jintArray nz = env.newIntArray(1);
+  EXPECT(FN(compute)(&env, self, ctx, num_pc, env.wrapDirect(comps.data(), 8 * (jlong)comps.size()),
+                     env.wrapDirect(lam.data(), 8 * (jlong)lam.size()), nz) == PCOA_OK);
+  dump(prefix + ".pc", comps);
+  dump(prefix + ".lam", lam);
+  double t3[3] = {0, 0, 0};
+  EXPECT(FN(timings)(&env, self, ctx, env.wrapDirect(t3, sizeof(t3))) == PCOA_OK);
+  EXPECT((int64_t)t3[0] > 0 || nv == 0);
+  std::printf("nonzero %d\n", nz->ints[0]);
+  FN(destroy)(&env, self, ctx);
+  return 0;
+}

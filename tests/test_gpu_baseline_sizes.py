@@ -1,0 +1,267 @@
+"""GPU parity at the sizes BASELINE.json quotes (VERDICT r01 "next round" items 1 and 2).
+
+  * configs[1] at FULL size: all N^2 entries of S from the default path against the CPU oracle on the same 10^6
+    variants, and the eigenpairs against oracle.compute_pca(S) at the north_star tolerance;
+  * configs[3] (N = 100,000): blocks of S against the CPU oracle run on just those sample columns;
+  * every reference-generated golden as a VCF through BOTH hosts: S == the reference's own similarity matrix;
+  * two real ranks (two processes, two engines) sharing the one GPU: HIP partials over dist.shard_range, reduced through
+    export -> gloo all-reduce -> import, bit-identical to the single-shard engine;
+  * the int64 branch of pcoa_gram_allreduce_rccl and its rank-agreement logic, forced at world size 1.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, align_sign, golden_cases, load_golden, load_oracle, load_pkg, write_golden_vcf
+
+pytestmark = pytest.mark.gpu
+
+EIG_TOL = 1e-6  # north_star: 1e-6 relative on sign-normalised eigenpairs
+
+
+@pytest.fixture(scope="module")
+def P():
+    return load_pkg()
+
+
+@pytest.fixture(scope="module")
+def O():
+    return load_oracle()
+
+
+def test_config1_full_size_every_entry_and_eigenpairs_against_the_oracle(P, O):
+    """BASELINE configs[1]: 2,504 samples x 1,000,000 variants fp32, resident in HBM, default (auto) path.
+    The oracle takes the same 10 GB tile (downloaded from the device; the generator itself is held to its host twin in
+    test_synthetic_device_generator_is_bit_identical_to_host_twin) through sgemm in exact-integer chunks."""
+    import torch
+    synth = load_pkg("synth")
+    n, v, seed = 2504, 1000000, 1002
+    offs = synth.pop_offsets(n)
+    x = torch.empty((v, n), dtype=torch.float32, device="cuda")
+    with P.PcoaEngine(n) as eng:
+        step = 1 << 18
+        for v0 in range(0, v, step):
+            v1 = min(v, v0 + step)
+            eng.synth_fill(seed, offs, synth.thresholds(seed, v0, v1 - v0), v0, x[v0:v1].data_ptr(), n)
+        eng.sync()
+        # spot-check the tile itself against the host twin of the generator (first and last rows)
+        for v0 in (0, v - 64):
+            want_rows = synth.genotypes(seed, v0, synth.thresholds(seed, v0, 64), offs)
+            assert np.array_equal(x[v0:v0 + 64].cpu().numpy(), want_rows)
+        eng.accumulate_dense(x)
+        s = eng.gram()
+        tim = eng.timings()
+        assert tim["gram_kernel_kind"] == 3 and tim["fp4_fallbacks"] == 0   # the measured path: MX-FP4
+        comps, lam, nz = eng.compute(2)
+        assert eng.timings()["eig_method"] == 1                                # ... and its default eigensolver
+    xh = x.cpu().numpy()
+    del x
+    want = O.similarity_from_dense_blas(xh)
+    del xh
+    assert np.array_equal(s, want)                                             # all 6,270,016 entries
+    ref = O.compute_pca(want, 2)
+    assert nz == ref["nonzero_rows"]
+    assert np.max(np.abs(lam - ref["eigenvalues"]) / np.abs(ref["eigenvalues"])) < EIG_TOL
+    got = align_sign(comps, ref["components"])
+    for c in range(2):
+        assert np.linalg.norm(got[:, c] - ref["components"][:, c]) < EIG_TOL
+
+
+def test_config3_biobank_sample_count_blocks_against_the_cpu_oracle(P, O):
+    """BASELINE configs[3] sample count (N = 100,000; S = 40 GB int32 in one HBM) x 65,536 variants generated on the
+    device.  A block S[r0:r0+b, c0:c0+b] depends only on those 2b sample columns of X: the host twin of the generator
+    produces exactly those columns and the oracle's faithful pair loop gives the block.  Top-left, far off-diagonal
+    (both triangles) and bottom-right, placed across tile and band edges of the contraction."""
+    synth = load_pkg("synth")
+    n, v, seed, chunk, b = 100000, 65536, 1004, 16384, 320
+    offs = synth.pop_offsets(n)
+    with P.PcoaEngine(n) as eng:
+        for v0 in range(0, v, chunk):
+            eng.accumulate_synthetic(seed, offs, synth.thresholds(seed, v0, chunk), v0)
+        eng.finalize()
+        thr = synth.thresholds(seed, 0, v)
+
+        def cols(c0):
+            return synth.genotypes(seed, 0, thr, offs, dtype=np.uint8, cols=(c0, c0 + b))
+
+        for (r0, c0) in ((0, 0), (130, 99000), (99000, 130), (4090, 4100), (n - b, n - b), (50000, 73211)):
+            xr, xc = cols(r0), cols(c0)
+            full = O.similarity_from_dense(np.concatenate([xr, xc], axis=1).astype(np.float32), 2 * b)
+            want = full[:b, b:]            # S[r0 + i, c0 + j] = sum_v xr[v, i] * xc[v, j]
+            got = eng.gram_block(r0, c0, b, b)
+            assert np.array_equal(got, want), (r0, c0)
+            assert int(got.sum()) > 0
+        comps, lam, nz = eng.compute(2)     # eigenpairs only come back after the on-device true-residual test
+        assert nz == n and lam[0] > lam[1] > 0
+        assert abs(np.linalg.norm(comps[:, 0]) - 1.0) < 1e-9 and abs(comps[:, 0] @ comps[:, 1]) < 1e-9
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_vcf_through_both_hosts_gives_the_reference_similarity_matrix(P, name, tmp_path):
+    """SURVEY 8(f) rank 1 against the reference: the records each golden was generated from, as a VCF, through the
+    compiled host (bitset boundary) and the Python mirror (CSR boundary): S must equal the matrix the reference's own
+    Python code produced (tests/golden/make_golden.py), entry for entry."""
+    g = load_golden(name)
+    n = int(g["n_samples"])
+    path = str(tmp_path / "golden.vcf")
+    write_golden_vcf(g, path)
+    exe = os.path.join(ROOT, "spark-examples_amd", "variants_pca_driver")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "spark-examples_amd", "host")])
+    dump_c = str(tmp_path / "s_cpp.bin")
+    res = subprocess.run([exe, "--input-path", path, "--dump-similarity", dump_c], stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, universal_newlines=True)
+    assert res.returncode == 0, res.stderr
+    s_cpp = np.fromfile(dump_c, dtype="<i8").reshape(n, n)
+    assert np.array_equal(s_cpp, g["similarity"])
+    vp = load_pkg("variants_pca")
+    dump_p = str(tmp_path / "s_py.bin")
+    assert vp.main(["--input-path", path, "--dump-similarity", dump_p]) == 0
+    assert np.array_equal(np.fromfile(dump_p, dtype="<i8").reshape(n, n), g["similarity"])
+
+
+def test_accumulate_calls_rejects_inconsistent_csr_arrays_before_the_c_call(P):
+    with P.PcoaEngine(8) as eng:
+        with pytest.raises(ValueError):
+            eng.accumulate_calls(np.array([0, 1, 2], dtype=np.int32), np.array([0, 2, 5], dtype=np.int64))   # end > len
+        with pytest.raises(ValueError):
+            eng.accumulate_calls(np.array([0, 1, 2], dtype=np.int32), np.array([0, 3, 2], dtype=np.int64))   # decreasing
+        with pytest.raises(ValueError):
+            eng.accumulate_calls(np.array([0, 1, 2], dtype=np.int32), np.array([-1, 2, 3], dtype=np.int64))  # negative
+        eng.accumulate_calls(np.array([0, 1, 2], dtype=np.int32), np.array([0, 2, 3], dtype=np.int64))
+        assert int(eng.gram().sum()) == 5
+
+
+# ------------------------------------------------------------------------------------------ two ranks, one GPU
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_worker(rank, world, port, seed, v, n, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as td
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    P = load_pkg()
+    dist = load_pkg("dist")
+    synth = load_pkg("synth")
+    offs = synth.pop_offsets(n)
+    v0, v1 = dist.shard_range(rank, world, v)
+    with P.PcoaEngine(n, device=0) as eng:                     # both ranks share cuda:0, each with its own pcoa_ctx
+        chunk = 50000
+        for a in range(v0, v1, chunk):                          # the HIP partial of this rank's variant range
+            cnt = min(chunk, v1 - a)
+            eng.accumulate_synthetic(seed, offs, synth.thresholds(seed, a, cnt), a)
+        buf = torch.empty((n, n), dtype=torch.int64, device="cuda:0")
+        eng.export_device(buf.data_ptr())
+        eng.sync()
+        host = buf.cpu()
+        td.all_reduce(host)                                     # the wire is gloo here, RCCL on a multi-GPU node
+        buf.copy_(host)
+        torch.cuda.synchronize()
+        eng.import_device(buf.data_ptr())
+        s = eng.gram()
+        np.save(os.path.join(out_dir, "s_rank%d.npy" % rank), s)
+        if rank == 0:                                           # eigendecomposition on rank 0 (north_star)
+            comps, lam, nz = eng.compute(2)
+            np.savez(os.path.join(out_dir, "pca_rank0.npz"), comps=comps, lam=lam, nz=nz)
+    td.barrier()
+    td.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_hip_partials_reduce_to_the_single_shard_result(P, O, tmp_path):
+    """VariantsPca.scala:190 (reduceByKey over partitions) with two REAL ranks: each process owns an engine on cuda:0,
+    accumulates its dist.shard_range of the cohort with the HIP kernels, and the partials are summed through
+    export -> all-reduce -> import.  S must be bit-identical on both ranks to a single engine fed the whole cohort, and
+    rank 0's eigenpairs within 1e-6 of the oracle's on that S."""
+    import torch.multiprocessing as mp
+    synth = load_pkg("synth")
+    seed, v, n, world = 1003, 300001, 2504, 2
+    port = _free_port()
+    mp.spawn(_rank_worker, args=(world, port, seed, v, n, str(tmp_path)), nprocs=world, join=True)
+    offs = synth.pop_offsets(n)
+    with P.PcoaEngine(n) as eng:
+        for a in range(0, v, 100000):
+            cnt = min(100000, v - a)
+            eng.accumulate_synthetic(seed, offs, synth.thresholds(seed, a, cnt), a)
+        full = eng.gram()
+    for r in range(world):
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), "s_rank%d.npy" % r)), full)
+    z = np.load(os.path.join(str(tmp_path), "pca_rank0.npz"))
+    ref = O.compute_pca(full, 2)
+    assert int(z["nz"]) == ref["nonzero_rows"]
+    assert np.max(np.abs(z["lam"] - ref["eigenvalues"]) / np.abs(ref["eigenvalues"])) < EIG_TOL
+    got = align_sign(z["comps"], ref["components"])
+    for c in range(2):
+        assert np.linalg.norm(got[:, c] - ref["components"][:, c]) < EIG_TOL
+
+
+def test_native_rccl_allreduce_int64_branch_and_rank_agreement_at_world_size_1(P, O, monkeypatch):
+    """pcoa_gram_allreduce_rccl: the ranks agree on {variants held in int32 partials, anyone folded} with a 2-word
+    all-reduce and then reduce EITHER the int32 partial in place OR the int64 total.  PCOA_DEBUG_FOLD_THRESHOLD forces a
+    fold after a handful of variants, so the int64 branch (export -> ncclAllReduce(int64) -> import) runs."""
+    rng = np.random.default_rng(12)
+    x = (rng.random((400, 70)) < 0.3).astype(np.float32)
+    want = O.similarity_from_dense(x, 70)
+    monkeypatch.setenv("PCOA_DEBUG_FOLD_THRESHOLD", "96")
+    with P.PcoaEngine(70, gram_kernel="i8") as eng:            # the int8 path contracts per call: folds really happen
+        for a in range(0, 400, 50):
+            eng.accumulate_dense(x[a:a + 50])
+        comm = eng.comm_init(eng.comm_unique_id(), 0, 1)
+        eng.allreduce_rccl(comm)                                # s64 exists -> int64 branch
+        assert np.array_equal(eng.gram(), want)
+        eng.accumulate_dense(x[:50])                            # and S keeps accumulating after it
+        eng.allreduce_rccl(comm)
+        assert np.array_equal(eng.gram(), want + O.similarity_from_dense(x[:50], 70))
+        eng.comm_destroy(comm)
+    monkeypatch.delenv("PCOA_DEBUG_FOLD_THRESHOLD")
+    with P.PcoaEngine(70) as eng:                               # control: the in-place int32 fast path
+        eng.accumulate_dense(x)
+        comm = eng.comm_init(eng.comm_unique_id(), 0, 1)
+        eng.allreduce_rccl(comm)
+        assert np.array_equal(eng.gram(), want)
+        eng.comm_destroy(comm)
+
+
+# ------------------------------------------------------------------------------------------ the JNI shim, without a JVM
+@pytest.mark.parametrize("name,batch", [("pops40", 65536), ("tile260", 100), ("tile130", 777)])
+def test_jni_shim_replay_matches_the_reference_goldens(O, name, batch, tmp_path):
+    """jni/pcoa_jni.cpp (the shim of the Scala host) compiled against tests/jni_stub/jni.h and driven
+    by tests/jni_replay.cpp with the call sequence of scala/.../VariantsPcaNative.scala: direct-buffer CSR batches ->
+    gramFinalize -> commInit / gramAllreduce (1 rank) -> compute.  S must equal the reference's own similarity matrix,
+    the components the oracle's within 1e-6."""
+    exe = str(tmp_path / "jni_replay")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "tests", "jni_stub"), "-I",
+                           os.path.join(ROOT, "include"), os.path.join(ROOT, "jni", "pcoa_jni.cpp"),
+                           os.path.join(ROOT, "tests", "jni_replay.cpp"), "-L", os.path.join(ROOT, "spark-examples_amd"),
+                           "-lpcoa_hip", "-Wl,-rpath," + os.path.join(ROOT, "spark-examples_amd"), "-Wl,-rpath,/opt/rocm/lib",
+                           "-o", exe])
+    g = load_golden(name)
+    n = int(g["n_samples"])
+    prefix = str(tmp_path / "case")
+    g["sample_idx"].astype("<i4").tofile(prefix + ".idx")
+    g["row_offsets"].astype("<i8").tofile(prefix + ".offs")
+    res = subprocess.run([exe, prefix, str(n), "2", str(batch)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         universal_newlines=True)
+    assert res.returncode == 0, res.stderr
+    s = np.fromfile(prefix + ".s", dtype="<i8").reshape(n, n)
+    assert np.array_equal(s, g["similarity"])
+    ref = O.compute_pca(g["similarity"], 2)
+    assert res.stdout.split() == ["nonzero", str(ref["nonzero_rows"])]
+    comps = np.fromfile(prefix + ".pc", dtype="<f8").reshape(2, n).T      # column-major N x 2 == pca.toArray
+    lam = np.fromfile(prefix + ".lam", dtype="<f8")
+    assert np.max(np.abs(lam - ref["eigenvalues"]) / np.abs(ref["eigenvalues"])) < EIG_TOL
+    got = align_sign(comps, ref["components"])
+    for c in range(2):
+        assert np.linalg.norm(got[:, c] - ref["components"][:, c]) < EIG_TOL

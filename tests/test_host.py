@@ -437,6 +437,34 @@ def test_gzip_path_with_shell_metacharacters_is_just_a_path(tmp_path):
     assert got == [[0, 1]] and not os.path.exists(str(tmp_path / "INJECTED"))
 
 
+def test_jni_shim_compiles_against_the_stub_and_covers_every_scala_native(tmp_path):
+    """SURVEY 8(f) rank 4 as source (no JDK in the image): jni/pcoa_jni.cpp must compile (here against
+    tests/jni_stub/jni.h), export one Java_..._NativePcoa_00024_<name> per @native of scala/.../NativePcoa.scala, and
+    forward only to functions include/pcoa.h declares.  The replay program that RUNS the shim is a GPU test."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    scala = open(os.path.join(ROOT, "scala", "com", "google", "cloud", "genomics", "spark", "examples", "NativePcoa.scala")).read()
+    natives = set(re.findall(r"@native\s+def\s+(\w+)", scala))
+    assert len(natives) >= 14
+    obj = str(tmp_path / "pcoa_jni.o")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-c", "-I", os.path.join(ROOT, "tests", "jni_stub"),
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "jni", "pcoa_jni.cpp"), "-o", obj])
+    syms = subprocess.check_output(["nm", "--defined-only", obj], universal_newlines=True)
+    exported = set(re.findall(r" T Java_com_google_cloud_genomics_spark_examples_NativePcoa_00024_(\w+)", syms))
+    assert exported == natives
+    undefined = subprocess.check_output(["nm", "--undefined-only", obj], universal_newlines=True)
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "pcoa.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(pcoa_[a-z0-9_]+)\s*\(", header))
+    used = set(re.findall(r" U (pcoa_[a-z0-9_]+)", undefined))
+    assert used and used <= declared
+    # the Scala host calls only natives that exist
+    host = open(os.path.join(ROOT, "scala", "com", "google", "cloud", "genomics", "spark", "examples", "VariantsPcaNative.scala")).read()
+    called = set(re.findall(r"NativePcoa\.(\w+)\(", host)) - {"direct", "check"}
+    assert called and called <= natives
+
+
 def test_hot_kernels_do_not_spill_to_scratch():
     """A register spill in a Gram kernel costs an order of magnitude (seen once: 1,632 B/lane of scratch made
     the i8 contraction 45x slower while every parity test stayed green).  hipcc reports it at compile time."""

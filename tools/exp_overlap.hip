@@ -65,7 +65,7 @@ struct PackCfg {
   int nt;
   std::string name() const {
     if (kind == PACK_OLD) return "old";
-    return "ring(wgs=" + std::to_string(wgs) + (nt ? ",nt)" : ",dflt)");
+    return "ring" + std::string((nt & 2) ? "8" : "16") + "(wgs=" + std::to_string(wgs) + ((nt & 1) ? ",nt)" : ",dflt)");
   }
 };
 
@@ -74,8 +74,16 @@ static void pack(const Ctx& c, const PackCfg& k, int buf, hipStream_t s, int64_t
   if (k.kind == PACK_OLD) CK(launch_pack_fp4(c.x, 0, c.ld, nv, c.n, c.p[buf], c.flag, s, c.nkb));
   else CK(launch_pack_fp4_ring(c.x, c.ld, nv, c.n, c.p[buf], c.flag, s, c.nkb, k.wgs, k.nt));
 }
+static int g_lockstep = 0;  // 1: lock-step contraction launch (all tiles of 4 k-streams resident, one workgroup per CU)
 static void contract(const Ctx& c, int buf, hipStream_t s, int num_cu = 0) {
-  CK(launch_gram_packed(c.p[buf], 1, c.nkb * 32, c.n, c.s32, num_cu ? num_cu : c.num_cu, s, nullptr));
+  if (g_lockstep) {
+    if (launch_gram_packed_lockstep(c.p[buf], 1, c.nkb * 32, c.n, c.s32, c.num_cu, s) != hipSuccess) {
+      (void)hipGetLastError();
+      CK(launch_gram_packed(c.p[buf], 1, c.nkb * 32, c.n, c.s32, c.num_cu, s, nullptr));  // shape does not fit: shipped launch
+    }
+  } else {
+    CK(launch_gram_packed(c.p[buf], 1, c.nkb * 32, c.n, c.s32, num_cu ? num_cu : c.num_cu, s, nullptr));
+  }
 }
 
 static float time_events(hipStream_t s, int reps, const std::function<void()>& body) {
@@ -124,6 +132,49 @@ static double pipelined(const Ctx& c, const PackCfg& k, hipStream_t sp, hipStrea
     CK(hipEventDestroy(ev_g[b]));
   }
   return dt / K;
+}
+
+// the same pipelined job with an event pair around every kernel: prints when each kernel ran (ms since the first one)
+static double timeline(const Ctx& c, const PackCfg& k, hipStream_t sp, hipStream_t sg, int K, bool verbose = true) {
+  std::vector<hipEvent_t> pa(K), pb(K), ga(K), gb(K);
+  for (int i = 0; i < K; ++i) {
+    CK(hipEventCreate(&pa[i])); CK(hipEventCreate(&pb[i])); CK(hipEventCreate(&ga[i])); CK(hipEventCreate(&gb[i]));
+  }
+  for (int i = 0; i < K; ++i) {
+    const int b = i & 1;
+    if (i >= 2) CK(hipStreamWaitEvent(sp, gb[i - 2], 0));
+    CK(hipEventRecord(pa[i], sp));
+    pack(c, k, b, sp);
+    CK(hipEventRecord(pb[i], sp));
+    CK(hipStreamWaitEvent(sg, pb[i], 0));
+    CK(hipEventRecord(ga[i], sg));
+    contract(c, b, sg);
+    CK(hipEventRecord(gb[i], sg));
+  }
+  CK(hipStreamSynchronize(sp));
+  CK(hipStreamSynchronize(sg));
+  float span = 0, psum = 0, gsum = 0;
+  CK(hipEventElapsedTime(&span, pa[1], pa[K - 1]));
+  for (int i = 1; i < K - 1; ++i) {
+    float t;
+    CK(hipEventElapsedTime(&t, pa[i], pb[i])); psum += t;
+    CK(hipEventElapsedTime(&t, ga[i], gb[i])); gsum += t;
+  }
+  const double step = span / (K - 2);
+  std::printf("pipelined %-24s + %-9s contraction: steady state %.3f ms/step (pre-pass kernel %.3f ms, contraction %.3f ms from queue entry)\n",
+              k.name().c_str(), g_lockstep ? "lock-step" : "shipped", step, psum / (K - 2), gsum / (K - 2));
+  if (verbose) {
+    for (int i = 0; i < K; ++i) {
+      float a0, a1, b0, b1;
+      CK(hipEventElapsedTime(&a0, pa[0], pa[i])); CK(hipEventElapsedTime(&a1, pa[0], pb[i]));
+      CK(hipEventElapsedTime(&b0, pa[0], ga[i])); CK(hipEventElapsedTime(&b1, pa[0], gb[i]));
+      std::printf("  %2d  pack %7.3f..%7.3f (%.3f) | gram %7.3f..%7.3f (%.3f)\n", i, a0, a1, a1 - a0, b0, b1, b1 - b0);
+    }
+  }
+  for (int i = 0; i < K; ++i) {
+    CK(hipEventDestroy(pa[i])); CK(hipEventDestroy(pb[i])); CK(hipEventDestroy(ga[i])); CK(hipEventDestroy(gb[i]));
+  }
+  return step;
 }
 
 int main(int argc, char** argv) {
@@ -196,14 +247,6 @@ int main(int argc, char** argv) {
   }
   pack(c, packs[0], 0, s0);
   pack(c, packs[0], 1, s0);
-  const float gram_ms = time_events(s0, 6, [&] { contract(c, 0, s0); });
-  std::printf("alone  contraction             %.3f ms per launch of %lld variants\n", gram_ms, (long long)c.v);
-
-  // ---- 3. the step: serial vs pipelined
-  for (const auto& k : {packs[0], packs[1], packs[2]}) {
-    const float ms = time_events(s0, K, [&] { pack(c, k, 0, s0); contract(c, 0, s0); });
-    std::printf("serial step, pack %-22s %.3f ms/step\n", k.name().c_str(), ms);
-  }
   int least = 0, greatest = 0;
   CK(hipDeviceGetStreamPriorityRange(&least, &greatest));
   hipStream_t sp, sg, sp_lo, sg_hi;
@@ -211,15 +254,76 @@ int main(int argc, char** argv) {
   CK(hipStreamCreateWithFlags(&sg, hipStreamNonBlocking));
   CK(hipStreamCreateWithPriority(&sp_lo, hipStreamNonBlocking, least));
   CK(hipStreamCreateWithPriority(&sg_hi, hipStreamNonBlocking, greatest));
-  for (const auto& k : packs) {
-    std::printf("pipelined, pack %-22s %.3f ms/step (equal priority)", k.name().c_str(), pipelined(c, k, sp, sg, K));
-    std::printf("   %.3f ms/step (contraction stream high, pre-pass low)\n", pipelined(c, k, sp_lo, sg_hi, K));
-    std::fflush(stdout);
+  // the lock-step launch must give the same S as the shipped one
+  {
+    const size_t nn = (size_t)c.n * c.n;
+    std::vector<int32_t> a(nn), b(nn);
+    CK(hipMemsetAsync(c.s32, 0, nn * 4, s0));
+    g_lockstep = 0; contract(c, 0, s0);
+    CK(hipMemcpyAsync(a.data(), c.s32, nn * 4, hipMemcpyDeviceToHost, s0));
+    CK(hipMemsetAsync(c.s32, 0, nn * 4, s0));
+    g_lockstep = 1; contract(c, 0, s0);
+    CK(hipMemcpyAsync(b.data(), c.s32, nn * 4, hipMemcpyDeviceToHost, s0));
+    CK(hipStreamSynchronize(s0));
+    size_t diff = 0; long long sum = 0;
+    for (size_t i = 0; i < nn; ++i) { diff += a[i] != b[i]; sum += a[i]; }
+    std::printf("lock-step contraction vs shipped: %zu differing entries of %zu (sum %lld)  %s\n", diff, nn, sum,
+                diff == 0 && sum > 0 ? "OK" : "MISMATCH");
+  }
+  std::printf("LDS per CU reported: sharedMemPerMultiprocessor %zu, maxSharedMemoryPerMultiProcessor %zu, sharedMemPerBlock %zu\n",
+              (size_t)prop.sharedMemPerMultiprocessor, (size_t)prop.maxSharedMemoryPerMultiProcessor, (size_t)prop.sharedMemPerBlock);
+  for (int ls : {0, 1}) {
+    g_lockstep = ls;
+    const char* gname = ls ? "lock-step(220 WGs, split-K 4)" : "shipped(1760 WGs, split-K 32)";
+    const float gram_ms = time_events(s0, 6, [&] { contract(c, 0, s0); });
+    std::printf("alone  contraction %-32s %.3f ms per launch of %lld variants\n", gname, gram_ms, (long long)c.v);
+    const float ms = time_events(s0, K, [&] { pack(c, packs[0], 0, s0); contract(c, 0, s0); });
+    std::printf("serial step    [%s], pack old  %.3f ms/step\n", gname, ms);
+  }
+  // ---- disjoint CU sets.  Mask bit g = (XCD g % 8, CU g / 8 of that XCD) -- decoded from r02a (12 bits per word gave
+  // 16 CUs on XCDs 0-3 and 8 on XCDs 4-7).  Pre-pass on CUs [0, pc) of every XCD, contraction on CUs [pc, 32).
+  // (pc, gc): pre-pass on CUs [0, pc) of every XCD, contraction on CUs [32 - gc, 32); pc + gc > 32 = overlapping sets
+  const int splits[][2] = {{16, 16}, {17, 15}, {18, 16}, {20, 16}, {24, 16}, {32, 16}};
+  for (const auto& sp2 : splits) {
+    const int pc = sp2[0], gc = sp2[1];
+    uint32_t mp[8] = {0}, mg[8] = {0};
+    for (int g = 0; g < 256; ++g) {
+      if (g / 8 < pc) mp[g / 32] |= 1u << (g % 32);
+      if (g / 8 >= 32 - gc) mg[g / 32] |= 1u << (g % 32);
+    }
+    hipStream_t smp, smg;
+    if (hipExtStreamCreateWithCUMask(&smp, 8, mp) != hipSuccess || hipExtStreamCreateWithCUMask(&smg, 8, mg) != hipSuccess) {
+      std::printf("CU-mask streams unavailable\n");
+      (void)hipGetLastError();
+      break;
+    }
+    const int gcus = 8 * gc;
+    const int saved = c.num_cu;
+    for (int ls : {1}) {
+      g_lockstep = ls;
+      c.num_cu = gcus;  // the contraction sizes its grid for the CUs it owns
+      const float galone = time_events(smg, 4, [&] { contract(c, 0, smg); });
+      std::printf("[%2d + %2d CUs per XCD] contraction %-9s alone on %3d CUs: %.3f ms\n", pc, gc, ls ? "lock-step" : "shipped",
+                  gcus, galone);
+      std::vector<PackCfg> cand = {{PACK_OLD, 0, 0}, {PACK_RING, 16 * pc, 0}};
+      for (const auto& k : cand) {
+        c.num_cu = saved;
+        const float alone = time_events(smp, 3, [&] { pack(c, k, 0, smp); });
+        c.num_cu = gcus;
+        std::printf("   pre-pass alone on %3d CUs %.3f ms (%.1f GB/s per CU) | ", 8 * pc, alone, gb / alone * 1e3 / (8 * pc));
+        timeline(c, k, smp, smg, K, false);
+        std::fflush(stdout);
+      }
+    }
+    c.num_cu = saved;
+    g_lockstep = 0;
+    CK(hipStreamDestroy(smp));
+    CK(hipStreamDestroy(smg));
   }
   // the same job with the contraction FIRST in every pair does not exist (it depends on the pre-pass); what can differ
   // is which kernel reaches an empty chip first: repeat the best candidates with 2-chunk look-ahead disabled
   // ---- disjoint CU masks: the pre-pass on m CUs per 32, the contraction on the rest
-  if (c.num_cu == 256) {
+  if (c.num_cu == 256 && argc > 3) {  // third argument present: also the CU-mask runs (r02a: no gain at any split)
     for (int m : {8, 12, 16}) {
       uint32_t mp[8], mg[8];
       for (int j = 0; j < 8; ++j) {
