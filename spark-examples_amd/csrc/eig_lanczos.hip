@@ -247,7 +247,7 @@ hipError_t lanczos_topk(const EigWorkspace& ws, double* lz, int32_t n, int32_t k
   // four steps (bisection + inverse iteration on T_m + two host round trips), and population structure converges
   // early (configs[1] stand-in: estimate 1e-14 at m = 12, true relative residual 3.7e-9)
   int next_check = 12;
-  if (const char* fc = std::getenv("PCOA_LANCZOS_FIRST_CHECK")) next_check = std::max(4, std::atoi(fc));
+  if (debug_knobs().lanczos_first_check > 0) next_check = std::max(4, debug_knobs().lanczos_first_check);
   if (next_check > mmax) next_check = mmax;
   std::vector<double> cand, ylast((size_t)k), hres((size_t)k);
   std::vector<int32_t> idx;
@@ -314,7 +314,7 @@ hipError_t lanczos_topk(const EigWorkspace& ws, double* lz, int32_t n, int32_t k
     bool ok = true;
     for (int t = 0; t < k; ++t) ok = ok && accept(fabs(beta_m * ylast[t]), t);
     const bool breakdown = beta_m <= 1e-14 * scale;  // invariant subspace: T_m holds exact eigenvalues
-    static const bool trace = std::getenv("PCOA_DEBUG_LANCZOS") != nullptr;
+    const bool trace = debug_knobs().lanczos_trace != 0;
     if (trace) {
       std::fprintf(stderr, "[lanczos] m=%d beta_m=%.3e scale=%.6e", m, beta_m, scale);
       for (int t = 0; t < k; ++t)

@@ -113,13 +113,16 @@ __device__ __forceinline__ void compute_stage(const Stage* st, int wm, int wn, i
 }
 
 __device__ __forceinline__ void store_tile(const f32x16& c, int32_t* __restrict__ s32, int n, int row0,
-                                           int col0, int lane) {
+                                           int col0, int lane, bool& inexact) {
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   const int j = col0 + (lane & 31);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int i = row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     const int v = (int)c[r];
+    // an fp32 chain of integer products is exact below 2^24; beyond it (carrier multiplicities m with V * m^2 >= 2^24 in
+    // one launch) the sum may have been rounded: reported, never silent
+    inexact |= (j >= i && j < n) && !(__builtin_fabsf(c[r]) < 16777216.0f);   // (padding columns may hold anything)
     if (j >= i && j < n && v != 0) atomicAdd(&s32[(int64_t)i * n + j], v);  // upper triangle only
   }
 }
@@ -127,7 +130,7 @@ __device__ __forceinline__ void store_tile(const f32x16& c, int32_t* __restrict_
 template <int VEC>
 __global__ __launch_bounds__(NT) void gram_f32_kernel(const float* __restrict__ x, int64_t ld, int64_t nv,
                                                       int n, int ntile, int ntri, int splitk, int64_t kchunk,
-                                                      int32_t* __restrict__ s32,
+                                                      int32_t* __restrict__ s32, int32_t* __restrict__ flag,
                                                       const float* __restrict__ zeros, int xcd_map) {
   __shared__ __attribute__((aligned(16))) Stage lds[2];
 
@@ -189,10 +192,12 @@ __global__ __launch_bounds__(NT) void gram_f32_kernel(const float* __restrict__ 
   wait_vmcnt<0>();  // drain the last (all-zero) prefetch before the LDS is released
 
   const int row0 = col_i + wm * 64, col0 = col_j + wn * 64;
-  store_tile(c00, s32, n, row0, col0, lane);
-  store_tile(c01, s32, n, row0, col0 + 32, lane);
-  store_tile(c10, s32, n, row0 + 32, col0, lane);
-  store_tile(c11, s32, n, row0 + 32, col0 + 32, lane);
+  bool inexact = false;
+  store_tile(c00, s32, n, row0, col0, lane, inexact);
+  store_tile(c01, s32, n, row0, col0 + 32, lane, inexact);
+  store_tile(c10, s32, n, row0 + 32, col0, lane, inexact);
+  store_tile(c11, s32, n, row0 + 32, col0 + 32, lane, inexact);
+  if (inexact && flag) atomicOr(flag, 16);
 }
 
 }  // namespace
@@ -225,10 +230,10 @@ hipError_t launch_gram_f32(const GramLaunch& g, int* splitk_out) {
   dim3 grid((unsigned)nblocks), block(NT);
   if (vec4) {
     hipLaunchKernelGGL(gram_f32_kernel<4>, grid, block, 0, g.stream, g.x, g.ld, g.nv, g.n, ntile, ntri,
-                       (int)splitk, kchunk, g.s32, g.zeros, xcd_map);
+                       (int)splitk, kchunk, g.s32, g.flag, g.zeros, xcd_map);
   } else {
     hipLaunchKernelGGL(gram_f32_kernel<1>, grid, block, 0, g.stream, g.x, g.ld, g.nv, g.n, ntile, ntri,
-                       (int)splitk, kchunk, g.s32, g.zeros, xcd_map);
+                       (int)splitk, kchunk, g.s32, g.flag, g.zeros, xcd_map);
   }
   return hipGetLastError();
 }

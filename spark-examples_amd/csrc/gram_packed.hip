@@ -108,9 +108,17 @@ __global__ __launch_bounds__(256) void pack_f32_i8_kernel(const float* __restric
     }
   }
   uint4* dst = reinterpret_cast<uint4*>(p + ((size_t)kb * npad + i0) * KB);
+  uint32_t mx = 0;  // largest multiplicity of this thread's 64 values (bytewise max of the packed words)
 #pragma unroll
-  for (int s = 0; s < 4; ++s) dst[s] = make_uint4(w[s][0], w[s][1], w[s][2], w[s][3]);
+  for (int s = 0; s < 4; ++s) {
+    dst[s] = make_uint4(w[s][0], w[s][1], w[s][2], w[s][3]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) mx = max(mx, (w[s][q] >> (8 * b)) & 0xffu);
+  }
   if (bad) atomicOr(flag, 4);
+  if (mx > 1) atomicMax(flag + 1, (int32_t)mx);   // binary tiles (the common case) never touch the word
 }
 
 // uint8 twin of the pre-pass: X u8 [V][ld] -> P.  One thread = 16 variants x 4 samples (16 coalesced 4-B
@@ -145,9 +153,14 @@ __global__ __launch_bounds__(256) void pack_u8_i8_kernel(const uint8_t* __restri
       if (i0 + s >= n) w &= ~(0xffu << (8 * s));
     v[t] = w;
   }
-  uint32_t any = 0;
+  uint32_t any = 0, mx = 0;
 #pragma unroll
-  for (int t = 0; t < 16; ++t) any |= v[t];
+  for (int t = 0; t < 16; ++t) {
+    any |= v[t];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) mx = max(mx, (v[t] >> (8 * b)) & 0xffu);
+  }
+  if (mx > 1) atomicMax(flag + 1, (int32_t)min(mx, 127u));
   uint4* dst = reinterpret_cast<uint4*>(p + ((size_t)kb * npad + i0) * KB);
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
@@ -317,7 +330,11 @@ __global__ __launch_bounds__(256) void pack_fp4_kernel(const T* __restrict__ x, 
   if (bad || badw) atomicOr(flag, 8);
 }
 
+#ifdef PCOA_EXPERIMENTS
 // ---- persistent FP4 pre-pass fed by an LDS-DMA ring (fp32 tiles with ld % 4 == 0) -----------------------------------
+// EXPERIMENT (only in a -DPCOA_EXPERIMENTS build; tools/exp_overlap.hip): bit-identical to and as fast as
+// pack_fp4_kernel (profiles/r02a), built to share a CU with the contraction -- which turned out negative-sum: a CU's
+// vector-memory path returns in order, so HBM-latency loads beside L2-hit operand loads slow both (profiles/r02d, r02e).
 // Same output as pack_fp4_kernel<float, 4>, built to run BESIDE the contraction: 256 threads (one wave per SIMD),
 // <= 64 VGPRs and 64 KiB of LDS, i.e. exactly what gram_packed_kernel (2 waves per SIMD x 224 VGPRs, 96 KiB) leaves free
 // on a CU, and a fixed grid of ~one workgroup per CU that lives for the whole launch (a stream of short-lived small
@@ -450,6 +467,8 @@ __global__ __launch_bounds__(256, 8) void pack_fp4_ring_kernel(const float* __re
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if (bad) atomicOr(flag, 8);
 }
+
+#endif  // PCOA_EXPERIMENTS
 
 // uint8 input, 8-byte loads: one thread packs 32 variants x 8 samples (a wave reads 512 contiguous bytes per row
 // instead of the 256 of the generic kernel above: 2504-byte rows are not line-aligned, so short segments pay for an
@@ -1001,8 +1020,11 @@ __device__ __forceinline__ void tile_coords(int tile, int ntile, int& row_blk, i
 template <int FMT, int NWM, int NNI, int SKB, int NST, bool PP, int LEFT = 0>
 __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram_packed_kernel(
     const int8_t* __restrict__ p, int npad, int64_t nstages, int n, int ntile, int ntri, int splitk,
-    int64_t stages_per, int32_t* __restrict__ s32, int xcd_map) {
+    int64_t stages_per, int32_t* __restrict__ s32, int xcd_map, const int32_t* __restrict__ skip) {
   __shared__ __attribute__((aligned(16))) StageI8<NWM, SKB> lds[NST];
+  // device-side predicate of the auto mode: a pre-pass met a value other than 0 / 1 in the buffered tiles, so this
+  // launch must not add anything to S (the host redoes those tiles on the int8 kernel once it reads the same word)
+  if (skip != nullptr && *skip != 0) return;
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1160,9 +1182,11 @@ hipError_t launch_pack_fp4(const void* x, int is_u8, int64_t ld, int64_t nv, int
 
 // Persistent LDS-ring twin of the fp32 FP4 pre-pass (pack_fp4_ring_kernel): `wgs` workgroups of 4 waves walk the
 // nkb_out x (Npad / 256) units.  Needs ld % 4 == 0 and a 16-byte aligned tile (the caller falls back to launch_pack_fp4).
+// (fp32 tiles the vectorised pre-passes take: ld % 4 == 0 and a 16-byte aligned base)
 bool pack_fp4_ring_ok(const void* x, int64_t ld) {
   return ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
 }
+#ifdef PCOA_EXPERIMENTS
 hipError_t launch_pack_fp4_ring(const float* x, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
                                 hipStream_t stream, int64_t nkb_out, int wgs, int nt) {
   if (nv <= 0) return hipSuccess;
@@ -1182,6 +1206,7 @@ hipError_t launch_pack_fp4_ring(const float* x, int64_t ld, int64_t nv, int32_t 
 #undef PCOA_RING
   return hipGetLastError();
 }
+#endif  // PCOA_EXPERIMENTS
 
 hipError_t launch_expand_bits_fp4(const uint32_t* bits, int64_t ld_words, int64_t nv, int32_t n, int8_t* p,
                                   hipStream_t stream, int64_t nkb_out) {
@@ -1242,9 +1267,6 @@ hipError_t launch_densify_csr_i8(const int32_t* idx_dev, const int64_t* offs_dev
   return hipGetLastError();
 }
 
-hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, int32_t* s32, int num_cu,
-                              hipStream_t stream, int* splitk_out);
-
 // carrier lists without repeated callsets -> nkb_out = ceil(nv / 32) k-blocks of FP4 operand at p
 hipError_t launch_densify_csr_fp4(const int32_t* idx_dev, const int64_t* offs_dev, int64_t nv, int64_t offs_base,
                                   int8_t* p, int32_t n, int32_t* flag, hipStream_t stream, int64_t nkb_out) {
@@ -1263,23 +1285,30 @@ hipError_t launch_gram_i8_packed(const int8_t* p, int64_t nv, int32_t n, int32_t
 }
 
 // Lock-step launch of the FP4 / int8 contraction (gram_packed_kernel with xcd_map = 2): ntri * splitk <= #CUs
-// persistent workgroups, splitk in {1, 2, 4, 8} k-streams, each on 8 / splitk XCDs.  Returns hipErrorInvalidValue when
-// the shape does not fit the chip (the caller then uses launch_gram_packed).
-hipError_t launch_gram_packed_lockstep(const int8_t* p, int fmt, int64_t nv, int32_t n, int32_t* s32, int num_cu,
-                                       hipStream_t stream) {
-  if (nv <= 0) return hipSuccess;
-  const int npad = (int)gram_packed_npad(n);
-  const int ntile = npad / TJ;
-  const int64_t ntri64 = (int64_t)ntile * (ntile + 1) / 2;
-  const int cus = num_cu > 0 ? num_cu : 256;
-  int splitk = 0;
+// persistent workgroups, splitk in {1, 2, 4, 8} k-streams, each on 8 / splitk XCDs.
+int gram_lockstep_splitk(int32_t n, int cus) {
+  const int ntile = (int)(gram_packed_npad(n) / TJ);
+  const int64_t ntri = (int64_t)ntile * (ntile + 1) / 2;
+  if (cus < kNumXcd) return 0;
   for (int k : {8, 4, 2, 1}) {
     const int g = kNumXcd / k;
-    const int64_t per = (ntri64 + g - 1) / g;
-    if (per * kNumXcd <= cus) { splitk = k; break; }   // one workgroup per CU, 32 CUs per XCD
+    const int64_t per = (ntri + g - 1) / g;
+    if (per * kNumXcd <= cus) return k;   // one workgroup per CU, cus / 8 CUs per XCD
   }
+  return 0;
+}
+int gram_lockstep_workgroups(int32_t n, int splitk) {
+  const int ntile = (int)(gram_packed_npad(n) / TJ);
+  return ntile * (ntile + 1) / 2 * splitk;
+}
+hipError_t launch_gram_packed_lockstep(const int8_t* p, int fmt, int64_t nv, int32_t n, int32_t* s32, int num_cu,
+                                       hipStream_t stream, const int32_t* skip) {
+  if (nv <= 0) return hipSuccess;
+  const int splitk = gram_lockstep_splitk(n, num_cu > 0 ? num_cu : 256);
   if (splitk == 0) return hipErrorInvalidValue;
-  const int ntri = (int)ntri64;
+  const int npad = (int)gram_packed_npad(n);
+  const int ntile = npad / TJ;
+  const int ntri = ntile * (ntile + 1) / 2;
   const int skb = 4;
   const int64_t nstages = gram_kb_pad(nv, fmt) / skb;
   const int64_t stages_per = (nstages + splitk - 1) / splitk;
@@ -1288,23 +1317,26 @@ hipError_t launch_gram_packed_lockstep(const int8_t* p, int fmt, int64_t nv, int
   const dim3 grid((unsigned)(per * kNumXcd)), block(512);
   if (fmt == 1)
     hipLaunchKernelGGL((gram_packed_kernel<1, 2, 2, 4, 3, true, 2>), grid, block, 0, stream, p, npad, nstages, n, ntile, ntri,
-                       splitk, stages_per, s32, 2);
+                       splitk, stages_per, s32, 2, skip);
   else
     hipLaunchKernelGGL((gram_packed_kernel<0, 2, 2, 4, 3, true, 2>), grid, block, 0, stream, p, npad, nstages, n, ntile, ntri,
-                       splitk, stages_per, s32, 2);
+                       splitk, stages_per, s32, 2, skip);
   return hipGetLastError();
 }
 
 hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, int32_t* s32, int num_cu,
-                              hipStream_t stream, int* splitk_out) {
+                              hipStream_t stream, int* splitk_out, const int32_t* skip) {
   if (nv <= 0) return hipSuccess;
-  // PCOA_GRAM_I8_CFG = [h]<k-blocks per stage><ring length>; h = 1 / 2 / 4: ping-pong with 0 / 2 / 4 MFMAs behind the
-  // barrier (243 = default), h absent: in-phase ring (43, 44)
-  static const int cfg = [] {
-    const char* v = std::getenv("PCOA_GRAM_I8_CFG");
-    const int t = v ? std::atoi(v) : 243;
-    return (t == 43 || t == 44 || t == 143 || t == 144 || t == 443) ? t : 243;  // 1xx / 2xx / 4xx = ping-pong with 0 / 2 / 4 MFMAs moved behind the barrier; xx = in-phase ring
-  }();
+  // Shipped schedule: ping-pong, 4 k-blocks per stage, 3-stage ring, two MFMAs behind the phase barrier ("243").  The
+  // other schedules of DESIGN.md 4.1 / 4.2 (PCOA_GRAM_I8_CFG = 43 | 44 | 143 | 144 | 443) only exist in a library built
+  // with -DPCOA_EXPERIMENTS.
+  int cfg = 243;
+#ifdef PCOA_EXPERIMENTS
+  {
+    const int t = debug_knobs().gram_cfg;
+    if (t == 43 || t == 44 || t == 143 || t == 144 || t == 443) cfg = t;
+  }
+#endif
   const int skb = (cfg % 100) / 10;
   const int npad = (int)gram_packed_npad(n);
   const int ntile = npad / TJ;
@@ -1315,10 +1347,7 @@ hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, i
   // one 512-thread workgroup per CU is resident; aim at ~7 work units per CU, >= 1024 variants each
   const int64_t target = (int64_t)(num_cu > 0 ? num_cu : 256) * 7;
   int64_t splitk = (target + ntri - 1) / ntri;
-  if (const char* sk = std::getenv("PCOA_GRAM_I8_SPLITK")) {  // experiment hook
-    const long long t = std::atoll(sk);
-    if (t > 0) splitk = t;
-  }
+  if (debug_knobs().gram_splitk > 0) splitk = debug_knobs().gram_splitk;  // experiment hook
   const int64_t max_by_work = nstages * skb / 64;
   if (splitk > max_by_work) splitk = max_by_work;
   if (splitk < 1) splitk = 1;
@@ -1336,17 +1365,19 @@ hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, i
   do {                                                                                                          \
     if (fmt == 1)                                                                                               \
       hipLaunchKernelGGL((gram_packed_kernel<1, 2, 2, SKB_, NST_, PP_, LEFT_>), grid, block, 0, stream, p, npad, nstages, n, ntile, \
-                         ntri, (int)splitk, stages_per, s32, xcd_map);                                          \
+                         ntri, (int)splitk, stages_per, s32, xcd_map, skip);                                    \
     else                                                                                                        \
       hipLaunchKernelGGL((gram_packed_kernel<0, 2, 2, SKB_, NST_, PP_, LEFT_>), grid, block, 0, stream, p, npad, nstages, n, ntile, \
-                         ntri, (int)splitk, stages_per, s32, xcd_map);                                          \
+                         ntri, (int)splitk, stages_per, s32, xcd_map, skip);                                    \
   } while (0)
   switch (cfg) {
+#ifdef PCOA_EXPERIMENTS
     case 44: PCOA_LAUNCH_I8(4, 4, false, 0); break;
     case 144: PCOA_LAUNCH_I8(4, 4, true, 0); break;
     case 43: PCOA_LAUNCH_I8(4, 3, false, 0); break;
     case 143: PCOA_LAUNCH_I8(4, 3, true, 0); break;
     case 443: PCOA_LAUNCH_I8(4, 3, true, 4); break;
+#endif
     default: PCOA_LAUNCH_I8(4, 3, true, 2); break;  // measured: 1.218 (LEFT 2) / 1.218 (4) / 1.236 (0) ms per 10^6 variants
   }
 #undef PCOA_LAUNCH_I8

@@ -46,7 +46,7 @@ struct pcoa_ctx {
   int64_t variants_in_s32 = 0;     // variants accumulated into s32 since the last fold
   bool dirty = false;              // s32 has contributions not yet mirrored
   float* zeros = nullptr;          // 4 KiB of zeros
-  int32_t* err_flag = nullptr;     // device
+  int32_t* err_flag = nullptr;     // device: [0] error bits, [1] max carrier multiplicity seen by the int8 pre-passes
 
   // staging (lazy)
   float* tile = nullptr;
@@ -64,17 +64,38 @@ struct pcoa_ctx {
   int64_t pack_cap = 0;            // bytes
   bool use_i8 = true;              // packed-operand Gram (FP4 / int8) or fp32-MFMA Gram
   int packed_mode = 0;             // 0 auto (FP4 for binary tiles, int8 otherwise), 2 int8 only, 3 FP4 only
-  int32_t* fp4_flag = nullptr;     // device: raised by the FP4 pre-pass on a value other than 0 / 1
   int64_t fp4_fallbacks = 0;
   int i8_streak = 0;               // auto mode: chunks still to be sent straight to the int8 kernel after a fallback
-  // FP4 operand buffer: binary chunks are only PACKED when they arrive; the contraction runs once the buffer is
-  // full or S is needed (finalize / read / all-reduce / compute), so that one launch carries up to 2^22 variants
-  // whatever the size of the calls -- its int32-atomic epilogue (one per output tile and launch, 0.11 ms at N = 2504)
-  // is then paid once per buffer, not once per call.
-  int8_t* fp4_buf = nullptr;
-  int64_t fp4_cap_kb = 0;          // capacity in k-blocks of 32 variants (+24 of zero padding behind it)
-  int64_t fp4_kb = 0;              // k-blocks buffered
-  int64_t fp4_vars = 0;            // variants buffered (the last k-block of a chunk may be partly empty)
+  // FP4 operand buffers.  Binary chunks are only PACKED when they arrive (behind what the active buffer already
+  // holds); a buffer is contracted when it is full or when S is needed (finalize / read / all-reduce / compute), so one
+  // launch carries up to the buffer's capacity whatever the size of the calls.  Two buffers exist where the fp32
+  // pipeline applies (fb_count == 2): the pre-pass of the next buffer then runs beside the contraction of the last one
+  // on disjoint CU sets.  Auto mode: the pre-passes of a buffer generation raise the buffer's device
+  // flag on a value other than 0 / 1, the contraction reads the same word and does nothing if it is set, and the host
+  // learns it when it next needs the buffer (fp4_resolve) and redoes the generation's chunks on the int8 kernel -- no
+  // host synchronisation per call.
+  struct Fp4Chunk { const void* x; int is_u8; int64_t nv, ld; };
+  struct Fp4Buf {
+    int8_t* p = nullptr;
+    int64_t cap_kb = 0;            // capacity in k-blocks of 32 variants (+24 of zero padding behind it)
+    int64_t kb = 0, vars = 0;      // filled: k-blocks / variants (the last k-block of a chunk may be partly empty)
+    hipStream_t fill_stream = nullptr;   // where this generation's pre-passes run (ctx stream or the masked pack stream)
+    hipEvent_t packed = nullptr, consumed = nullptr;
+    bool launched = false;         // the contraction of the last generation is queued; `consumed` tells when it is done
+    bool verify = false;           // that generation's pre-passes report non-binary values through the buffer's flag
+    int64_t launched_vars = 0;
+    std::vector<Fp4Chunk> chunks;  // device-resident inputs of the generation (kept until it is verified)
+  };
+  Fp4Buf fb[2];
+  int fb_count = 1, fb_active = 0;
+  int32_t* fb_flags = nullptr;       // device: the flag word of buffer b at fb_flags[16 * b]
+  int32_t* fb_flags_host = nullptr;  // pinned host copy, written by an async D2H behind each contraction
+  // fp32 pipeline: pre-pass and contraction on two streams with disjoint CU masks (16 + 16 CUs of every XCD)
+  bool pipe_ok = false;
+  int pipe_gram_cus = 0;
+  hipStream_t pack_stream = nullptr, gram_stream = nullptr;
+  hipEvent_t ev_fork = nullptr;
+  bool lockstep_ok = false;          // the lock-step contraction launch fits this N on the whole chip
   int64_t pack_chunk = (int64_t)1 << 20;  // variants packed + contracted per launch pair
   int64_t pack_launches = 0;
   double pack_bytes = 0;
@@ -145,7 +166,11 @@ hipEvent_t get_event(pcoa_ctx* c) {
 
 // resolves finished (or, if wait, all) event pairs into the per-category sums
 void drain_events(pcoa_ctx* c, bool wait) {
-  if (wait) (void)hipStreamSynchronize(c->stream);
+  if (wait) {
+    (void)hipStreamSynchronize(c->stream);
+    if (c->pack_stream) (void)hipStreamSynchronize(c->pack_stream);
+    if (c->gram_stream) (void)hipStreamSynchronize(c->gram_stream);
+  }
   size_t keep = 0;
   for (size_t i = 0; i < c->pending.size(); ++i) {
     EventPair& p = c->pending[i];
@@ -169,15 +194,16 @@ void drain_events(pcoa_ctx* c, bool wait) {
 struct ScopedTimer {
   pcoa_ctx* c;
   EventPair p;
+  hipStream_t s;
   bool on;
-  ScopedTimer(pcoa_ctx* ctx, int cat) : c(ctx), on(false) {
+  ScopedTimer(pcoa_ctx* ctx, int cat, hipStream_t stream = nullptr) : c(ctx), s(stream ? stream : ctx->stream), on(false) {
     p.a = get_event(c);
     p.b = get_event(c);
     p.cat = cat;
-    if (p.a && p.b && hipEventRecord(p.a, c->stream) == hipSuccess) on = true;
+    if (p.a && p.b && hipEventRecord(p.a, s) == hipSuccess) on = true;
   }
   ~ScopedTimer() {
-    if (on && hipEventRecord(p.b, c->stream) == hipSuccess) {
+    if (on && hipEventRecord(p.b, s) == hipSuccess) {
       c->pending.push_back(p);
       if (c->pending.size() > 2048) drain_events(c, true);
     } else {
@@ -212,17 +238,13 @@ int64_t staging_rows(int64_t n_variants, int64_t ld4) {
   return std::max<int64_t>(1, std::min(n_variants, rows));
 }
 
+constexpr int64_t KB_I8 = 16;                             // variants per int8 k-block
 constexpr int64_t kMaxLaunchVariants = (int64_t)1 << 24;  // fp32 accumulators exact below 2^24
 constexpr int64_t kFoldThreshold = (int64_t)1 << 30;      // fold int32 partials long before 2^31
 
-// Test hooks: PCOA_DEBUG_MAX_LAUNCH / PCOA_DEBUG_FOLD_THRESHOLD shrink the two limits so that the
-// multi-launch and int64-fold paths can be exercised with small inputs (read at pcoa_create).
-int64_t env_limit(const char* name, int64_t dflt) {
-  const char* v = std::getenv(name);
-  if (!v || !*v) return dflt;
-  const long long x = std::atoll(v);
-  return (x > 0 && x < dflt) ? (int64_t)x : dflt;
-}
+// Test hooks (DebugKnobs): PCOA_DEBUG_MAX_LAUNCH / PCOA_DEBUG_FOLD_THRESHOLD shrink the two limits so that the
+// multi-launch and int64-fold paths can be exercised with small inputs.
+int64_t knob_limit(int64_t x, int64_t dflt) { return (x > 0 && x < dflt) ? x : dflt; }
 
 int fold_now(pcoa_ctx* c) {
   const int64_t count = (int64_t)c->n * c->n;
@@ -238,18 +260,24 @@ int fold_now(pcoa_ctx* c) {
   return PCOA_OK;
 }
 
-// bookkeeping shared by every Gram launch
-void account_gram(pcoa_ctx* c, int64_t cur) {
+// bookkeeping shared by every Gram launch.  `weight` bounds what one variant can add to an entry of S: 1 for binary
+// tiles, m^2 for carrier multiplicities up to m.  variants_in_s32 is therefore an upper bound of every int32 partial;
+// the int64 fold and the int32 fast path of the all-reduce go by it.
+void account_gram(pcoa_ctx* c, int64_t cur, int64_t weight = 1) {
   c->gram_launches += 1;
   c->gram_variants += cur;
   c->gram_flops += 2.0 * (double)cur * (double)c->n * (double)c->n;
   c->gram_bytes += 4.0 * (double)cur * (double)c->n + 4.0 * (double)c->n * (double)c->n;
-  c->variants_in_s32 += cur;
+  c->variants_in_s32 += cur * weight;
   c->dirty = true;
 }
 
+int fp4_quiesce(pcoa_ctx* c);
+
 int fold_if_needed(pcoa_ctx* c, int64_t cur) {
   if (c->variants_in_s32 + cur > c->fold_threshold) {
+    int rc = fp4_quiesce(c);  // contractions queued on the side streams still add into S32
+    if (rc != PCOA_OK) return rc;
     ScopedTimer t(c, T_FINALIZE);
     return fold_now(c);
   }
@@ -257,76 +285,317 @@ int fold_if_needed(pcoa_ctx* c, int64_t cur) {
 }
 
 constexpr int64_t kBatchVariants = (int64_t)1 << 22;   // variants per FP4 contraction launch (fp32 exact below 2^24)
-constexpr int64_t kBatchBytes = (int64_t)6 << 30;      // cap of the FP4 operand buffer
+constexpr int64_t kBatchBytes = (int64_t)6 << 30;      // cap of an FP4 operand buffer
+constexpr int64_t kPipeVariants = (int64_t)1 << 20;    // buffer size where two buffers alternate (pipeline / lock-step)
 
 int64_t fp4_kb_bytes(const pcoa_ctx* c) { return gram_packed_npad(c->n) * 16; }
+int32_t* fb_flag(pcoa_ctx* c, int b) { return c->fb_flags + 16 * b; }
 
-// Contract what the FP4 operand buffer holds into S32.
-int fp4_flush(pcoa_ctx* c) {
-  if (c->fp4_kb == 0) return PCOA_OK;
-  int rc = fold_if_needed(c, c->fp4_vars);
-  if (rc != PCOA_OK) return rc;
-  const int64_t kb_pad = round_up(c->fp4_kb, 24);
-  if (kb_pad > c->fp4_kb)  // whole stages only: zero k-blocks behind the data
-    HIP_TRY(c, hipMemsetAsync(c->fp4_buf + c->fp4_kb * fp4_kb_bytes(c), 0, (size_t)((kb_pad - c->fp4_kb) * fp4_kb_bytes(c)),
-                              c->stream));
-  {
-    ScopedTimer t(c, T_GRAM);
-    hipError_t e = launch_gram_packed(c->fp4_buf, 1, c->fp4_kb * 32, c->n, c->s32, c->num_cu, c->stream, nullptr);
-    if (e != hipSuccess) return hip_fail(c, e, "packed gram kernel launch");
-  }
-  c->gram_kind = 3;
-  account_gram(c, c->fp4_vars);
-  c->fp4_kb = 0;
-  c->fp4_vars = 0;
+// k-blocks a buffer is meant to hold
+int64_t fp4_target_kb(const pcoa_ctx* c) {
+  const int64_t per_kb = fp4_kb_bytes(c);
+  const int64_t by_launch = (c->fb_count == 2) ? kPipeVariants : kBatchVariants;
+  return std::max<int64_t>(1, std::min(std::min(c->max_launch, by_launch) / 32, kBatchBytes / per_kb));
+}
+
+// `side` runs behind everything queued on the ctx stream so far
+int fork_to(pcoa_ctx* c, hipStream_t side) {
+  if (side == c->stream) return PCOA_OK;
+  HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+  HIP_TRY(c, hipStreamWaitEvent(side, c->ev_fork, 0));
   return PCOA_OK;
 }
 
-// Room for kb more k-blocks at the end of the FP4 operand buffer.  The buffer grows (contents kept) until it reaches
-// its target size -- straight away when the calls are large, geometrically when they are small -- and is only
-// contracted (fp4_flush) once that is full.
-int fp4_reserve(pcoa_ctx* c, int64_t kb, int64_t chunk_variants) {
-  if (c->fp4_kb + kb <= c->fp4_cap_kb) return PCOA_OK;
-  const int64_t per_kb = fp4_kb_bytes(c);
-  int64_t target = std::min(std::min(c->max_launch, kBatchVariants) / 32, kBatchBytes / per_kb);
-  target = std::max<int64_t>(target, kb);
-  if (c->fp4_cap_kb >= target || c->fp4_kb + kb > target) {  // full: contract what is there
-    int rc = fp4_flush(c);
-    if (rc != PCOA_OK) return rc;
-    if (kb <= c->fp4_cap_kb) return PCOA_OK;
+int int8_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64_t ld);
+
+// Lazily creates what the FP4 path needs besides the operand memory: the buffer flags (device + pinned host), the
+// events, and -- where the shape fits -- the two CU-masked streams of the fp32 pipeline.  hipExtStreamCreateWithCUMask
+// mask bit g = CU g / 8 of XCD g % 8 (measured: profiles/r02a, r02f): the pre-pass gets CUs 0..15 of every XCD, the
+// contraction CUs 16..31.
+int fp4_setup(pcoa_ctx* c) {
+  if (c->fb_flags) return PCOA_OK;
+  HIP_TRY(c, hipMalloc((void**)&c->fb_flags, 256));
+  HIP_TRY(c, hipMemsetAsync(c->fb_flags, 0, 256, c->stream));
+  HIP_TRY(c, hipHostMalloc((void**)&c->fb_flags_host, 256, hipHostMallocDefault));
+  std::memset(c->fb_flags_host, 0, 256);
+  HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  for (auto& b : c->fb) {
+    HIP_TRY(c, hipEventCreateWithFlags(&b.packed, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&b.consumed, hipEventDisableTiming));
   }
+  const DebugKnobs& k = debug_knobs();
+  // lock-step contraction on the whole chip: used when it fills >= 80 % of the CUs
+  const int ls = gram_lockstep_splitk(c->n, c->num_cu);
+  c->lockstep_ok = ls > 0 && gram_lockstep_workgroups(c->n, ls) * 5 >= c->num_cu * 4;
+  if (k.lockstep == 0) c->lockstep_ok = false;
+  if (k.lockstep == 1) c->lockstep_ok = ls > 0;
+  // fp32 pipeline: MI355X geometry (8 XCDs x 32 CUs) and a lock-step contraction that fills >= 80 % of half the chip
+  const int half = c->num_cu / 2;
+  const int lsh = (c->num_cu == 256) ? gram_lockstep_splitk(c->n, half) : 0;
+  bool want = lsh > 0 && gram_lockstep_workgroups(c->n, lsh) * 5 >= half * 4;
+  if (k.pipeline == 0) want = false;
+  if (k.pipeline == 1) want = lsh > 0;
+  if (want) {
+    uint32_t mp[8] = {0}, mg[8] = {0};
+    for (int g = 0; g < 256; ++g) {
+      if (g / 8 < 16) mp[g / 32] |= 1u << (g % 32);
+      else mg[g / 32] |= 1u << (g % 32);
+    }
+    hipError_t e1 = hipExtStreamCreateWithCUMask(&c->pack_stream, 8, mp);
+    hipError_t e2 = (e1 == hipSuccess) ? hipExtStreamCreateWithCUMask(&c->gram_stream, 8, mg) : e1;
+    if (e1 == hipSuccess && e2 == hipSuccess) {
+      c->pipe_ok = true;
+      c->pipe_gram_cus = half;
+      c->fb_count = 2;
+    } else {  // no CU-mask streams on this runtime: the serial path is what ships anyway
+      (void)hipGetLastError();
+      if (c->pack_stream) (void)hipStreamDestroy(c->pack_stream);
+      c->pack_stream = c->gram_stream = nullptr;
+    }
+  }
+  if (!c->pipe_ok && c->lockstep_ok) c->fb_count = 2;  // cheap epilogue: 2^20-variant launches from alternating buffers
+  return PCOA_OK;
+}
+
+// Queue the contraction of buffer b's current generation.  overlapped: more fp32 pre-passes are coming, so the
+// contraction goes to the masked contraction stream; otherwise it takes the whole chip on the ctx stream.
+int fp4_launch(pcoa_ctx* c, int bi, bool overlapped) {
+  pcoa_ctx::Fp4Buf& b = c->fb[bi];
+  if (b.kb == 0) return PCOA_OK;
+  int rc = fold_if_needed(c, b.vars);
+  if (rc != PCOA_OK) return rc;
+  const int64_t per_kb = fp4_kb_bytes(c);
+  const int64_t kb_pad = round_up(b.kb, 24);
+  if (kb_pad > b.kb)  // whole stages only: zero k-blocks behind the data
+    HIP_TRY(c, hipMemsetAsync(b.p + b.kb * per_kb, 0, (size_t)((kb_pad - b.kb) * per_kb), b.fill_stream));
+  const bool side = overlapped && c->pipe_ok;
+  hipStream_t gs = side ? c->gram_stream : c->stream;
+  if (gs != b.fill_stream) {
+    HIP_TRY(c, hipEventRecord(b.packed, b.fill_stream));
+    HIP_TRY(c, hipStreamWaitEvent(gs, b.packed, 0));
+  }
+  if ((rc = fork_to(c, gs)) != PCOA_OK) return rc;  // e.g. a pcoa_reset memset of S queued on the ctx stream
+  const int cus = side ? c->pipe_gram_cus : c->num_cu;
+  const int32_t* skip = b.verify ? fb_flag(c, bi) : nullptr;
+  {
+    ScopedTimer t(c, T_GRAM, gs);
+    hipError_t e = hipErrorInvalidValue;
+    if (side || c->lockstep_ok) e = launch_gram_packed_lockstep(b.p, 1, b.kb * 32, c->n, c->s32, cus, gs, skip);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      e = launch_gram_packed(b.p, 1, b.kb * 32, c->n, c->s32, cus, gs, nullptr, skip);
+    }
+    if (e != hipSuccess) return hip_fail(c, e, "packed gram kernel launch");
+  }
+  if (b.verify)
+    HIP_TRY(c, hipMemcpyAsync(c->fb_flags_host + 16 * bi, fb_flag(c, bi), sizeof(int32_t), hipMemcpyDeviceToHost, gs));
+  HIP_TRY(c, hipEventRecord(b.consumed, gs));
+  b.launched = true;
+  b.launched_vars = b.vars;
+  c->gram_kind = 3;
+  account_gram(c, b.vars);
+  b.kb = 0;
+  b.vars = 0;
+  return PCOA_OK;
+}
+
+// Wait for buffer b's queued contraction and, in auto mode, learn whether its pre-passes met a value other than
+// 0 / 1: the contraction then did nothing (device-side predicate) and the generation's chunks are redone on the int8
+// kernel -- their inputs are device pointers, valid until the next synchronising call returns (include/pcoa.h).
+int fp4_resolve(pcoa_ctx* c, int bi, bool redo = true) {
+  pcoa_ctx::Fp4Buf& b = c->fb[bi];
+  if (!b.launched) {
+    if (b.kb == 0) b.chunks.clear();
+    return PCOA_OK;
+  }
+  HIP_TRY(c, hipEventSynchronize(b.consumed));
+  b.launched = false;
+  int rc = PCOA_OK;
+  if (b.verify && c->fb_flags_host[16 * bi] != 0) {
+    // the skipped launch added nothing: take its variants back out of the books
+    c->gram_variants -= b.launched_vars;
+    c->gram_flops -= 2.0 * (double)b.launched_vars * (double)c->n * (double)c->n;
+    c->gram_bytes -= 4.0 * (double)b.launched_vars * (double)c->n + 4.0 * (double)c->n * (double)c->n;
+    c->variants_in_s32 -= b.launched_vars;
+    c->fb_flags_host[16 * bi] = 0;
+    HIP_TRY(c, hipMemsetAsync(fb_flag(c, bi), 0, sizeof(int32_t), c->stream));
+    if (redo) {
+      c->fp4_fallbacks += (int64_t)b.chunks.size();
+      c->i8_streak = 8;  // then FP4 is tried again
+      std::vector<pcoa_ctx::Fp4Chunk> chunks;
+      chunks.swap(b.chunks);
+      for (const auto& ch : chunks)
+        if ((rc = int8_chunk(c, ch.x, ch.is_u8, ch.nv, ch.ld)) != PCOA_OK) break;
+    }
+  }
+  b.chunks.clear();
+  return rc;
+}
+
+// Everything the FP4 path has queued anywhere has finished (and been verified) when this returns.
+int fp4_quiesce(pcoa_ctx* c) {
+  int rc = PCOA_OK;
+  for (int bi = 0; bi < 2 && rc == PCOA_OK; ++bi) rc = fp4_resolve(c, bi);
+  if (rc != PCOA_OK) return rc;
+  for (auto& b : c->fb)   // pre-passes of a generation still being filled on the masked stream
+    if (b.kb > 0 && b.fill_stream && b.fill_stream != c->stream) HIP_TRY(c, hipStreamSynchronize(b.fill_stream));
+  return PCOA_OK;
+}
+
+// Contract what the FP4 operand buffers hold into S32 and wait for it: S is needed.
+int fp4_flush(pcoa_ctx* c) {
+  int rc = PCOA_OK;
+  for (int bi = 0; bi < 2; ++bi)
+    if (c->fb[bi].kb > 0 && (rc = fp4_launch(c, bi, false)) != PCOA_OK) return rc;
+  return fp4_quiesce(c);
+}
+
+// A synchronising call that does not need S (pcoa_sync, timings): afterwards the caller may release the device inputs
+// of earlier accumulate calls, so generations whose verification is still owed (auto mode, device pointers) are
+// contracted and verified now; generations that owe nothing (host tiles, bitsets, carrier lists) stay buffered.
+int fp4_sync_point(pcoa_ctx* c) {
+  int rc = PCOA_OK;
+  for (int bi = 0; bi < 2; ++bi)
+    if (c->fb[bi].kb > 0 && c->fb[bi].verify && (rc = fp4_launch(c, bi, false)) != PCOA_OK) return rc;
+  return fp4_quiesce(c);
+}
+
+// S is being replaced or zeroed: what is buffered or in flight for the old S goes with it.
+int fp4_discard(pcoa_ctx* c) {
+  for (int bi = 0; bi < 2; ++bi) {
+    pcoa_ctx::Fp4Buf& b = c->fb[bi];
+    int rc = fp4_resolve(c, bi, false);
+    if (rc != PCOA_OK) return rc;
+    if (b.kb > 0 && b.fill_stream && b.fill_stream != c->stream) HIP_TRY(c, hipStreamSynchronize(b.fill_stream));
+    b.kb = 0;
+    b.vars = 0;
+    b.chunks.clear();
+  }
+  return PCOA_OK;
+}
+
+// Capacity for kb more k-blocks in buffer bi (contents kept).  The buffer grows straight to its target size when the
+// calls are large, geometrically when they are small.
+int fp4_grow(pcoa_ctx* c, int bi, int64_t kb, int64_t chunk_variants) {
+  pcoa_ctx::Fp4Buf& b = c->fb[bi];
+  if (b.kb + kb <= b.cap_kb) return PCOA_OK;
+  const int64_t per_kb = fp4_kb_bytes(c);
+  const int64_t target = std::max(fp4_target_kb(c), kb);
   const int64_t floor_kb = std::max<int64_t>(1, std::min<int64_t>(1024, ((int64_t)256 << 20) / per_kb));
   int64_t want = (chunk_variants >= ((int64_t)1 << 18))
                      ? target
-                     : std::min(target, std::max(std::max(c->fp4_kb + kb, floor_kb), 2 * c->fp4_cap_kb));
+                     : std::min(target, std::max(std::max(b.kb + kb, floor_kb), 2 * b.cap_kb));
   int8_t* fresh = nullptr;
   for (;;) {
     hipError_t e = hipMalloc((void**)&fresh, (size_t)((want + 24) * per_kb));
     if (e == hipSuccess) break;
     (void)hipGetLastError();
-    if (want <= c->fp4_kb + kb) {       // no room to grow: contract, then make do with what fits
-      int rc = fp4_flush(c);
-      if (rc != PCOA_OK) return rc;
-      if (kb <= c->fp4_cap_kb) return PCOA_OK;
-      if (want <= kb) return hip_fail(c, e, "hipMalloc(FP4 operand buffer)");
-    }
-    want = std::max(c->fp4_kb + kb, want / 2);
+    if (want <= b.kb + kb) return hip_fail(c, e, "hipMalloc(FP4 operand buffer)");
+    want = std::max(b.kb + kb, want / 2);
   }
-  if (c->fp4_kb > 0)
-    HIP_TRY(c, hipMemcpyAsync(fresh, c->fp4_buf, (size_t)(c->fp4_kb * per_kb), hipMemcpyDeviceToDevice, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));  // the old buffer may still be read by queued kernels
-  if (c->fp4_buf) (void)hipFree(c->fp4_buf);
-  c->fp4_buf = fresh;
-  c->fp4_cap_kb = want;
+  hipStream_t s = b.fill_stream ? b.fill_stream : c->stream;
+  if (b.kb > 0) HIP_TRY(c, hipMemcpyAsync(fresh, b.p, (size_t)(b.kb * per_kb), hipMemcpyDeviceToDevice, s));
+  HIP_TRY(c, hipStreamSynchronize(s));   // the old buffer may still be read by queued kernels ...
+  if (b.launched) HIP_TRY(c, hipEventSynchronize(b.consumed));  // ... or by its last contraction
+  if (b.p) (void)hipFree(b.p);
+  b.p = fresh;
+  b.cap_kb = want;
+  return PCOA_OK;
+}
+
+// Where the next `kb` k-blocks of packed operand go: *dst in the active buffer, to be written on *stream (already
+// ordered behind the ctx stream).  deferrable_f32: the chunk is an fp32 device tile whose pre-pass may run on the
+// masked stream beside a contraction in flight; verify: its pre-pass reports non-binary values through *flag.
+int fp4_reserve(pcoa_ctx* c, int64_t kb, int64_t chunk_variants, bool deferrable_f32, bool verify, int8_t** dst,
+                hipStream_t* stream, int32_t** flag) {
+  int rc = fp4_setup(c);
+  if (rc != PCOA_OK) return rc;
+  pcoa_ctx::Fp4Buf* b = &c->fb[c->fb_active];
+  const bool want_side = deferrable_f32 && c->pipe_ok;
+  // a generation filling on the masked stream only takes chunks that may run there; a generation that does not report
+  // through its flag cannot start to (an earlier launch decision may already have been made without it)
+  // (nor the other way round: a skipped launch would drop chunks that cannot be redone)
+  const bool misfit = b->kb > 0 && ((b->fill_stream != c->stream && !want_side) || (verify != b->verify));
+  const bool full = b->kb > 0 && b->kb + kb > std::max(fp4_target_kb(c), kb);
+  if (misfit || full) {
+    if ((rc = fp4_launch(c, c->fb_active, want_side)) != PCOA_OK) return rc;
+    if (c->fb_count == 2) c->fb_active ^= 1;
+    b = &c->fb[c->fb_active];
+  }
+  if (b->kb == 0) {  // a new generation starts in this buffer: the old one must be done and verified
+    if ((rc = fp4_resolve(c, c->fb_active)) != PCOA_OK) return rc;
+    b->verify = verify;
+    b->fill_stream = c->stream;
+    if (want_side) {
+      const pcoa_ctx::Fp4Buf& o = c->fb[c->fb_active ^ 1];
+      if (o.launched && hipEventQuery(o.consumed) == hipErrorNotReady) b->fill_stream = c->pack_stream;
+      (void)hipGetLastError();
+    }
+  }
+  if ((rc = fp4_grow(c, c->fb_active, kb, chunk_variants)) != PCOA_OK) return rc;
+  if ((rc = fork_to(c, b->fill_stream)) != PCOA_OK) return rc;
+  *dst = b->p + b->kb * fp4_kb_bytes(c);
+  *stream = b->fill_stream;
+  if (flag) *flag = fb_flag(c, c->fb_active);
+  return PCOA_OK;
+}
+
+void fp4_commit(pcoa_ctx* c, int64_t kb, int64_t vars) {
+  pcoa_ctx::Fp4Buf& b = c->fb[c->fb_active];
+  b.kb += kb;
+  b.vars += vars;
+  c->gram_kind = 3;
+  c->dirty = true;
+}
+
+// int8 path of one chunk: pre-pass into the workspace and contraction at once, on the ctx stream.  The pre-pass
+// reports the largest carrier multiplicity m it met; one variant adds at most m^2 to an entry of S, so the launch is
+// cut into pieces of < 2^31 / m^2 variants (int32 accumulators and partials) and the books carry the weight m^2.
+int int8_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64_t ld) {
+  int rc = PCOA_OK;
+  const int64_t need = (int64_t)gram_packed_workspace_bytes(c->n, cur);
+  if ((rc = ensure(c, &c->pack_buf, &c->pack_cap, need)) != PCOA_OK) return rc;
+  HIP_TRY(c, hipMemsetAsync(c->err_flag + 1, 0, sizeof(int32_t), c->stream));
+  {
+    ScopedTimer t(c, T_PACK);
+    hipError_t e = is_u8 ? launch_pack_u8_i8(static_cast<const uint8_t*>(x_chunk), ld, cur, c->n, c->pack_buf,
+                                             c->err_flag, c->stream)
+                         : launch_pack_f32_i8(static_cast<const float*>(x_chunk), ld, cur, c->n, c->pack_buf,
+                                              c->err_flag, c->stream);
+    if (e != hipSuccess) return hip_fail(c, e, "pack(i8) kernel launch");
+    c->pack_launches += 1;
+    c->pack_bytes += (is_u8 ? 1.0 : 4.0) * (double)cur * (double)c->n + (double)need;
+  }
+  int32_t mmax = 0;
+  HIP_TRY(c, hipMemcpyAsync(&mmax, c->err_flag + 1, sizeof(mmax), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const int64_t weight = (int64_t)std::max(1, mmax) * std::max(1, mmax);
+  // (< 2^30 per launch on top of a partial that is folded before it passes 2^30: every int32 stays below 2^31)
+  const int64_t per_launch = std::max<int64_t>(24 * KB_I8, ((int64_t)1 << 30) / weight / (24 * KB_I8) * (24 * KB_I8));
+  const int64_t row_bytes = gram_packed_npad(c->n) * 16;  // one k-block of 16 variants
+  for (int64_t v0 = 0; v0 < cur; v0 += per_launch) {
+    const int64_t part = std::min(per_launch, cur - v0);
+    if ((rc = fold_if_needed(c, part * weight)) != PCOA_OK) return rc;
+    {
+      ScopedTimer t(c, T_GRAM);
+      hipError_t e = launch_gram_packed(c->pack_buf + (v0 / KB_I8) * row_bytes, 0, part, c->n, c->s32, c->num_cu, c->stream,
+                                        nullptr);
+      if (e != hipSuccess) return hip_fail(c, e, "packed gram kernel launch");
+    }
+    c->gram_kind = 2;
+    account_gram(c, part, weight);
+  }
   return PCOA_OK;
 }
 
 // One chunk (<= pack_chunk variants) of a dense tile resident on the device: re-layout pre-pass into the
-// packed operand workspace, then the matrix-core contraction.
+// packed operand, then (at once, or when the buffer is full / S is needed) the matrix-core contraction.
 //   auto : FP4 pre-pass (it also verifies that every value is exactly 0 or 1); if a tile holds a
-//          multiplicity the chunk is re-packed as int8 and contracted on the i8 MFMA instead;
+//          multiplicity its buffer generation is redone as int8 and contracted on the i8 MFMA instead;
 //   fp4  : FP4 only, a non-binary value is an error;   i8 : int8 only (values 0..127).
-int packed_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64_t ld) {
+// can_defer: x_chunk stays valid until the next synchronising call (a caller's device pointer); a staging tile that
+// is about to be overwritten is verified at once instead.
+int packed_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64_t ld, bool can_defer) {
   const double in_bytes = (is_u8 ? 1.0 : 4.0) * (double)cur * (double)c->n;
   int rc = PCOA_OK;
   bool fp4 = c->packed_mode != 2;
@@ -336,28 +605,29 @@ int packed_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64
     fp4 = false;
   }
   if (fp4) {
-    // binary tile (to be verified by the pre-pass): packed behind what the FP4 operand buffer already holds; the
-    // contraction is deferred (fp4_flush)
+    const bool autom = c->packed_mode == 0;
     const int64_t kb = (cur + 31) / 32;
-    if ((rc = fp4_reserve(c, kb, cur)) != PCOA_OK) return rc;
-    int8_t* dst = c->fp4_buf + c->fp4_kb * fp4_kb_bytes(c);
+    int8_t* dst = nullptr;
+    hipStream_t ps = nullptr;
+    int32_t* bflag = nullptr;
+    const bool deferrable_f32 = can_defer && !is_u8 && pack_fp4_ring_ok(x_chunk, ld);
+    if ((rc = fp4_reserve(c, kb, cur, deferrable_f32, autom && can_defer, &dst, &ps, &bflag)) != PCOA_OK) return rc;
+    // where the pre-pass reports a value other than 0 / 1: the generation's flag (auto, deferred), a scratch word that
+    // is read back at once (auto, staging tile), or the ctx error word (FP4 forced: an error)
     int32_t* flag = c->err_flag;
-    if (c->packed_mode == 0) {
-      if (!c->fp4_flag) HIP_TRY(c, hipMalloc((void**)&c->fp4_flag, 16));
-      HIP_TRY(c, hipMemsetAsync(c->fp4_flag, 0, 16, c->stream));
-      flag = c->fp4_flag;
-    }
+    if (autom) flag = can_defer ? bflag : (c->fb_flags + 32);
+    if (autom && !can_defer) HIP_TRY(c, hipMemsetAsync(flag, 0, sizeof(int32_t), ps));
     {
-      ScopedTimer t(c, T_PACK);
-      hipError_t e = launch_pack_fp4(x_chunk, is_u8, ld, cur, c->n, dst, flag, c->stream, kb);
+      ScopedTimer t(c, T_PACK, ps);
+      hipError_t e = launch_pack_fp4(x_chunk, is_u8, ld, cur, c->n, dst, flag, ps, kb);
       if (e != hipSuccess) return hip_fail(c, e, "pack(fp4) kernel launch");
     }
     c->pack_launches += 1;
     c->pack_bytes += in_bytes + (double)(kb * fp4_kb_bytes(c));
-    if (c->packed_mode == 0) {
+    if (autom && !can_defer) {
       int32_t seen = 0;
-      HIP_TRY(c, hipMemcpyAsync(&seen, c->fp4_flag, sizeof(seen), hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      HIP_TRY(c, hipMemcpyAsync(&seen, flag, sizeof(seen), hipMemcpyDeviceToHost, ps));
+      HIP_TRY(c, hipStreamSynchronize(ps));
       if (seen) {  // a multiplicity (or garbage): this chunk takes the int8 path, which validates 0..127
         fp4 = false;  // (what was just written behind the buffered k-blocks is simply not kept)
         c->fp4_fallbacks += 1;
@@ -365,44 +635,21 @@ int packed_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64
       }
     }
     if (fp4) {
-      c->fp4_kb += kb;
-      c->fp4_vars += cur;
-      c->gram_kind = 3;
-      c->dirty = true;
+      if (autom && can_defer) c->fb[c->fb_active].chunks.push_back(pcoa_ctx::Fp4Chunk{x_chunk, is_u8, cur, ld});
+      fp4_commit(c, kb, cur);
       return PCOA_OK;
     }
   }
-  // int8 path: pre-pass into the workspace and contraction at once
-  if ((rc = fold_if_needed(c, cur)) != PCOA_OK) return rc;
-  const int64_t need = (int64_t)gram_packed_workspace_bytes(c->n, cur);
-  if ((rc = ensure(c, &c->pack_buf, &c->pack_cap, need)) != PCOA_OK) return rc;
-  {
-    ScopedTimer t(c, T_PACK);
-    hipError_t e = is_u8 ? launch_pack_u8_i8(static_cast<const uint8_t*>(x_chunk), ld, cur, c->n, c->pack_buf,
-                                             c->err_flag, c->stream)
-                         : launch_pack_f32_i8(static_cast<const float*>(x_chunk), ld, cur, c->n, c->pack_buf,
-                                              c->err_flag, c->stream);
-    if (e != hipSuccess) return hip_fail(c, e, "pack(i8) kernel launch");
-    c->pack_launches += 1;
-    c->pack_bytes += in_bytes + (double)need;
-  }
-  {
-    ScopedTimer t(c, T_GRAM);
-    hipError_t e = launch_gram_packed(c->pack_buf, 0, cur, c->n, c->s32, c->num_cu, c->stream, nullptr);
-    if (e != hipSuccess) return hip_fail(c, e, "packed gram kernel launch");
-  }
-  c->gram_kind = 2;
-  account_gram(c, cur);
-  return PCOA_OK;
+  return int8_chunk(c, x_chunk, is_u8, cur, ld);
 }
 
 // uint8 tile resident on the device (always a packed-operand path)
-int gram_device_u8(pcoa_ctx* c, const uint8_t* x_dev, int64_t nv, int64_t ld) {
+int gram_device_u8(pcoa_ctx* c, const uint8_t* x_dev, int64_t nv, int64_t ld, bool can_defer) {
   int64_t done = 0;
   const int64_t max_cur = std::min(c->max_launch, c->pack_chunk);
   while (done < nv) {
     const int64_t cur = std::min(nv - done, max_cur);
-    int rc = packed_chunk(c, x_dev + done * ld, 1, cur, ld);
+    int rc = packed_chunk(c, x_dev + done * ld, 1, cur, ld, can_defer);
     if (rc != PCOA_OK) return rc;
     done += cur;
   }
@@ -410,7 +657,7 @@ int gram_device_u8(pcoa_ctx* c, const uint8_t* x_dev, int64_t nv, int64_t ld) {
 }
 
 // X tile already resident on the device: split into launches that keep fp32/int32 exact.
-int gram_device(pcoa_ctx* c, const float* x_dev, int64_t nv, int64_t ld) {
+int gram_device(pcoa_ctx* c, const float* x_dev, int64_t nv, int64_t ld, bool can_defer) {
   int64_t done = 0;
   const int64_t max_cur = c->use_i8 ? std::min(c->max_launch, c->pack_chunk) : c->max_launch;
   while (done < nv) {
@@ -418,7 +665,7 @@ int gram_device(pcoa_ctx* c, const float* x_dev, int64_t nv, int64_t ld) {
     if (c->use_i8) {
       // fp32 tile -> packed operand (HBM-bound pre-pass); the matrix-core contraction follows at once (int8) or when
       // the FP4 operand buffer is full / S is needed (packed_chunk accounts for itself)
-      int rc = packed_chunk(c, x_dev + done * ld, 0, cur, ld);
+      int rc = packed_chunk(c, x_dev + done * ld, 0, cur, ld, can_defer);
       if (rc != PCOA_OK) return rc;
       done += cur;
       continue;
@@ -431,6 +678,7 @@ int gram_device(pcoa_ctx* c, const float* x_dev, int64_t nv, int64_t ld) {
       g.nv = cur;
       g.n = c->n;
       g.s32 = c->s32;
+      g.flag = c->err_flag;
       g.zeros = c->zeros;
       g.num_cu = c->num_cu;
       g.stream = c->stream;
@@ -454,6 +702,10 @@ int check_device_flags(pcoa_ctx* c) {
     return fail(c, PCOA_ERR_INVALID_ARG,
                 "a genotype tile holds a value other than 0 or 1 and PCOA_FLAG_GRAM_FP4_MFMA was forced; S is "
                 "invalid, call pcoa_reset; the default mode falls back to the int8 kernel by itself");
+  if (flag & 16)
+    return fail(c, PCOA_ERR_INVALID_ARG,
+                "an fp32 accumulator of the fp32-MFMA kernel left the exact range (a sum of products reached 2^24 inside "
+                "one launch: carrier multiplicities too large for it); S is invalid, call pcoa_reset");
   if (flag & 4)
     return fail(c, PCOA_ERR_INVALID_ARG,
                 "a genotype tile holds a value that is not an integer in [0, 127] (carrier multiplicity); S is "
@@ -537,6 +789,36 @@ int upload_synth(pcoa_ctx* c, const pcoa_synth_params* p, int64_t nv) {
 
 }  // namespace
 
+namespace pcoa {
+const DebugKnobs& debug_knobs() {
+  static const DebugKnobs knobs = [] {
+    DebugKnobs k;
+    auto num = [](const char* name) -> long long {
+      const char* v = std::getenv(name);
+      return (v && *v) ? std::atoll(v) : 0;
+    };
+    if (const char* kk = std::getenv("PCOA_GRAM_KERNEL")) {
+      if (!std::strcmp(kk, "f32")) k.gram_kernel = 1;
+      if (!std::strcmp(kk, "i8")) k.gram_kernel = 2;
+      if (!std::strcmp(kk, "fp4")) k.gram_kernel = 3;
+      if (!std::strcmp(kk, "auto")) k.gram_kernel = 0;
+    }
+    k.pack_chunk = num("PCOA_DEBUG_PACK_CHUNK");
+    k.max_launch = num("PCOA_DEBUG_MAX_LAUNCH");
+    k.fold_threshold = num("PCOA_DEBUG_FOLD_THRESHOLD");
+    if (const char* v = std::getenv("PCOA_PIPELINE")) k.pipeline = std::atoi(v) != 0;
+    if (const char* v = std::getenv("PCOA_GRAM_LOCKSTEP")) k.lockstep = std::atoi(v) != 0;
+    k.explicit_center = std::getenv("PCOA_EXPLICIT_CENTER") != nullptr;
+    k.lanczos_first_check = (int)num("PCOA_LANCZOS_FIRST_CHECK");
+    k.lanczos_trace = std::getenv("PCOA_DEBUG_LANCZOS") != nullptr;
+    k.gram_cfg = (int)num("PCOA_GRAM_I8_CFG");
+    k.gram_splitk = (int)num("PCOA_GRAM_I8_SPLITK");
+    return k;
+  }();
+  return knobs;
+}
+}  // namespace pcoa
+
 // ================================================================================================
 extern "C" {
 
@@ -562,24 +844,20 @@ int pcoa_create(pcoa_ctx** out, int32_t n_samples, int32_t device_ordinal, uint3
   c->flags = flags;
   c->use_i8 = !(flags & PCOA_FLAG_GRAM_F32_MFMA);
   c->packed_mode = (flags & PCOA_FLAG_GRAM_I8_MFMA) ? 2 : (flags & PCOA_FLAG_GRAM_FP4_MFMA) ? 3 : 0;
-  if (const char* kk = std::getenv("PCOA_GRAM_KERNEL")) {
-    if (!std::strcmp(kk, "f32")) c->use_i8 = false;
-    if (!std::strcmp(kk, "i8")) { c->use_i8 = true; c->packed_mode = 2; }
-    if (!std::strcmp(kk, "fp4")) { c->use_i8 = true; c->packed_mode = 3; }
-    if (!std::strcmp(kk, "auto")) { c->use_i8 = true; c->packed_mode = 0; }
-  }
+  const DebugKnobs& knobs = debug_knobs();
+  if (knobs.gram_kernel == 1) c->use_i8 = false;
+  if (knobs.gram_kernel == 2) { c->use_i8 = true; c->packed_mode = 2; }
+  if (knobs.gram_kernel == 3) { c->use_i8 = true; c->packed_mode = 3; }
+  if (knobs.gram_kernel == 0) { c->use_i8 = true; c->packed_mode = 0; }
   c->gram_kind = c->use_i8 ? (c->packed_mode == 2 ? 2 : 3) : 1;
   {
     // keep the int8 workspace at or below ~4 GiB whatever N is (one byte per genotype, Npad columns)
     const int64_t by_mem = (((int64_t)4 << 30) / gram_packed_npad(n_samples)) / 1536 * 1536;
     c->pack_chunk = std::max<int64_t>(1536, std::min<int64_t>(c->pack_chunk, by_mem));
   }
-  if (const char* pc = std::getenv("PCOA_DEBUG_PACK_CHUNK")) {
-    const long long x = std::atoll(pc);
-    if (x > 0 && x <= ((long long)1 << 24)) c->pack_chunk = (int64_t)x;
-  }
-  c->max_launch = env_limit("PCOA_DEBUG_MAX_LAUNCH", kMaxLaunchVariants);
-  c->fold_threshold = env_limit("PCOA_DEBUG_FOLD_THRESHOLD", kFoldThreshold);
+  if (knobs.pack_chunk > 0 && knobs.pack_chunk <= ((int64_t)1 << 24)) c->pack_chunk = knobs.pack_chunk;
+  c->max_launch = knob_limit(knobs.max_launch, kMaxLaunchVariants);
+  c->fold_threshold = knob_limit(knobs.fold_threshold, kFoldThreshold);
   auto bail = [&](hipError_t err, const char* what) {
     int rc = hip_fail(c, err, what);
     g_create_error = c->last_error;
@@ -610,14 +888,25 @@ void pcoa_destroy(pcoa_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->pack_stream) (void)hipStreamSynchronize(c->pack_stream);
+  if (c->gram_stream) (void)hipStreamSynchronize(c->gram_stream);
   for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto& ev : c->pool) (void)hipEventDestroy(ev);
+  for (auto& b : c->fb) {
+    if (b.packed) (void)hipEventDestroy(b.packed);
+    if (b.consumed) (void)hipEventDestroy(b.consumed);
+    if (b.p) (void)hipFree(b.p);
+  }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->fb_flags_host) (void)hipHostFree(c->fb_flags_host);
   void* bufs[] = {c->s32, c->s64, c->zeros, c->err_flag, c->tile, c->csr_idx, c->csr_offs, c->thr_dev,
-                  c->sample_pop, c->xfer, c->coll, c->fp4_flag, c->fp4_buf, c->pack_buf, c->lanczos_ws, c->ws.a, c->ws.d, c->ws.e, c->ws.tau, c->ws.q, c->ws.w, c->ws.lam,
+                  c->sample_pop, c->xfer, c->coll, c->fb_flags, c->pack_buf, c->lanczos_ws, c->ws.a, c->ws.d, c->ws.e, c->ws.tau, c->ws.q, c->ws.w, c->ws.lam,
                   c->ws.z, c->ws.scratch, c->ws.iscratch, c->row_sums, c->colmean, c->stats, c->nz,
                   c->out_dev};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
+  if (c->pack_stream) (void)hipStreamDestroy(c->pack_stream);
+  if (c->gram_stream) (void)hipStreamDestroy(c->gram_stream);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -628,6 +917,8 @@ int pcoa_n_samples(const pcoa_ctx* c) { return c ? c->n : PCOA_ERR_INVALID_ARG; 
 
 int pcoa_set_stream(pcoa_ctx* c, void* hip_stream) {
   CHECK_CTX(c);
+  int rc = fp4_flush(c);  // nothing of the old stream's generation survives the switch half-filled
+  if (rc != PCOA_OK) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   drain_events(c, true);
   c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
@@ -636,19 +927,21 @@ int pcoa_set_stream(pcoa_ctx* c, void* hip_stream) {
 
 int pcoa_sync(pcoa_ctx* c) {
   CHECK_CTX(c);
+  int rc = fp4_sync_point(c);
+  if (rc != PCOA_OK) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return PCOA_OK;
 }
 
 int pcoa_reset(pcoa_ctx* c) {
   CHECK_CTX(c);
+  int rc = fp4_discard(c);  // buffered or in-flight operands belong to the old S
+  if (rc != PCOA_OK) return rc;
   const size_t nn = (size_t)c->n * (size_t)c->n;
   HIP_TRY(c, hipMemsetAsync(c->s32, 0, sizeof(int32_t) * nn, c->stream));
   if (c->s64) HIP_TRY(c, hipMemsetAsync(c->s64, 0, sizeof(int64_t) * nn, c->stream));
   HIP_TRY(c, hipMemsetAsync(c->err_flag, 0, 16, c->stream));
   c->variants_in_s32 = 0;
-  c->fp4_kb = 0;  // buffered, not yet contracted operands belong to the old S
-  c->fp4_vars = 0;
   c->dirty = false;
   return PCOA_OK;
 }
@@ -658,7 +951,7 @@ int pcoa_accumulate_dense_f32(pcoa_ctx* c, const float* x, int64_t n_variants, i
   if (n_variants < 0 || (n_variants > 0 && !x)) return fail(c, PCOA_ERR_INVALID_ARG, "x is NULL or n_variants < 0");
   if (ld < c->n) return fail(c, PCOA_ERR_INVALID_ARG, "ld must be >= n_samples");
   if (n_variants == 0) return PCOA_OK;
-  if (is_device_ptr) return gram_device(c, x, n_variants, ld);
+  if (is_device_ptr) return gram_device(c, x, n_variants, ld, true);
   // host tile: stage through a device tile of at most ~256 MiB, rows packed at ld4 = round_up(n, 4)
   const int64_t ld4 = round_up(c->n, 4);
   const int64_t rows_cap = staging_rows(n_variants, ld4);
@@ -669,7 +962,7 @@ int pcoa_accumulate_dense_f32(pcoa_ctx* c, const float* x, int64_t n_variants, i
     if (ld4 != c->n) HIP_TRY(c, hipMemsetAsync(c->tile, 0, sizeof(float) * (size_t)(rows * ld4), c->stream));
     HIP_TRY(c, hipMemcpy2DAsync(c->tile, sizeof(float) * (size_t)ld4, x + v0 * ld, sizeof(float) * (size_t)ld,
                                 sizeof(float) * (size_t)c->n, (size_t)rows, hipMemcpyHostToDevice, c->stream));
-    rc = gram_device(c, c->tile, rows, ld4);
+    rc = gram_device(c, c->tile, rows, ld4, false);
     if (rc != PCOA_OK) return rc;
   }
   // the caller may free/overwrite x after we return: pageable copies have been staged, but keep it simple
@@ -682,7 +975,7 @@ int pcoa_accumulate_dense_u8(pcoa_ctx* c, const uint8_t* x, int64_t n_variants, 
   if (n_variants < 0 || (n_variants > 0 && !x)) return fail(c, PCOA_ERR_INVALID_ARG, "x is NULL or n_variants < 0");
   if (ld < c->n) return fail(c, PCOA_ERR_INVALID_ARG, "ld must be >= n_samples");
   if (n_variants == 0) return PCOA_OK;
-  if (is_device_ptr) return gram_device_u8(c, x, n_variants, ld);
+  if (is_device_ptr) return gram_device_u8(c, x, n_variants, ld, true);
   // host tile: staged through the (byte-addressed) tile buffer in chunks of at most 256 MiB
   const int64_t ld4 = round_up(c->n, 4);
   const int64_t rows_cap = std::max<int64_t>(1, std::min<int64_t>(n_variants, ((int64_t)256 << 20) / ld4));
@@ -694,7 +987,7 @@ int pcoa_accumulate_dense_u8(pcoa_ctx* c, const uint8_t* x, int64_t n_variants, 
     if (ld4 != c->n) HIP_TRY(c, hipMemsetAsync(stage, 0, (size_t)(rows * ld4), c->stream));
     HIP_TRY(c, hipMemcpy2DAsync(stage, (size_t)ld4, x + v0 * ld, (size_t)ld, (size_t)c->n, (size_t)rows,
                                 hipMemcpyHostToDevice, c->stream));
-    rc = gram_device_u8(c, stage, rows, ld4);
+    rc = gram_device_u8(c, stage, rows, ld4, false);
     if (rc != PCOA_OK) return rc;
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -709,20 +1002,18 @@ int gram_device_bits(pcoa_ctx* c, const uint32_t* bits_dev, int64_t nv, int64_t 
   while (done < nv) {
     const int64_t cur = std::min(nv - done, max_cur);
     const int64_t kb = (cur + 31) / 32;
-    int rc = fp4_reserve(c, kb, cur);  // bitsets are binary by construction: straight into the FP4 operand buffer
+    int8_t* dst = nullptr;
+    hipStream_t ps = nullptr;
+    int rc = fp4_reserve(c, kb, cur, false, false, &dst, &ps, nullptr);  // bitsets are binary by construction
     if (rc != PCOA_OK) return rc;
     {
-      ScopedTimer t(c, T_PACK);
-      hipError_t e = launch_expand_bits_fp4(bits_dev + done * ld_words, ld_words, cur, c->n,
-                                            c->fp4_buf + c->fp4_kb * fp4_kb_bytes(c), c->stream, kb);
+      ScopedTimer t(c, T_PACK, ps);
+      hipError_t e = launch_expand_bits_fp4(bits_dev + done * ld_words, ld_words, cur, c->n, dst, ps, kb);
       if (e != hipSuccess) return hip_fail(c, e, "expand(bits) kernel launch");
     }
     c->pack_launches += 1;
     c->pack_bytes += 4.0 * (double)((c->n + 31) / 32) * (double)cur + (double)(kb * fp4_kb_bytes(c));
-    c->fp4_kb += kb;
-    c->fp4_vars += cur;
-    c->gram_kind = 3;
-    c->dirty = true;
+    fp4_commit(c, kb, cur);
     done += cur;
   }
   return PCOA_OK;
@@ -770,9 +1061,11 @@ int pcoa_accumulate_calls(pcoa_ctx* c, const int32_t* sample_idx, const int64_t*
   // multiplicity (VariantsPca.scala:187), which only the int8 / fp32 kernels can express; lists that are SETS go to the
   // FP4 operand.
   bool any_repeat = false;
+  int32_t mult_max = 1;  // largest multiplicity of a callset inside one carrier list
   {
-    const bool want_repeats = c->use_i8 && c->packed_mode != 2;
+    const bool want_repeats = c->use_i8;
     std::vector<int64_t> last(want_repeats ? (size_t)c->n : 0, (int64_t)-1);
+    std::vector<int32_t> cnt(want_repeats ? (size_t)c->n : 0, 0);
     for (int64_t v = 0; v < n_variants; ++v) {
       for (int64_t p = row_offsets[v]; p < row_offsets[v + 1]; ++p) {
         const int32_t s = sample_idx[p];
@@ -782,8 +1075,13 @@ int pcoa_accumulate_calls(pcoa_ctx* c, const int32_t* sample_idx, const int64_t*
           return fail(c, PCOA_ERR_INDEX_RANGE, buf);
         }
         if (want_repeats) {
-          any_repeat |= (last[(size_t)s] == v);
-          last[(size_t)s] = v;
+          if (last[(size_t)s] == v) {
+            any_repeat = true;
+            mult_max = std::max(mult_max, ++cnt[(size_t)s]);
+          } else {
+            last[(size_t)s] = v;
+            cnt[(size_t)s] = 1;
+          }
         }
       }
     }
@@ -793,7 +1091,10 @@ int pcoa_accumulate_calls(pcoa_ctx* c, const int32_t* sample_idx, const int64_t*
   }
   const bool csr_fp4 = c->use_i8 && c->packed_mode != 2 && !any_repeat;
   const int64_t ld4 = round_up(c->n, 4);
-  const int64_t rows_cap = staging_rows(n_variants, ld4);
+  // one variant adds at most mult_max^2 to an entry of S: int32 launches stay below 2^30 / weight variants
+  const int64_t weight = (int64_t)mult_max * mult_max;
+  int64_t rows_cap = staging_rows(n_variants, ld4);
+  if (c->use_i8 && !csr_fp4) rows_cap = std::max<int64_t>(1, std::min(rows_cap, ((int64_t)1 << 30) / weight));
   int rc = PCOA_OK;
   if (!c->use_i8) {
     rc = ensure(c, &c->tile, &c->tile_elems, rows_cap * ld4);
@@ -815,21 +1116,19 @@ int pcoa_accumulate_calls(pcoa_ctx* c, const int32_t* sample_idx, const int64_t*
     if (csr_fp4) {
       // carrier SETS -> FP4 operand, appended to the operand buffer; the contraction is deferred (fp4_flush)
       const int64_t kb = (rows + 31) / 32;
-      if ((rc = fp4_reserve(c, kb, rows)) != PCOA_OK) return rc;
+      int8_t* dst = nullptr;
+      hipStream_t ps = nullptr;
+      if ((rc = fp4_reserve(c, kb, rows, false, false, &dst, &ps, nullptr)) != PCOA_OK) return rc;
       {
-        ScopedTimer t(c, T_DENSIFY);
-        HIP_TRY(c, launch_densify_csr_fp4(c->csr_idx, c->csr_offs, rows, b, c->fp4_buf + c->fp4_kb * fp4_kb_bytes(c),
-                                          c->n, c->err_flag, c->stream, kb));
+        ScopedTimer t(c, T_DENSIFY, ps);
+        HIP_TRY(c, launch_densify_csr_fp4(c->csr_idx, c->csr_offs, rows, b, dst, c->n, c->err_flag, ps, kb));
       }
-      c->fp4_kb += kb;
-      c->fp4_vars += rows;
-      c->gram_kind = 3;
-      c->dirty = true;
+      fp4_commit(c, kb, rows);
       continue;
     }
     if (c->use_i8) {
       // carriers -> k-blocked int8 operand directly (no fp32 tile, no pre-pass), then the i8 contraction
-      rc = fold_if_needed(c, rows);
+      rc = fold_if_needed(c, rows * weight);
       if (rc != PCOA_OK) return rc;
       rc = ensure(c, &c->pack_buf, &c->pack_cap, (int64_t)gram_packed_workspace_bytes(c->n, rows));
       if (rc != PCOA_OK) return rc;
@@ -843,7 +1142,7 @@ int pcoa_accumulate_calls(pcoa_ctx* c, const int32_t* sample_idx, const int64_t*
         HIP_TRY(c, launch_gram_i8_packed(c->pack_buf, rows, c->n, c->s32, c->num_cu, c->stream, nullptr));
       }
       c->gram_kind = 2;  // a carrier list repeats a callset (or int8 was forced)
-      account_gram(c, rows);
+      account_gram(c, rows, weight);
       continue;
     }
     {
@@ -852,7 +1151,7 @@ int pcoa_accumulate_calls(pcoa_ctx* c, const int32_t* sample_idx, const int64_t*
       HIP_TRY(c, launch_densify_csr(c->csr_idx, c->csr_offs, 0, rows, b, c->tile, ld4, c->n, c->err_flag,
                                     c->stream));
     }
-    rc = gram_device(c, c->tile, rows, ld4);
+    rc = gram_device(c, c->tile, rows, ld4, false);
     if (rc != PCOA_OK) return rc;
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // host arrays may be released by the caller now
@@ -896,7 +1195,7 @@ int pcoa_accumulate_synthetic(pcoa_ctx* c, const pcoa_synth_params* p, int64_t f
       HIP_TRY(c, launch_synth_fill_f32(q.seed, c->thr_dev, c->sample_pop, q.n_pops, first_variant + v0, rows, c->n,
                                        c->tile, ld4, c->stream));
     }
-    rc = gram_device(c, c->tile, rows, ld4);
+    rc = gram_device(c, c->tile, rows, ld4, false);
     if (rc != PCOA_OK) return rc;
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -915,6 +1214,7 @@ int pcoa_gram_export_device_i64(pcoa_ctx* c, int64_t* dst_dev) {
   if (!dst_dev) return fail(c, PCOA_ERR_INVALID_ARG, "dst_dev is NULL");
   int rc = finalize_impl(c);
   if (rc != PCOA_OK) return rc;
+  if ((rc = check_device_flags(c)) != PCOA_OK) return rc;  // never hand out an S that an input check has invalidated
   HIP_TRY(c, launch_export_i64(c->s32, c->s64, dst_dev, (int64_t)c->n * c->n, c->stream));
   return PCOA_OK;
 }
@@ -923,12 +1223,12 @@ int pcoa_gram_import_device_i64(pcoa_ctx* c, const int64_t* src_dev) {
   CHECK_CTX(c);
   if (!src_dev) return fail(c, PCOA_ERR_INVALID_ARG, "src_dev is NULL");
   const size_t nn = (size_t)c->n * (size_t)c->n;
+  int rc = fp4_discard(c);  // S is replaced: what was buffered or in flight for the old S goes with it
+  if (rc != PCOA_OK) return rc;
   if (!c->s64) HIP_TRY(c, hipMalloc((void**)&c->s64, sizeof(int64_t) * nn));
   HIP_TRY(c, hipMemcpyAsync(c->s64, src_dev, sizeof(int64_t) * nn, hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(c, hipMemsetAsync(c->s32, 0, sizeof(int32_t) * nn, c->stream));
   c->variants_in_s32 = 0;
-  c->fp4_kb = 0;  // S is replaced: what was buffered for the old S goes with it
-  c->fp4_vars = 0;
   c->dirty = false;
   return PCOA_OK;
 }
@@ -1047,6 +1347,7 @@ int pcoa_center_read_f64(pcoa_ctx* c, double* out_b, double* out_row_sums, int32
   CHECK_CTX(c);
   int rc = finalize_impl(c);
   if (rc != PCOA_OK) return rc;
+  if ((rc = check_device_flags(c)) != PCOA_OK) return rc;
   rc = ensure_workspace(c, 1);
   if (rc != PCOA_OK) return rc;
   if (out_b && (rc = ensure_b(c)) != PCOA_OK) return rc;
@@ -1086,7 +1387,15 @@ int pcoa_compute(pcoa_ctx* c, int32_t num_pc, double* out_components, double* ou
   rc = ensure_workspace(c, num_pc);
   if (rc != PCOA_OK) return rc;
 
-  hipEvent_t w0 = get_event(c), w1 = get_event(c);
+  struct WallEvents {  // back to the pool on every path out of this function
+    pcoa_ctx* c;
+    hipEvent_t w0, w1;
+    ~WallEvents() {
+      if (w0) c->pool.push_back(w0);
+      if (w1) c->pool.push_back(w1);
+    }
+  } wall{c, get_event(c), get_event(c)};
+  hipEvent_t w0 = wall.w0, w1 = wall.w1;
   if (w0) (void)hipEventRecord(w0, c->stream);
 
   const bool force_householder = (c->flags & PCOA_FLAG_EIG_HOUSEHOLDER) != 0;
@@ -1094,8 +1403,7 @@ int pcoa_compute(pcoa_ctx* c, int32_t num_pc, double* out_components, double* ou
   const bool try_lanczos = !force_householder && n >= 32;
   // The Lanczos path evaluates B on the fly inside its matvec (bit-identical entries, half the bytes, no N x N fp64
   // matrix); B is only materialised for the dense solver.  PCOA_EXPLICIT_CENTER=1 restores the materialised form.
-  static const bool explicit_env = std::getenv("PCOA_EXPLICIT_CENTER") != nullptr;
-  const bool explicit_b = !try_lanczos || explicit_env;
+  const bool explicit_b = !try_lanczos || debug_knobs().explicit_center != 0;
   if (explicit_b && (rc = ensure_b(c)) != PCOA_OK) return rc;
   {
     ScopedTimer t(c, T_CENTER);
@@ -1195,8 +1503,6 @@ int pcoa_compute(pcoa_ctx* c, int32_t num_pc, double* out_components, double* ou
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, w0, w1) == hipSuccess) c->compute_total = (double)ms * 1e-3;
   }
-  if (w0) c->pool.push_back(w0);
-  if (w1) c->pool.push_back(w1);
   for (int32_t t = 0; t < num_pc; ++t) {
     for (int32_t i = 0; i < n; ++i)
       if (!std::isfinite(out_components[(size_t)t * n + i]))
@@ -1211,6 +1517,8 @@ int pcoa_compute(pcoa_ctx* c, int32_t num_pc, double* out_components, double* ou
 int pcoa_get_timings(pcoa_ctx* c, pcoa_timings* out) {
   CHECK_CTX(c);
   if (!out) return fail(c, PCOA_ERR_INVALID_ARG, "out is NULL");
+  int rc0 = fp4_sync_point(c);
+  if (rc0 != PCOA_OK) return rc0;
   drain_events(c, true);
   std::memset(out, 0, sizeof(*out));
   out->gram_kernel_seconds = c->tsec[T_GRAM];
@@ -1239,6 +1547,8 @@ int pcoa_get_timings(pcoa_ctx* c, pcoa_timings* out) {
 
 int pcoa_reset_timings(pcoa_ctx* c) {
   CHECK_CTX(c);
+  int rc0 = fp4_sync_point(c);
+  if (rc0 != PCOA_OK) return rc0;
   drain_events(c, true);
   for (double& t : c->tsec) t = 0;
   c->gram_launches = 0;

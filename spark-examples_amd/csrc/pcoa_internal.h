@@ -16,6 +16,24 @@ namespace pcoa {
 constexpr int kWave = 64;     // CDNA wavefront
 constexpr int kNumXcd = 8;    // MI355X: block b is dispatched to XCD b % 8 (speed only, never correctness)
 
+// ---- debug / experiment knobs -------------------------------------------------------------------
+// Every environment variable the library looks at, read ONCE (first use) into this struct; nothing else calls getenv.
+// None is needed for normal use; DESIGN.md "Environment hooks" documents them.
+struct DebugKnobs {
+  int gram_kernel = -1;            // PCOA_GRAM_KERNEL = auto | fp4 | i8 | f32  -> 0 | 3 | 2 | 1 (overrides the create flags)
+  int64_t pack_chunk = 0;          // PCOA_DEBUG_PACK_CHUNK: variants per pre-pass launch (tests: multi-chunk paths)
+  int64_t max_launch = 0;          // PCOA_DEBUG_MAX_LAUNCH: variants per contraction launch (tests: multi-launch paths)
+  int64_t fold_threshold = 0;      // PCOA_DEBUG_FOLD_THRESHOLD: int32 -> int64 fold (tests: the fold / int64 all-reduce)
+  int pipeline = -1;               // PCOA_PIPELINE = 0 | 1: force the two-stream fp32 pipeline off / on where it fits
+  int explicit_center = 0;         // PCOA_EXPLICIT_CENTER: materialise B for the Lanczos path
+  int lanczos_first_check = 0;     // PCOA_LANCZOS_FIRST_CHECK: Krylov dimension of the first Ritz check
+  int lanczos_trace = 0;           // PCOA_DEBUG_LANCZOS: print the Ritz estimates
+  int gram_cfg = 0;                // PCOA_GRAM_I8_CFG: contraction schedule (library built with -DPCOA_EXPERIMENTS only)
+  int gram_splitk = 0;             // PCOA_GRAM_I8_SPLITK: split-K of the legacy launch
+  int lockstep = -1;               // PCOA_GRAM_LOCKSTEP = 0 | 1: lock-step contraction launch off / on where it fits
+};
+const DebugKnobs& debug_knobs();
+
 // ---- Gram kernels (gram_f32.hip / gram_packed.hip) ------------------------------------------------
 struct GramLaunch {
   const float* x;        // device, [nv][ld] carrier multiplicities (0/1)
@@ -23,6 +41,7 @@ struct GramLaunch {
   int64_t nv;            // variants in this launch (<= 2^24 so fp32 accumulators stay exact)
   int32_t n;             // samples
   int32_t* s32;          // device, [n][n] int32 partial (upper-triangular tiles only)
+  int32_t* flag;         // device: bit 4 is raised when an fp32 accumulator leaves the exact range (|sum| >= 2^24)
   const float* zeros;    // device, >= 4 KiB of zeros (source for out-of-range rows)
   int num_cu;
   hipStream_t stream;
@@ -34,6 +53,8 @@ hipError_t launch_gram_f32(const GramLaunch& g, int* splitk_out);
 int64_t gram_packed_npad(int32_t n);
 int64_t gram_packed_kb_pad_i8(int64_t nv);
 size_t gram_packed_workspace_bytes(int32_t n, int64_t nv);
+// flag[0]: bit 2 = a value that is not an integer in [0, 127]; flag[1] = max value seen (atomicMax): the carrier
+// multiplicity bound the host sizes its int32 launches and folds by
 hipError_t launch_pack_f32_i8(const float* x, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
                               hipStream_t stream);
 hipError_t launch_pack_u8_i8(const uint8_t* x, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
@@ -51,10 +72,16 @@ hipError_t launch_pack_fp4(const void* x, int is_u8, int64_t ld, int64_t nv, int
 bool pack_fp4_ring_ok(const void* x, int64_t ld);
 hipError_t launch_pack_fp4_ring(const float* x, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
                                 hipStream_t stream, int64_t nkb_out, int wgs, int nt);
+// skip (optional, device): the launch does nothing when *skip != 0 -- the auto mode's device-side predicate (a pre-pass
+// found a value other than 0 / 1 in the buffered tiles; the host learns it later and redoes them on the int8 kernel)
 hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, int32_t* s32, int num_cu,
-                              hipStream_t stream, int* splitk_out);
+                              hipStream_t stream, int* splitk_out, const int32_t* skip = nullptr);
+// Lock-step launch: all tiles of `splitk` k-streams resident at once, one workgroup per CU for the whole launch.
+// gram_lockstep_splitk: the k-stream count that fits `cus` CUs (8 XCDs), 0 if the shape does not fit.
+int gram_lockstep_splitk(int32_t n, int cus);
+int gram_lockstep_workgroups(int32_t n, int splitk);
 hipError_t launch_gram_packed_lockstep(const int8_t* p, int fmt, int64_t nv, int32_t n, int32_t* s32, int num_cu,
-                                       hipStream_t stream);
+                                       hipStream_t stream, const int32_t* skip = nullptr);
 hipError_t launch_gram_i8_packed(const int8_t* p, int64_t nv, int32_t n, int32_t* s32, int num_cu,
                                  hipStream_t stream, int* splitk_out);
 

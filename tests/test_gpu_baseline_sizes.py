@@ -258,10 +258,91 @@ def test_jni_shim_replay_matches_the_reference_goldens(O, name, batch, tmp_path)
     s = np.fromfile(prefix + ".s", dtype="<i8").reshape(n, n)
     assert np.array_equal(s, g["similarity"])
     ref = O.compute_pca(g["similarity"], 2)
-    assert res.stdout.split() == ["nonzero", str(ref["nonzero_rows"])]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("nonzero ")]   # (RCCL prints a version banner to stdout)
+    assert lines == ["nonzero %d" % ref["nonzero_rows"]]
     comps = np.fromfile(prefix + ".pc", dtype="<f8").reshape(2, n).T      # column-major N x 2 == pca.toArray
     lam = np.fromfile(prefix + ".lam", dtype="<f8")
     assert np.max(np.abs(lam - ref["eigenvalues"]) / np.abs(ref["eigenvalues"])) < EIG_TOL
     got = align_sign(comps, ref["components"])
     for c in range(2):
         assert np.linalg.norm(got[:, c] - ref["components"][:, c]) < EIG_TOL
+
+
+# ------------------------------------------------------------------------------------------ fp32 pipeline / deferred checks
+_PIPE_CODE = r'''
+import json, os, sys
+import numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import torch
+from conftest import load_pkg, load_oracle
+P = load_pkg(); O = load_oracle(); synth = load_pkg("synth")
+n, v, seed = 2504, 300000, 1002
+offs = synth.pop_offsets(n)
+x = torch.empty((v, n), dtype=torch.float32, device="cuda")
+out = {}
+with P.PcoaEngine(n) as eng:
+    for v0 in range(0, v, 1 << 17):
+        v1 = min(v, v0 + (1 << 17))
+        eng.synth_fill(seed, offs, synth.thresholds(seed, v0, v1 - v0), v0, x[v0:v1].data_ptr(), n)
+    eng.sync()
+    # (1) binary cohort, device pointers: three passes over the resident tile, many buffer generations
+    eng.reset_timings()
+    for _ in range(3):
+        eng.accumulate_dense(x)
+    eng.accumulate_dense(x[:77777])
+    s = eng.gram()
+    t = eng.timings()
+    out["launches"] = int(t["gram_kernel_launches"]); out["fallbacks"] = int(t["fp4_fallbacks"])
+    out["kind"] = int(t["gram_kernel_kind"]); out["variants"] = int(t["gram_variants"])
+    want = O.similarity_from_dense_blas(x.cpu().numpy())
+    want = 3 * want + O.similarity_from_dense_blas(x[:77777].cpu().numpy())
+    out["binary_exact"] = bool(np.array_equal(s, want))
+    # (2) a multiplicity deep inside one generation of a device tile: the device-side predicate skips that
+    #     generation's contraction, the host redoes its chunks on the int8 kernel -- no error, exact S
+    eng.reset(); eng.reset_timings()
+    y = x.clone()
+    y[200123, 17] = 3.0
+    y[200124, 2503] = 2.0
+    eng.accumulate_dense(y)
+    eng.accumulate_dense(x[:50000])
+    s2 = eng.gram()
+    t2 = eng.timings()
+    yh = y.cpu().numpy()
+    want2 = (O.similarity_from_dense_blas(np.minimum(yh, 1.0)) + O.similarity_from_dense_blas(x[:50000].cpu().numpy()))
+    # entries touched by the two multiplicities: add the exact difference (rows 200123 / 200124 only)
+    for r in (200123, 200124):
+        a = yh[r].astype(np.int64); b = np.minimum(a, 1)
+        want2 += np.outer(a, a) - np.outer(b, b)
+    out["mult_exact"] = bool(np.array_equal(s2, want2))
+    out["mult_fallbacks"] = int(t2["fp4_fallbacks"]); out["mult_variants"] = int(t2["gram_variants"])
+    # (3) the tile is released right after a synchronising call: nothing may still need it
+    eng.reset()
+    z = x[:150000].clone()
+    eng.accumulate_dense(z)
+    eng.sync()
+    z.fill_(7.0); del z
+    torch.cuda.synchronize()
+    out["released_exact"] = bool(np.array_equal(eng.gram(), O.similarity_from_dense_blas(x[:150000].cpu().numpy())))
+print(json.dumps(out))
+'''
+
+
+@pytest.mark.parametrize("env", [{}, {"PCOA_PIPELINE": "0"}, {"PCOA_PIPELINE": "0", "PCOA_GRAM_LOCKSTEP": "0"}])
+def test_fp32_pipeline_and_deferred_verification_on_device_tiles(env):
+    """The default path for fp32 device tiles at N = 2504: operand buffers of `max_launch` variants alternate, the
+    pre-pass of one runs on CUs 0-15 of every XCD beside the lock-step contraction of the other on CUs 16-31, and the
+    auto mode's binary check is a device-side predicate (no host sync per call).  Forced small buffers
+    (PCOA_DEBUG_MAX_LAUNCH) so that 977,777 variants are ~8 generations.  Same job with the pipeline off and with the
+    legacy contraction launch: identical S."""
+    import json
+    full_env = dict(os.environ, PCOA_DEBUG_MAX_LAUNCH="131072", **env)
+    code = _PIPE_CODE % {"root": ROOT, "tests": os.path.join(ROOT, "tests")}
+    res = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         universal_newlines=True, env=full_env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads(res.stdout.strip().splitlines()[-1])
+    assert out["binary_exact"] and out["kind"] == 3 and out["fallbacks"] == 0
+    assert out["variants"] == 3 * 300000 + 77777 and out["launches"] >= 7
+    assert out["mult_exact"], out
+    assert out["mult_fallbacks"] >= 1 and out["mult_variants"] == 350000
+    assert out["released_exact"]

@@ -19,6 +19,14 @@
 
 #include "../spark-examples_amd/csrc/gram_packed.hip"
 
+// the library reads its environment knobs through this accessor (pcoa_capi.hip); the harness has none
+namespace pcoa {
+const DebugKnobs& debug_knobs() {
+  static const DebugKnobs k;
+  return k;
+}
+}  // namespace pcoa
+
 using namespace pcoa;
 
 #define CK(expr)                                                                                  \
