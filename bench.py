@@ -2,14 +2,16 @@
 """bench.py -- BASELINE.json's metric on BASELINE.json's config, on N GPUs of one node.
 
 Workload (config.workload): BASELINE configs[1] per GPU -- synthetic 2,504 samples x 1,000,000 variants
-fp32 (10.0 GB), resident in HBM before the timed region (weak scaling: every rank holds its own 1M-variant
-shard of one 1M*N_gpus-variant cohort; the generator is counter-based, so the cohort does not depend on N).
+fp32 (10.0 GB) per step, resident in HBM before the timed region.  Weak scaling (default): every rank holds
+min(K, 5) DISTINCT 1M-variant batches of its own shard (up to 5M variants = 50 GB per GPU: BASELINE configs[2]'s
+shape, 40M variants at 8 GPUs; the generator is counter-based, so the cohort does not depend on N); step i takes
+batch i mod 5.  --scaling strong: a FIXED cohort (--cohort, default 8M variants) is sharded over the ranks with
+dist.shard_range and the K steps are one pass over the rank's resident shard.
 
-One step = one pass of the hot path over the resident batch: the Gram accumulation of 10^6 variants per GPU
-(re-layout pre-pass + matrix-core contraction: MX-FP4 for binary tiles, int8 for multiplicities; exact).  The job = K steps, then ONE finalize (mirror) and, for N > 1, ONE RCCL
-all-reduce of S -- the reference reduces once per job too (reduceByKey after all partitions, VariantsPca.scala:190),
-and with --steps 5 this is exactly BASELINE configs[2]'s shape (5M variants per GPU, 40M at 8 GPUs).  The
-finalize/all-reduce is INSIDE the timed region.
+One step = one pass of the hot path over one resident batch: the Gram accumulation of its variants
+(re-layout pre-pass + matrix-core contraction: MX-FP4 for binary tiles, int8 for multiplicities; exact).  The job =
+K steps, then ONE finalize (mirror) and, for N > 1, ONE RCCL all-reduce of S -- the reference reduces once per job too
+(reduceByKey after all partitions, VariantsPca.scala:190).  The finalize/all-reduce is INSIDE the timed region.
 value = variants of ALL ranks over the K steps / max-over-ranks wall time of the timed region.
 The PCoA wall-clock (centring + eigensolve + D2H of N x 2, rank 0) is reported in `pcoa_wall_ms`.
 
@@ -75,7 +77,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--variants", type=int, default=1000000, help="variants per GPU (default = BASELINE configs[1])")
+    ap.add_argument("--variants", type=int, default=1000000, help="variants per step and GPU (default = BASELINE configs[1])")
+    ap.add_argument("--distinct-batches", type=int, default=5,
+                    help="weak scaling: distinct resident batches per GPU (5 x 1M variants = configs[2]'s 5M per GPU)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--cohort", type=int, default=8000000, help="--scaling strong: variants of the fixed cohort")
     ap.add_argument("--samples", type=int, default=N_SAMPLES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pcoa-reps", type=int, default=3)
@@ -112,12 +118,23 @@ def main():
     dev_name, cus = eng.device_info()
 
     # ---- resident input: this rank's shard of the cohort, generated on device --------------------------
-    first = rank * v
     offs = synth.pop_offsets(n)
-    x = torch.empty((v, n), dtype=torch.float32, device=dev)
+    steps_n = max(args.steps, 1)
+    if args.scaling == "strong":
+        s0, s1 = dist.shard_range(rank, world, args.cohort)      # the reference's partitioning (VariantsPca.scala:184)
+        first, resident = s0, s1 - s0
+        cuts = [resident * i // steps_n for i in range(steps_n + 1)]
+        batch_of = lambda i: (cuts[i % steps_n], cuts[i % steps_n + 1])   # noqa: E731
+        variants_per_job = args.cohort                             # fixed total work
+    else:
+        nb = max(1, min(args.distinct_batches, steps_n))
+        first, resident = rank * nb * v, nb * v
+        batch_of = lambda i: ((i % nb) * v, (i % nb) * v + v)      # noqa: E731
+        variants_per_job = world * v * steps_n
+    x = torch.empty((resident, n), dtype=torch.float32, device=dev)
     step_rows = 1 << 18
-    for v0 in range(0, v, step_rows):
-        v1 = min(v, v0 + step_rows)
+    for v0 in range(0, resident, step_rows):
+        v1 = min(resident, v0 + step_rows)
         eng.synth_fill(SEED, offs, synth.thresholds(SEED, first + v0, v1 - v0), first + v0, x[v0:v1].data_ptr(), n)
     eng.sync()
 
@@ -142,8 +159,9 @@ def main():
                 native = None
                 allreduce_mode = "torch"
 
-    def one_step():
-        eng.accumulate_dense(x)
+    def one_step(i=0):
+        a, b = batch_of(i)
+        eng.accumulate_dense(x[a:b])
 
     def finish_job():
         nonlocal scratch
@@ -190,8 +208,8 @@ def main():
     eng.reset_timings()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
+    for i in range(args.steps):
+        one_step(i)
     finish_job()
     fence()
     elapsed = time.perf_counter() - t0
@@ -205,23 +223,36 @@ def main():
     if rank == 0:
         steps = max(args.steps, 1)
         ms_per_step = 1e3 * elapsed / steps
-        value = world * v * steps / elapsed
+        value = variants_per_job / elapsed
         launches = max(int(tim["gram_kernel_launches"]), 1)
+        info = {"pipeline": bool(tim["pipeline_launches"] > 0), "lockstep": bool(tim["lockstep_launches"] > 0),
+                "pipeline_launches": int(tim["pipeline_launches"]), "lockstep_launches": int(tim["lockstep_launches"]),
+                "pipeline_pre_pass_cus": int(tim["pipeline_pre_pass_cus"]),
+                "pipeline_contraction_cus": int(tim["pipeline_contraction_cus"]),
+                "what": "fp32 tiles at this N: the pre-pass of operand buffer k+1 runs on a CU-masked stream beside the lock-step "
+                        "contraction of buffer k on the complementary CUs (DESIGN.md 4.1); PCOA_PIPELINE=0 disables it"}
         kern_s = tim["gram_kernel_seconds"] / launches           # average Gram-kernel launch duration (HIP events)
-        flops_per_launch = 2.0 * (tim["gram_variants"] / launches) * n * n   # algorithmic 2*V*N^2
+        vpl = tim["gram_variants"] / launches                    # variants per contraction launch
+        flops_per_launch = 2.0 * vpl * n * n                     # algorithmic 2*V*N^2
         achieved = flops_per_launch / kern_s / 1e12 if kern_s > 0 else 0.0
-        pmc = {}
+        pmc, pmc_src = {}, None
         pmc_path = os.path.join(ROOT, "profiles", "gram_pmc_latest.json")
         if os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path)).get({1: "f32", 2: "i8", 3: "fp4"}[tim["gram_kernel_kind"]], {})
+                pmc_src = "profiles/gram_pmc_latest.json (static: rocprofv3 --pmc passes of an earlier run of this command, " \
+                          "scaled to this run's launch size; NOT measured in this run)"
             except Exception:
                 pmc = {}
         kind = tim["gram_kernel_kind"]          # what actually ran: 1 fp32, 2 int8, 3 MX-FP4
+        pipe = bool(info.get("pipeline"))
+        gram_cus = info.get("pipeline_contraction_cus", cus) if pipe else cus
         if kind == 3:
-            tile, peak, kname = 256, PEAK_FP4_MFMA_TFLOPS, "gram_packed_kernel<1, 2, 2, 4, 3, true, 2> (FMT 1 = MX-FP4, ping-pong)"
+            tile, peak = 256, PEAK_FP4_MFMA_TFLOPS
+            kname = "gram_packed_kernel<1, 2, 2, 4, 3, true, 2> (FMT 1 = MX-FP4, ping-pong; %s launch)" % (
+                "lock-step" if info.get("lockstep") or pipe else "split-K")
             kdesc = ("pack fp32->k-blocked FP4 E2M1 (HBM-bound, verifies values are 0/1) + MX-FP4 MFMA "
-                     "v_mfma_f32_32x32x64_f8f6f4 (unscaled form, exact), upper-triangular 256x256 tiles, split-K, "
+                     "v_mfma_f32_32x32x64_f8f6f4 (unscaled form, exact), upper-triangular 256x256 tiles, "
                      "fp32 accumulators (< 2^24 per launch) -> int32 atomics")
         elif kind == 2:
             tile, peak, kname = 256, PEAK_I8_MFMA_TOPS, "gram_packed_kernel<0, 2, 2, 4, 3, true, 2> (FMT 0 = int8, ping-pong)"
@@ -229,39 +260,51 @@ def main():
         else:
             tile, peak, kname = 128, PEAK_FP32_MFMA_TFLOPS, "gram_f32_kernel"
             kdesc = "fp32 MFMA v_mfma_f32_32x32x2_f32, upper-triangular 128x128 tiles, split-K"
-        frac_syrk = syrk_fraction(n, tile)
-        roof_gram = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                     "frac": achieved / peak,
-                     # PMC traffic is stored per 10^6 variants (launch sizes differ: the FP4 contraction runs once per
-                     # <= 2^22 buffered variants) and scaled to this run's average launch, like `achieved`
-                     "traffic": (pmc["gram_hbm_bytes_per_mvariants"] * (tim["gram_variants"] / launches) / 1e6
+        frac_issued = issued_fraction(n, tile, idle_diag=(kind != 1 or True))
+        issued = achieved * frac_issued
+        roof_gram = {"bound": "mfma", "achieved": issued, "peak": peak, "unit": "TFLOP/s", "frac": issued / peak,
+                     "convention": "ISSUED matrix-core work: only upper-triangular tiles are computed and the below-diagonal "
+                                   "waves of diagonal tiles issue nothing (%.3f of the 2*V*N^2 of SURVEY 8d)" % frac_issued,
+                     "algorithmic_tflops": achieved, "algorithmic_frac": achieved / peak,
+                     "algorithmic_note": "2*V*N^2 per launch / launch duration (both triangles credited: can exceed 1)",
+                     "cus_used": gram_cus, "frac_of_cus_used": issued / (peak * gram_cus / float(cus)),
+                     # PMC traffic is stored per 10^6 variants and scaled to this run's average launch, like `achieved`
+                     "traffic": (pmc["gram_hbm_bytes_per_mvariants"] * vpl / 1e6
                                  if "gram_hbm_bytes_per_mvariants" in pmc else pmc.get("gram_hbm_bytes_per_launch")),
-                     "variants_per_launch": tim["gram_variants"] / launches,
-                     "kernel": kname, "avg_launch_ms": 1e3 * kern_s, "launches": launches,
-                     "flops_convention": "algorithmic 2*V*N^2 per launch (integer MACs count 2 ops); the kernel "
-                                         "issues the SYRK half (upper-triangular tiles only: %.3f of the MFMA work)"
-                                         % frac_syrk,
-                     "issued_tflops": achieved * frac_syrk, "issued_frac": achieved * frac_syrk / peak,
-                     "frac_note": "frac follows the algorithmic convention (both triangles of S credited) and can exceed 1; "
-                                  "issued_frac is the share of the matrix-core peak the kernel actually issues"}
+                     "traffic_source": pmc_src, "variants_per_launch": vpl,
+                     "kernel": kname, "avg_launch_ms": 1e3 * kern_s, "launches": launches}
         roof_pack = None
         if kind != 1 and tim["pack_launches"] > 0:
             pl = int(tim["pack_launches"])
             pack_s = tim["pack_seconds"] / pl
-            pack_gbs = tim["pack_bytes"] / pl / pack_s / 1e9 if pack_s > 0 else 0.0
-            roof_pack = {"bound": "hbm", "achieved": pack_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": pack_gbs / PEAK_HBM_GBS,
+            read_bytes = 4.0 * (tim["gram_variants"] / pl) * n               # X read once, 4*V*N
+            read_gbs = read_bytes / pack_s / 1e9 if pack_s > 0 else 0.0
+            all_gbs = tim["pack_bytes"] / pl / pack_s / 1e9 if pack_s > 0 else 0.0
+            pack_cus = info.get("pipeline_pre_pass_cus", cus) if pipe else cus
+            roof_pack = {"bound": "hbm", "achieved": read_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": read_gbs / PEAK_HBM_GBS,
+                         "bytes_convention": "SURVEY 8(d): 4*V*N bytes of X read once per launch",
+                         "achieved_incl_operand_writes": all_gbs, "frac_incl_operand_writes": all_gbs / PEAK_HBM_GBS,
+                         "incl_note": "also credits the V*Npad%s bytes of packed operand the pre-pass writes" % ("/2" if kind == 3 else ""),
+                         "cus_used": pack_cus,
                          "traffic": (pmc["pack_hbm_bytes_per_mvariants"] * (tim["gram_variants"] / pl) / 1e6
                                      if "pack_hbm_bytes_per_mvariants" in pmc else pmc.get("pack_hbm_bytes_per_launch")),
+                         "traffic_source": pmc_src,
                          "kernel": "pack_fp4_kernel<float, 4, true>" if kind == 3 else "pack_f32_i8_kernel<4>",
-                         "avg_launch_ms": 1e3 * pack_s, "launches": pl,
-                         "bytes_convention": "algorithmic 4*V*N read + V*Npad%s written per launch"
-                                             % ("/2" if kind == 3 else "")}
+                         "avg_launch_ms": 1e3 * pack_s, "launches": pl}
+            if pipe:
+                roof_pack["note"] = ("fp32 pipeline: this kernel runs on %d of the %d CUs (CU-masked stream) BESIDE the "
+                                     "contraction on the other %d, so its launch duration ~ the step; alone on the whole chip "
+                                     "it takes ~2.0 ms per 10^6 variants (profiles/r02*_overlap_harness.txt)"
+                                     % (pack_cus, cus, gram_cus))
         # the dominant kernel (larger share of the step) goes into `roofline`, the other into `roofline_other`
         if roof_pack is not None and tim["pack_seconds"] > tim["gram_kernel_seconds"]:
             roofline, roofline_other = roof_pack, roof_gram
         else:
             roofline, roofline_other = roof_gram, roof_pack
+        # whole step against the HBM roofline: SURVEY 8(d) algorithmic bytes (4*N per variant + 4*N^2 of S per job)
+        step_bytes = 4.0 * n * (variants_per_job / world) / steps + 4.0 * n * n / steps
+        step_hbm_frac = step_bytes / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS
         # PCoA wall-clock on rank 0 (S of the last step is in place)
         pcoa = []
         for _ in range(max(args.pcoa_reps, 1)):
@@ -282,15 +325,25 @@ def main():
             np.linalg.norm(comps[:, c] - comps_hh[:, c] * np.sign(np.dot(comps[:, c], comps_hh[:, c]))) for c in range(2)))
         out = {
             "metric": METRIC, "value": value, "unit": "variants/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": {1: "f32", 2: "i8->i32", 3: "fp4(e2m1)->f32->i32"}[kind], "data": "synthetic",
-            "config": {"workload": "configs[1]: synthetic %d samples x %d variants fp32 per GPU, resident in HBM "
-                                   "(Gram + eig on rank 0)" % (n, v),
-                       "n_samples": n, "variants_per_gpu": v, "seed": SEED, "parallelism": "variant-sharded x%d" % world,
+            "config": {"workload": ("configs[1]: synthetic %d samples x %d variants fp32 per step and GPU, resident in HBM "
+                                    "(Gram + eig on rank 0); %s" % (
+                                        n, v, ("weak scaling, %d distinct resident batches per GPU (configs[2]: 5M variants per "
+                                               "GPU), step i takes batch i mod %d" % (resident // v, resident // v))
+                                        if args.scaling == "weak" else
+                                        "STRONG scaling: fixed cohort of %d variants sharded over %d ranks, K steps = one pass"
+                                        % (args.cohort, world))),
+                       "n_samples": n, "variants_per_step_per_gpu": v if args.scaling == "weak" else resident // steps,
+                       "resident_variants_per_gpu": resident, "seed": SEED,
+                       "parallelism": "variant-sharded x%d" % world,
                        "allreduce": allreduce_mode,
                        "gram_kernel": kdesc, "gram_kernel_mode": args.gram_kernel,
                        "fp4_fallback_chunks": int(tim["fp4_fallbacks"])},
             "roofline": roofline, "roofline_other": roofline_other,
+            "step_hbm_frac": step_hbm_frac,
+            "step_hbm_note": "SURVEY 8(d) algorithmic bytes of a step (4*N per variant, X read once) / ms_per_step / 8 TB/s",
+            "pipeline": info,
             "gram_ms_per_step": 1e3 * tim["gram_kernel_seconds"] / steps,
             "pack_ms_per_step": 1e3 * tim["pack_seconds"] / steps,
             "finalize_ms_per_step": 1e3 * tim["finalize_seconds"] / steps,
@@ -308,9 +361,29 @@ def main():
             "eigenvalues": [float(t) for t in lam], "nonzero_rows": int(nz),
             "device": dev_name, "cu_count": cus,
         }
+        if not args.no_extras:
+            # north_star's literal kernel: the fp32-MFMA Gram (v_mfma_f32_32x32x2_f32) on a slice of the same batch, so that
+            # the record carries its roofline fraction too ("at >= 40 % fp32-MFMA roofline")
+            vf = int(min(131072, resident))
+            with P.PcoaEngine(n, device=local_rank, gram_kernel="f32") as ef:
+                ef.accumulate_dense(x[:vf]); ef.finalize(); ef.sync()
+                ef.reset(); ef.reset_timings()
+                ef.accumulate_dense(x[:vf]); ef.finalize(); ef.sync()
+                tf = ef.timings()
+            f32_s = tf["gram_kernel_seconds"] / max(int(tf["gram_kernel_launches"]), 1)
+            f32_alg = 2.0 * vf * n * n / f32_s / 1e12 if f32_s > 0 else 0.0
+            f32_iss = f32_alg * issued_fraction(n, 128)
+            out["roofline_f32_mfma"] = {
+                "bound": "mfma", "achieved": f32_iss, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": f32_iss / PEAK_FP32_MFMA_TFLOPS, "convention": "issued (upper-triangular 128x128 tiles)",
+                "algorithmic_tflops": f32_alg, "algorithmic_frac": f32_alg / PEAK_FP32_MFMA_TFLOPS,
+                "variants_per_s": vf / f32_s if f32_s > 0 else 0.0, "variants": vf, "kernel": "gram_f32_kernel<4>",
+                "avg_launch_ms": 1e3 * f32_s,
+                "note": "gram_kernel=f32 (PCOA_FLAG_GRAM_F32_MFMA) on the first %d variants of the batch; not the default path" % vf}
         if world == 1 and not args.no_extras:
             # the production input format (one byte per genotype): same contraction, 4x cheaper pre-pass
-            x8 = x.to(torch.uint8)
+            x1 = x[:min(v, resident)]          # the extras below work on the first resident batch
+            x8 = x1.to(torch.uint8)
             torch.cuda.synchronize(dev)
             eng.reset()
             for _ in range(2):
@@ -331,10 +404,10 @@ def main():
             del x8
             # the bit-packed boundary (1 bit per genotype, 313 B per variant): expand to FP4 + the same contraction
             words = (n + 31) // 32
-            bits = torch.empty((v, words), dtype=torch.int32, device=dev)
+            bits = torch.empty((x1.shape[0], words), dtype=torch.int32, device=dev)
             wts = (1 << torch.arange(32, device=dev, dtype=torch.int64))
-            for r0 in range(0, v, 1 << 16):
-                xb = torch.nn.functional.pad(x[r0:r0 + (1 << 16)] > 0, (0, words * 32 - n))
+            for r0 in range(0, x1.shape[0], 1 << 16):
+                xb = torch.nn.functional.pad(x1[r0:r0 + (1 << 16)] > 0, (0, words * 32 - n))
                 val = (xb.view(-1, words, 32).to(torch.int64) * wts).sum(dim=2)
                 bits[r0:r0 + val.shape[0]] = torch.where(val >= 2 ** 31, val - 2 ** 32, val).to(torch.int32)
             del xb, val
@@ -402,7 +475,7 @@ def main():
                 "eigenvalues": [float(t) for t in l1], "cpu_local4": cpu_c0}
         if world == 1 and not args.no_extras:
             # PCIe-inclusive rates (host tiles through the staging path): noted, never `value`
-            hv = min(v, 131072)
+            hv = min(v, resident, 131072)
             xh = x[:hv].cpu().numpy()
             xh8 = xh.astype(np.uint8)
             pcie = {}
@@ -418,7 +491,7 @@ def main():
             out["pcie_inclusive"] = pcie
             del xh, xh8, xhb
         if world == 1 and not args.no_cpu_baseline:
-            base, s_ref, sample = cpu_baseline(x, n)
+            base, s_ref, sample = cpu_baseline(x[:min(v, resident)], n)
             out["cpu_baseline"] = base
             # the CPU sample doubles as an end-of-run parity check of the measured path
             eng.reset()
@@ -436,9 +509,13 @@ def main():
     return 0
 
 
-def syrk_fraction(n, bm):
+def issued_fraction(n, bm, idle_diag=True):
+    """Share of the 2*V*N^2 of SURVEY 8(d) the Gram kernels issue on the matrix cores: upper-triangular tiles only,
+    and in a diagonal tile the waves that lie wholly below the diagonal skip their MFMAs (2 of 8 waves of a
+    256 x 256 tile: 0.75 of it; 1 of 4 waves of a 128 x 128 tile of the fp32 kernel)."""
     t = (n + bm - 1) // bm
-    return (t * (t + 1) / 2.0) / float(t * t)
+    diag = 0.75 if idle_diag else 1.0
+    return (t * (t - 1) / 2.0 + t * diag) / float(t * t)
 
 
 if __name__ == "__main__":

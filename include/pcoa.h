@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define PCOA_VERSION_MAJOR 0
-#define PCOA_VERSION_MINOR 1
+#define PCOA_VERSION_MINOR 2
 
 typedef struct pcoa_ctx pcoa_ctx;
 
@@ -82,6 +82,11 @@ typedef struct pcoa_timings {
   int32_t eig_method;           /* of the last pcoa_compute: 1 = Lanczos (verified), 2 = Householder  */
   int32_t lanczos_steps;        /* Krylov dimension reached by the last pcoa_compute                  */
   int64_t fp4_fallbacks;        /* chunks the auto mode re-ran on the int8 kernel (non-binary values) */
+  int64_t lockstep_launches;    /* contraction launches in the lock-step form (all tiles of a k-stream resident)  */
+  int64_t pipeline_launches;    /* of those: launched on the CU-masked contraction stream beside a pre-pass
+                                   (fp32 pipeline)                                                  */
+  int32_t pipeline_pre_pass_cus;    /* CUs the pre-pass stream owns when the pipeline runs (0 = pipeline unavailable) */
+  int32_t pipeline_contraction_cus; /* CUs of the contraction stream                                             */
 } pcoa_timings;
 
 /* Synthetic genotype model (bench / tests only; not part of the reference).  Sample i belongs to

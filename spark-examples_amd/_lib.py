@@ -52,6 +52,10 @@ class PcoaTimings(ctypes.Structure):
         ("eig_method", ctypes.c_int32),
         ("lanczos_steps", ctypes.c_int32),
         ("fp4_fallbacks", ctypes.c_int64),
+        ("lockstep_launches", ctypes.c_int64),
+        ("pipeline_launches", ctypes.c_int64),
+        ("pipeline_pre_pass_cus", ctypes.c_int32),
+        ("pipeline_contraction_cus", ctypes.c_int32),
     ]
 
 

@@ -96,6 +96,7 @@ struct pcoa_ctx {
   hipStream_t pack_stream = nullptr, gram_stream = nullptr;
   hipEvent_t ev_fork = nullptr;
   bool lockstep_ok = false;          // the lock-step contraction launch fits this N on the whole chip
+  int64_t lockstep_launches = 0, pipeline_launches = 0;
   int64_t pack_chunk = (int64_t)1 << 20;  // variants packed + contracted per launch pair
   int64_t pack_launches = 0;
   double pack_bytes = 0;
@@ -381,6 +382,10 @@ int fp4_launch(pcoa_ctx* c, int bi, bool overlapped) {
     ScopedTimer t(c, T_GRAM, gs);
     hipError_t e = hipErrorInvalidValue;
     if (side || c->lockstep_ok) e = launch_gram_packed_lockstep(b.p, 1, b.kb * 32, c->n, c->s32, cus, gs, skip);
+    if (e == hipSuccess) {
+      c->lockstep_launches += 1;
+      if (side) c->pipeline_launches += 1;
+    }
     if (e != hipSuccess) {
       (void)hipGetLastError();
       e = launch_gram_packed(b.p, 1, b.kb * 32, c->n, c->s32, cus, gs, nullptr, skip);
@@ -822,7 +827,7 @@ const DebugKnobs& debug_knobs() {
 // ================================================================================================
 extern "C" {
 
-const char* pcoa_version(void) { return "pcoa_hip 0.1 (gfx950)"; }
+const char* pcoa_version(void) { return "pcoa_hip 0.2 (gfx950)"; }
 
 int pcoa_create(pcoa_ctx** out, int32_t n_samples, int32_t device_ordinal, uint32_t flags) {
   if (!out) return fail(nullptr, PCOA_ERR_INVALID_ARG, "out is NULL");
@@ -1539,6 +1544,10 @@ int pcoa_get_timings(pcoa_ctx* c, pcoa_timings* out) {
   out->eig_method = c->eig_method;
   out->lanczos_steps = c->lanczos_steps;
   out->fp4_fallbacks = c->fp4_fallbacks;
+  out->lockstep_launches = c->lockstep_launches;
+  out->pipeline_launches = c->pipeline_launches;
+  out->pipeline_pre_pass_cus = c->pipe_ok ? c->num_cu - c->pipe_gram_cus : 0;
+  out->pipeline_contraction_cus = c->pipe_ok ? c->pipe_gram_cus : 0;
   out->pack_seconds = c->tsec[T_PACK];
   out->pack_launches = c->pack_launches;
   out->pack_bytes = c->pack_bytes;
@@ -1557,6 +1566,8 @@ int pcoa_reset_timings(pcoa_ctx* c) {
   c->compute_total = 0;
   c->pack_launches = 0;
   c->pack_bytes = 0;
+  c->lockstep_launches = 0;
+  c->pipeline_launches = 0;
   return PCOA_OK;
 }
 
