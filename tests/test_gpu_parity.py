@@ -222,6 +222,41 @@ def test_i8_path_rejects_non_integer_or_large_values_and_f32_path_accepts_intege
         assert np.array_equal(eng.gram(), want)
 
 
+def test_large_multiplicities_never_wrap_or_round_silently(P):
+    """the exactness limits used to count variants, not summed counts.  With multiplicity m an entry grows
+    by m^2 per variant: the int8 path now sizes its launches and int64 folds by the largest m its pre-pass met, and the
+    fp32-MFMA kernel reports an accumulator that left the exact range instead of rounding."""
+    import torch
+    n, v = 40, 300000
+    x = torch.zeros((v, n), dtype=torch.float32, device="cuda")
+    x[:, 0] = 100.0                                   # S[0, 0] = 3e9 > 2^31: must come back exact (int64)
+    x[:, 1] = 1.0
+    x[::3, 2] = 7.0
+    for kernel in ("i8", "auto"):
+        with P.PcoaEngine(n, gram_kernel=kernel) as eng:
+            eng.accumulate_dense(x)
+            s = eng.gram()
+            assert s[0, 0] == 100 * 100 * v and s[0, 1] == 100 * v and s[1, 1] == v
+            assert s[2, 2] == 49 * ((v + 2) // 3) and s[0, 2] == 700 * ((v + 2) // 3)
+            assert np.array_equal(s, s.T)
+    with P.PcoaEngine(n, gram_kernel="f32") as eng:   # 3e9 does not fit an exact fp32 accumulator: an error, not a wrong S
+        eng.accumulate_dense(x)
+        with pytest.raises(P.PcoaError) as ei:
+            eng.gram()
+        assert "exact range" in str(ei.value)
+    with P.PcoaEngine(n, gram_kernel="f32") as eng:   # ... while small products stay exact on it
+        eng.accumulate_dense(x[:1000])
+        assert eng.gram()[0, 0] == 100 * 100 * 1000
+    # repeated callsets in carrier lists (CSR boundary): multiplicity 3 over many rows
+    rows = 200000
+    idx = np.tile(np.array([5, 5, 5, 9], dtype=np.int32), rows)
+    offs = (np.arange(rows + 1, dtype=np.int64) * 4)
+    with P.PcoaEngine(n) as eng:
+        eng.accumulate_calls(idx, offs)
+        s = eng.gram()
+        assert s[5, 5] == 9 * rows and s[5, 9] == 3 * rows and s[9, 9] == rows
+
+
 def test_auto_mode_picks_fp4_per_chunk_and_falls_back_to_int8_on_multiplicities(P, O):
     """auto: binary chunks run on the MX-FP4 MFMA, a chunk holding a multiplicity is re-packed as int8;
     the sum over chunks is exact either way (chunk size forced small through the debug hook)."""

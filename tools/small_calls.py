@@ -1,5 +1,5 @@
 import sys, time, importlib, numpy as np, torch
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 P = importlib.import_module("spark-examples_amd"); synth = importlib.import_module("spark-examples_amd.synth")
 n, v = 2504, 1 << 20
 offs = synth.pop_offsets(n)
