@@ -43,7 +43,7 @@ typedef enum pcoa_status {
                                   (mapping(call.callsetId), VariantsPca.scala:59; Breeze bounds check :188) */
   PCOA_ERR_RCCL = -6,
   PCOA_ERR_NOT_CONVERGED = -7, /* no verified eigenpair (Lanczos-only mode, or N too large for the dense fallback) */
-  PCOA_ERR_STATE = -8          /* reserved                                                        */
+  PCOA_ERR_STATE = -8          /* the call does not apply to this kind of ctx (e.g. pcoa_compute on a strip owner) */
 } pcoa_status;
 
 /* flags for pcoa_create */
@@ -107,6 +107,31 @@ typedef struct pcoa_synth_params {
  * Replaces: the per-partition DenseMatrix.zeros[Int](size, size) (VariantsPca.scala:183-185) plus
  * the SparkContext the driver holds (VariantsPca.scala:83-85).  N = common.indexes.size. */
 int pcoa_create(pcoa_ctx** out, int32_t n_samples, int32_t device_ordinal, uint32_t flags);
+
+/* Strip owner (a cohort whose N x N matrix does not fit one HBM -- BASELINE configs[4], 250,000 samples,
+ * S = 250 GB).  The ctx holds S[:, col0 .. col0 + cols) only -- every row, the strip's columns, BOTH triangles -- as a
+ * row-major [N][cols] matrix; the strips of all owners tile S.  Every owner is fed ALL variants (the accumulate calls
+ * below, unchanged; bitsets are 31 KB per variant at N = 250,000), so nothing is all-reduced: the exchange step is the
+ * all-gather of an N-vector per Lanczos step (pcoa_strip_matvec).  pcoa_gram_read_i64 / _load_i64 / _export / _import
+ * move [N][cols] matrices on a strip ctx, pcoa_gram_read_block_i64 takes (row, strip-relative column).
+ * pcoa_center_read_f64 / pcoa_compute / pcoa_gram_allreduce_rccl are not available on it (PCOA_ERR_STATE).
+ * Replaces: the same per-partition matrix of getSimilarityMatrix (VariantsPca.scala:183-189), column-sliced; the
+ * reference itself stops at N^2 < 2^31 (DenseMatrix[Int]). */
+int pcoa_create_strip(pcoa_ctx** out, int32_t n_samples, int32_t col0, int32_t cols, int32_t device_ordinal,
+                      uint32_t flags);
+
+/* Returns 1 for a strip owner (and its column range), 0 for an ordinary ctx. */
+int pcoa_strip_info(const pcoa_ctx* ctx, int32_t* col0_out, int32_t* cols_out);
+
+/* out_cols[jj] = sum_i S(i, col0 + jj): the row sum of sample col0 + jj (S is symmetric), an exact integer.
+ * Replaces: rowSums (VariantsPca.scala:206) for the strip's samples; the owners' vectors concatenate to rowSums. */
+int pcoa_strip_col_sums(pcoa_ctx* ctx, double* out_cols);
+
+/* y_out[jj] = sum_i B(col0 + jj, i) * v[i] with B(j, i) = ((S(j, i) - means[j]) - means[i]) + matrix_mean -- rows of the
+ * double-centred matrix in the reference's operation order (VariantsPca.scala:216-221), evaluated on the fly from the
+ * strip (B is never stored).  v, means (= rowSums / N, all N samples) and y_out are host arrays.  One call per owner and
+ * Lanczos step; the owners' results concatenate (all-gather) to B v. */
+int pcoa_strip_matvec(pcoa_ctx* ctx, const double* v, const double* means, double matrix_mean, double* y_out);
 
 /* Replaces: VariantsPcaDriver.stop (VariantsPca.scala:283-285). */
 void pcoa_destroy(pcoa_ctx* ctx);

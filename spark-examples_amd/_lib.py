@@ -76,6 +76,10 @@ _i64 = ctypes.c_int64
 _SIGNATURES = [
     ("pcoa_version", ctypes.c_char_p, []),
     ("pcoa_create", ctypes.c_int, [ctypes.POINTER(_vp), _i32, _i32, ctypes.c_uint32]),
+    ("pcoa_create_strip", ctypes.c_int, [ctypes.POINTER(_vp), _i32, _i32, _i32, _i32, ctypes.c_uint32]),
+    ("pcoa_strip_info", ctypes.c_int, [_vp, ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
+    ("pcoa_strip_col_sums", ctypes.c_int, [_vp, _vp]),
+    ("pcoa_strip_matvec", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _vp]),
     ("pcoa_destroy", None, [_vp]),
     ("pcoa_last_error", ctypes.c_char_p, [_vp]),
     ("pcoa_reset", ctypes.c_int, [_vp]),

@@ -99,7 +99,85 @@ __global__ __launch_bounds__(256) void col_means_kernel(const double* __restrict
   if (j < n) cm[j] = row_sums[j] / (double)n;
 }
 
+// ---- strip owner: S is [n][cols] row-major.  Both reductions run over the ROWS for every column: a
+// workgroup takes 256 columns x a band of 256 rows (coalesced along the columns), writes one partial per column, and a
+// second pass adds the bands in a fixed order -- deterministic, no floating-point atomics.
+constexpr int STRIP_BAND = 256;
+
+template <bool MATVEC>
+__global__ __launch_bounds__(256) void strip_band_kernel(const int32_t* __restrict__ s32, const int64_t* __restrict__ s64,
+                                                         int32_t n, int32_t col0, int32_t cols, const double* __restrict__ v,
+                                                         const double* __restrict__ means, double mmean,
+                                                         double* __restrict__ partial /* [bands][cols] */) {
+#pragma clang fp contract(off)
+  const int jj = blockIdx.x * 256 + threadIdx.x;
+  const int band = blockIdx.y;
+  const int i0 = band * STRIP_BAND, i1 = min(n, i0 + STRIP_BAND);
+  if (jj >= cols) return;
+  if constexpr (MATVEC) {
+    const double row_mean = means[col0 + jj];   // the strip's column j is row j of the symmetric matrix
+    double acc = 0.0;
+    for (int i = i0; i < i1; ++i) {
+      const int64_t idx = (int64_t)i * cols + jj;
+      const double data = (double)((int64_t)s32[idx] + (s64 ? s64[idx] : 0));
+      double t = data - row_mean;
+      t = t - means[i];
+      t = t + mmean;
+      acc += t * v[i];
+    }
+    partial[(int64_t)band * cols + jj] = acc;
+  } else {
+    int64_t acc = 0;
+    for (int i = i0; i < i1; ++i) {
+      const int64_t idx = (int64_t)i * cols + jj;
+      acc += (int64_t)s32[idx] + (s64 ? s64[idx] : 0);
+    }
+    reinterpret_cast<int64_t*>(partial)[(int64_t)band * cols + jj] = acc;
+  }
+}
+
+template <bool MATVEC>
+__global__ __launch_bounds__(256) void strip_finish_kernel(const double* __restrict__ partial, int32_t cols, int32_t bands,
+                                                           double* __restrict__ out) {
+  const int jj = blockIdx.x * 256 + threadIdx.x;
+  if (jj >= cols) return;
+  if constexpr (MATVEC) {
+    double acc = 0.0;
+    for (int b = 0; b < bands; ++b) acc += partial[(int64_t)b * cols + jj];
+    out[jj] = acc;
+  } else {
+    int64_t acc = 0;
+    for (int b = 0; b < bands; ++b) acc += reinterpret_cast<const int64_t*>(partial)[(int64_t)b * cols + jj];
+    out[jj] = (double)acc;
+  }
+}
+
 }  // namespace
+
+int64_t strip_ws_doubles(int32_t n, int32_t cols) {
+  const int64_t bands = ((int64_t)n + STRIP_BAND - 1) / STRIP_BAND;
+  return (bands + 1) * (int64_t)cols;   // [0, cols): the result; behind it the per-band partials
+}
+
+hipError_t launch_strip_col_sums(const int32_t* s32, const int64_t* s64_or_null, int32_t n, int32_t cols, double* ws,
+                                 hipStream_t stream) {
+  const int bands = (n + STRIP_BAND - 1) / STRIP_BAND;
+  const dim3 grid((unsigned)((cols + 255) / 256), (unsigned)bands);
+  hipLaunchKernelGGL(strip_band_kernel<false>, grid, dim3(256), 0, stream, s32, s64_or_null, n, 0, cols, nullptr, nullptr, 0.0,
+                     ws + cols);
+  hipLaunchKernelGGL(strip_finish_kernel<false>, dim3(grid.x), dim3(256), 0, stream, ws + cols, cols, bands, ws);
+  return hipGetLastError();
+}
+
+hipError_t launch_strip_matvec(const int32_t* s32, const int64_t* s64_or_null, int32_t n, int32_t col0, int32_t cols,
+                               const double* v, const double* means, double matrix_mean, double* ws, hipStream_t stream) {
+  const int bands = (n + STRIP_BAND - 1) / STRIP_BAND;
+  const dim3 grid((unsigned)((cols + 255) / 256), (unsigned)bands);
+  hipLaunchKernelGGL(strip_band_kernel<true>, grid, dim3(256), 0, stream, s32, s64_or_null, n, col0, cols, v, means,
+                     matrix_mean, ws + cols);
+  hipLaunchKernelGGL(strip_finish_kernel<true>, dim3(grid.x), dim3(256), 0, stream, ws + cols, cols, bands, ws);
+  return hipGetLastError();
+}
 
 hipError_t launch_col_means(const double* row_sums, int32_t n, double* cm, hipStream_t stream) {
   hipLaunchKernelGGL(col_means_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, row_sums, n, cm);

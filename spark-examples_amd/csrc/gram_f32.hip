@@ -123,7 +123,13 @@ __device__ __forceinline__ void store_tile(const f32x16& c, int32_t* __restrict_
     // an fp32 chain of integer products is exact below 2^24; beyond it (carrier multiplicities m with V * m^2 >= 2^24 in
     // one launch) the sum may have been rounded: reported, never silent
     inexact |= (j >= i && j < n) && !(__builtin_fabsf(c[r]) < 16777216.0f);   // (padding columns may hold anything)
-    if (j >= i && j < n && v != 0) atomicAdd(&s32[(int64_t)i * n + j], v);  // upper triangle only
+    if (j >= i && j < n && v != 0) {                                          // upper triangle only
+      // (the returned old value costs a round trip, but this kernel has no pre-pass that could bound the carrier
+      // multiplicities: an int32 partial that would wrap is reported through the same flag)
+      const int old = atomicAdd(&s32[(int64_t)i * n + j], v);
+      const int64_t sum = (int64_t)old + (int64_t)v;
+      inexact |= (sum > 2147483647LL) || (sum < -2147483648LL);
+    }
   }
 }
 

@@ -1020,7 +1020,7 @@ __device__ __forceinline__ void tile_coords(int tile, int ntile, int& row_blk, i
 template <int FMT, int NWM, int NNI, int SKB, int NST, bool PP, int LEFT = 0>
 __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram_packed_kernel(
     const int8_t* __restrict__ p, int npad, int64_t nstages, int n, int ntile, int ntri, int splitk,
-    int64_t stages_per, int32_t* __restrict__ s32, int xcd_map, const int32_t* __restrict__ skip) {
+    int64_t stages_per, int32_t* __restrict__ s32, int xcd_map, const int32_t* __restrict__ skip, GramStrip strip) {
   __shared__ __attribute__((aligned(16))) StageI8<NWM, SKB> lds[NST];
   // device-side predicate of the auto mode: a pre-pass met a value other than 0 / 1 in the buffered tiles, so this
   // launch must not add anything to S (the host redoes those tiles on the int8 kernel once it reads the same word)
@@ -1053,7 +1053,12 @@ __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram
     ks = b / ntri;
   }
   int row_blk, col_blk;
-  tile_coords<NWM>(tile, ntile, row_blk, col_blk);
+  if (strip.cols > 0) {  // strip owner: ALL tiles (row block, column block of the strip), column-major over the strip
+    row_blk = tile % ntile;
+    col_blk = strip.cb0 + tile / ntile;
+  } else {
+    tile_coords<NWM>(tile, ntile, row_blk, col_blk);
+  }
 
   const int64_t st_begin = (int64_t)ks * stages_per;
   const int64_t st_end = (st_begin + stages_per < nstages) ? (st_begin + stages_per) : nstages;
@@ -1063,7 +1068,8 @@ __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram
   const int col_i = row_blk * 128 * NWM, col_j = col_blk * TJ;
   // Diagonal tiles: a wave whose whole 128 x (32*NNI) sub-tile has row > column holds nothing of the
   // upper triangle; it skips its MFMAs (2 of 8 waves in 10 of 55 tiles at N = 2504).
-  const bool idle = (col_i + wm * 128) > (col_j + wn * 32 * NNI + 32 * NNI - 1);
+  // (a strip owner keeps both triangles: nothing is idle there)
+  const bool idle = strip.cols == 0 && (col_i + wm * 128) > (col_j + wn * 32 * NNI + 32 * NNI - 1);
 
   typename AccType<FMT>::type acc[4][NNI];
 #pragma unroll
@@ -1123,7 +1129,12 @@ __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram
       for (int r = 0; r < 16; ++r) {
         const int i = col_i + wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int v = (int)acc[mi][ni][r];  // fp32 accumulators hold exact integers below 2^24
-        if (j >= i && j < n && v != 0) atomicAdd(&s32[(int64_t)i * n + j], v);
+        if (strip.cols > 0) {           // S[:, col0 .. col0 + cols): every row, the strip's columns, row length `cols`
+          if (i < n && j >= strip.col0 && j < strip.col0 + strip.cols && v != 0)
+            atomicAdd(&s32[(int64_t)i * strip.cols + (j - strip.col0)], v);
+        } else if (j >= i && j < n && v != 0) {
+          atomicAdd(&s32[(int64_t)i * n + j], v);
+        }
       }
       // keep the float->int conversions of one MFMA tile next to their atomics: hoisting all 128 of them
       // ahead of the stores would need 128 more registers (the FP4 variant then spills)
@@ -1317,15 +1328,15 @@ hipError_t launch_gram_packed_lockstep(const int8_t* p, int fmt, int64_t nv, int
   const dim3 grid((unsigned)(per * kNumXcd)), block(512);
   if (fmt == 1)
     hipLaunchKernelGGL((gram_packed_kernel<1, 2, 2, 4, 3, true, 2>), grid, block, 0, stream, p, npad, nstages, n, ntile, ntri,
-                       splitk, stages_per, s32, 2, skip);
+                       splitk, stages_per, s32, 2, skip, GramStrip{});
   else
     hipLaunchKernelGGL((gram_packed_kernel<0, 2, 2, 4, 3, true, 2>), grid, block, 0, stream, p, npad, nstages, n, ntile, ntri,
-                       splitk, stages_per, s32, 2, skip);
+                       splitk, stages_per, s32, 2, skip, GramStrip{});
   return hipGetLastError();
 }
 
 hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, int32_t* s32, int num_cu,
-                              hipStream_t stream, int* splitk_out, const int32_t* skip) {
+                              hipStream_t stream, int* splitk_out, const int32_t* skip, GramStrip strip) {
   if (nv <= 0) return hipSuccess;
   // Shipped schedule: ping-pong, 4 k-blocks per stage, 3-stage ring, two MFMAs behind the phase barrier ("243").  The
   // other schedules of DESIGN.md 4.1 / 4.2 (PCOA_GRAM_I8_CFG = 43 | 44 | 143 | 144 | 443) only exist in a library built
@@ -1340,7 +1351,12 @@ hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, i
   const int skb = (cfg % 100) / 10;
   const int npad = (int)gram_packed_npad(n);
   const int ntile = npad / TJ;
-  const int64_t ntri64 = (int64_t)ntile * (ntile + 1) / 2;
+  int64_t ntri64 = (int64_t)ntile * (ntile + 1) / 2;
+  if (strip.cols > 0) {  // strip owner: ntile row blocks x the column blocks that touch [col0, col0 + cols)
+    strip.cb0 = strip.col0 / TJ;
+    const int cb1 = (strip.col0 + strip.cols + TJ - 1) / TJ;
+    ntri64 = (int64_t)ntile * (cb1 - strip.cb0);
+  }
   if (ntri64 > (1 << 28)) return hipErrorInvalidValue;
   const int ntri = (int)ntri64;
   const int64_t nstages = gram_kb_pad(nv, fmt) / skb;
@@ -1365,10 +1381,10 @@ hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, i
   do {                                                                                                          \
     if (fmt == 1)                                                                                               \
       hipLaunchKernelGGL((gram_packed_kernel<1, 2, 2, SKB_, NST_, PP_, LEFT_>), grid, block, 0, stream, p, npad, nstages, n, ntile, \
-                         ntri, (int)splitk, stages_per, s32, xcd_map, skip);                                    \
+                         ntri, (int)splitk, stages_per, s32, xcd_map, skip, strip);                             \
     else                                                                                                        \
       hipLaunchKernelGGL((gram_packed_kernel<0, 2, 2, SKB_, NST_, PP_, LEFT_>), grid, block, 0, stream, p, npad, nstages, n, ntile, \
-                         ntri, (int)splitk, stages_per, s32, xcd_map, skip);                                    \
+                         ntri, (int)splitk, stages_per, s32, xcd_map, skip, strip);                             \
   } while (0)
   switch (cfg) {
 #ifdef PCOA_EXPERIMENTS

@@ -32,6 +32,12 @@ struct EventPair {
 
 struct pcoa_ctx {
   int32_t n = 0;
+  // strip owner (SURVEY 8e, N beyond one HBM): the ctx holds S[:, strip_col0 .. strip_col0 + s_cols) as [n][s_cols]
+  // (both triangles, no mirror); s_cols == n and is_strip == false for the ordinary symmetric engine
+  int32_t s_cols = 0, strip_col0 = 0;
+  bool is_strip = false;
+  double* strip_ws = nullptr;      // partial sums of the strip reductions (lazy)
+  int64_t strip_ws_cap = 0;
   int device = 0;
   uint32_t flags = 0;
   int num_cu = 256;
@@ -247,14 +253,21 @@ constexpr int64_t kFoldThreshold = (int64_t)1 << 30;      // fold int32 partials
 // multi-launch and int64-fold paths can be exercised with small inputs.
 int64_t knob_limit(int64_t x, int64_t dflt) { return (x > 0 && x < dflt) ? x : dflt; }
 
+size_t s_count(const pcoa_ctx* c) { return (size_t)c->n * (size_t)c->s_cols; }
+GramStrip strip_of(const pcoa_ctx* c) {
+  GramStrip st;
+  if (c->is_strip) { st.col0 = c->strip_col0; st.cols = c->s_cols; }
+  return st;
+}
+
 int fold_now(pcoa_ctx* c) {
-  const int64_t count = (int64_t)c->n * c->n;
+  const int64_t count = (int64_t)s_count(c);
   if (!c->s64) {
     HIP_TRY(c, hipMalloc((void**)&c->s64, sizeof(int64_t) * (size_t)count));
     HIP_TRY(c, hipMemsetAsync(c->s64, 0, sizeof(int64_t) * (size_t)count, c->stream));
   }
-  // s64 is kept symmetric: mirror the partial before it is folded in
-  HIP_TRY(c, launch_symmetrize_i32(c->s32, c->n, c->stream));
+  // s64 is kept symmetric: mirror the partial before it is folded in (a strip holds both triangles already)
+  if (!c->is_strip) HIP_TRY(c, launch_symmetrize_i32(c->s32, c->n, c->stream));
   HIP_TRY(c, launch_fold_i32_to_i64(c->s32, c->s64, count, c->stream));
   c->variants_in_s32 = 0;
   c->dirty = false;
@@ -327,15 +340,15 @@ int fp4_setup(pcoa_ctx* c) {
   const DebugKnobs& k = debug_knobs();
   // lock-step contraction on the whole chip: used when it fills >= 80 % of the CUs
   const int ls = gram_lockstep_splitk(c->n, c->num_cu);
-  c->lockstep_ok = ls > 0 && gram_lockstep_workgroups(c->n, ls) * 5 >= c->num_cu * 4;
+  c->lockstep_ok = !c->is_strip && ls > 0 && gram_lockstep_workgroups(c->n, ls) * 5 >= c->num_cu * 4;
   if (k.lockstep == 0) c->lockstep_ok = false;
-  if (k.lockstep == 1) c->lockstep_ok = ls > 0;
+  if (k.lockstep == 1) c->lockstep_ok = !c->is_strip && ls > 0;
   // fp32 pipeline: MI355X geometry (8 XCDs x 32 CUs) and a lock-step contraction that fills >= 80 % of half the chip
   const int half = c->num_cu / 2;
   const int lsh = (c->num_cu == 256) ? gram_lockstep_splitk(c->n, half) : 0;
-  bool want = lsh > 0 && gram_lockstep_workgroups(c->n, lsh) * 5 >= half * 4;
+  bool want = !c->is_strip && lsh > 0 && gram_lockstep_workgroups(c->n, lsh) * 5 >= half * 4;
   if (k.pipeline == 0) want = false;
-  if (k.pipeline == 1) want = lsh > 0;
+  if (k.pipeline == 1) want = !c->is_strip && lsh > 0;
   if (want) {
     uint32_t mp[8] = {0}, mg[8] = {0};
     for (int g = 0; g < 256; ++g) {
@@ -388,7 +401,7 @@ int fp4_launch(pcoa_ctx* c, int bi, bool overlapped) {
     }
     if (e != hipSuccess) {
       (void)hipGetLastError();
-      e = launch_gram_packed(b.p, 1, b.kb * 32, c->n, c->s32, cus, gs, nullptr, skip);
+      e = launch_gram_packed(b.p, 1, b.kb * 32, c->n, c->s32, cus, gs, nullptr, skip, strip_of(c));
     }
     if (e != hipSuccess) return hip_fail(c, e, "packed gram kernel launch");
   }
@@ -584,7 +597,7 @@ int int8_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64_t
     {
       ScopedTimer t(c, T_GRAM);
       hipError_t e = launch_gram_packed(c->pack_buf + (v0 / KB_I8) * row_bytes, 0, part, c->n, c->s32, c->num_cu, c->stream,
-                                        nullptr);
+                                        nullptr, nullptr, strip_of(c));
       if (e != hipSuccess) return hip_fail(c, e, "packed gram kernel launch");
     }
     c->gram_kind = 2;
@@ -709,8 +722,9 @@ int check_device_flags(pcoa_ctx* c) {
                 "invalid, call pcoa_reset; the default mode falls back to the int8 kernel by itself");
   if (flag & 16)
     return fail(c, PCOA_ERR_INVALID_ARG,
-                "an fp32 accumulator of the fp32-MFMA kernel left the exact range (a sum of products reached 2^24 inside "
-                "one launch: carrier multiplicities too large for it); S is invalid, call pcoa_reset");
+                "an accumulator of the fp32-MFMA kernel left the exact range (a sum of products reached 2^24 inside one "
+                "launch, or an int32 partial passed 2^31: carrier multiplicities too large for it); S is invalid, call "
+                "pcoa_reset and use the default engine (multiplicities up to 127)");
   if (flag & 4)
     return fail(c, PCOA_ERR_INVALID_ARG,
                 "a genotype tile holds a value that is not an integer in [0, 127] (carrier multiplicity); S is "
@@ -763,7 +777,7 @@ int finalize_impl(pcoa_ctx* c) {
   if (rc0 != PCOA_OK) return rc0;
   if (c->dirty) {
     ScopedTimer t(c, T_FINALIZE);
-    HIP_TRY(c, launch_symmetrize_i32(c->s32, c->n, c->stream));
+    if (!c->is_strip) HIP_TRY(c, launch_symmetrize_i32(c->s32, c->n, c->stream));
     c->dirty = false;
   }
   return PCOA_OK;
@@ -829,10 +843,15 @@ extern "C" {
 
 const char* pcoa_version(void) { return "pcoa_hip 0.2 (gfx950)"; }
 
-int pcoa_create(pcoa_ctx** out, int32_t n_samples, int32_t device_ordinal, uint32_t flags) {
+static int create_impl(pcoa_ctx** out, int32_t n_samples, int32_t device_ordinal, uint32_t flags, int32_t col0, int32_t cols) {
   if (!out) return fail(nullptr, PCOA_ERR_INVALID_ARG, "out is NULL");
   *out = nullptr;
   if (n_samples <= 0) return fail(nullptr, PCOA_ERR_INVALID_ARG, "n_samples must be positive");
+  const bool strip = cols >= 0;
+  if (strip && (col0 < 0 || cols <= 0 || (int64_t)col0 + cols > n_samples))
+    return fail(nullptr, PCOA_ERR_INVALID_ARG, "strip [col0, col0 + cols) must lie inside [0, n_samples) and be non-empty");
+  if (strip && (flags & PCOA_FLAG_GRAM_F32_MFMA))
+    return fail(nullptr, PCOA_ERR_INVALID_ARG, "a strip owner needs a packed-operand engine (not PCOA_FLAG_GRAM_F32_MFMA)");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0) {
@@ -845,6 +864,9 @@ int pcoa_create(pcoa_ctx** out, int32_t n_samples, int32_t device_ordinal, uint3
   pcoa_ctx* c = new (std::nothrow) pcoa_ctx();
   if (!c) return fail(nullptr, PCOA_ERR_OUT_OF_MEMORY, "host allocation failed");
   c->n = n_samples;
+  c->is_strip = strip;
+  c->s_cols = strip ? cols : n_samples;
+  c->strip_col0 = strip ? col0 : 0;
   c->device = device_ordinal;
   c->flags = flags;
   c->use_i8 = !(flags & PCOA_FLAG_GRAM_F32_MFMA);
@@ -877,7 +899,11 @@ int pcoa_create(pcoa_ctx** out, int32_t n_samples, int32_t device_ordinal, uint3
   if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess)
     return bail(e, "hipStreamCreate");
   c->stream = c->own_stream;
-  const size_t nn = (size_t)n_samples * (size_t)n_samples;
+  if (strip && !c->use_i8) {
+    pcoa_destroy(c);
+    return fail(nullptr, PCOA_ERR_INVALID_ARG, "a strip owner needs a packed-operand engine (PCOA_GRAM_KERNEL=f32 is set)");
+  }
+  const size_t nn = s_count(c);
   if ((e = hipMalloc((void**)&c->s32, sizeof(int32_t) * nn)) != hipSuccess) return bail(e, "hipMalloc(S)");
   if ((e = hipMemsetAsync(c->s32, 0, sizeof(int32_t) * nn, c->stream)) != hipSuccess) return bail(e, "memset(S)");
   if ((e = hipMalloc((void**)&c->zeros, 4096)) != hipSuccess) return bail(e, "hipMalloc(zeros)");
@@ -887,6 +913,16 @@ int pcoa_create(pcoa_ctx** out, int32_t n_samples, int32_t device_ordinal, uint3
   if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
   *out = c;
   return PCOA_OK;
+}
+
+int pcoa_create(pcoa_ctx** out, int32_t n_samples, int32_t device_ordinal, uint32_t flags) {
+  return create_impl(out, n_samples, device_ordinal, flags, 0, -1);
+}
+
+int pcoa_create_strip(pcoa_ctx** out, int32_t n_samples, int32_t col0, int32_t cols, int32_t device_ordinal,
+                      uint32_t flags) {
+  if (cols < 0) return fail(nullptr, PCOA_ERR_INVALID_ARG, "cols must be positive");
+  return create_impl(out, n_samples, device_ordinal, flags, col0, cols);
 }
 
 void pcoa_destroy(pcoa_ctx* c) {
@@ -905,7 +941,7 @@ void pcoa_destroy(pcoa_ctx* c) {
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->fb_flags_host) (void)hipHostFree(c->fb_flags_host);
   void* bufs[] = {c->s32, c->s64, c->zeros, c->err_flag, c->tile, c->csr_idx, c->csr_offs, c->thr_dev,
-                  c->sample_pop, c->xfer, c->coll, c->fb_flags, c->pack_buf, c->lanczos_ws, c->ws.a, c->ws.d, c->ws.e, c->ws.tau, c->ws.q, c->ws.w, c->ws.lam,
+                  c->sample_pop, c->xfer, c->coll, c->fb_flags, c->strip_ws, c->pack_buf, c->lanczos_ws, c->ws.a, c->ws.d, c->ws.e, c->ws.tau, c->ws.q, c->ws.w, c->ws.lam,
                   c->ws.z, c->ws.scratch, c->ws.iscratch, c->row_sums, c->colmean, c->stats, c->nz,
                   c->out_dev};
   for (void* b : bufs)
@@ -942,7 +978,7 @@ int pcoa_reset(pcoa_ctx* c) {
   CHECK_CTX(c);
   int rc = fp4_discard(c);  // buffered or in-flight operands belong to the old S
   if (rc != PCOA_OK) return rc;
-  const size_t nn = (size_t)c->n * (size_t)c->n;
+  const size_t nn = s_count(c);
   HIP_TRY(c, hipMemsetAsync(c->s32, 0, sizeof(int32_t) * nn, c->stream));
   if (c->s64) HIP_TRY(c, hipMemsetAsync(c->s64, 0, sizeof(int64_t) * nn, c->stream));
   HIP_TRY(c, hipMemsetAsync(c->err_flag, 0, 16, c->stream));
@@ -1144,7 +1180,7 @@ int pcoa_accumulate_calls(pcoa_ctx* c, const int32_t* sample_idx, const int64_t*
       }
       {
         ScopedTimer t(c, T_GRAM);
-        HIP_TRY(c, launch_gram_i8_packed(c->pack_buf, rows, c->n, c->s32, c->num_cu, c->stream, nullptr));
+        HIP_TRY(c, launch_gram_packed(c->pack_buf, 0, rows, c->n, c->s32, c->num_cu, c->stream, nullptr, nullptr, strip_of(c)));
       }
       c->gram_kind = 2;  // a carrier list repeats a callset (or int8 was forced)
       account_gram(c, rows, weight);
@@ -1220,14 +1256,14 @@ int pcoa_gram_export_device_i64(pcoa_ctx* c, int64_t* dst_dev) {
   int rc = finalize_impl(c);
   if (rc != PCOA_OK) return rc;
   if ((rc = check_device_flags(c)) != PCOA_OK) return rc;  // never hand out an S that an input check has invalidated
-  HIP_TRY(c, launch_export_i64(c->s32, c->s64, dst_dev, (int64_t)c->n * c->n, c->stream));
+  HIP_TRY(c, launch_export_i64(c->s32, c->s64, dst_dev, (int64_t)s_count(c), c->stream));
   return PCOA_OK;
 }
 
 int pcoa_gram_import_device_i64(pcoa_ctx* c, const int64_t* src_dev) {
   CHECK_CTX(c);
   if (!src_dev) return fail(c, PCOA_ERR_INVALID_ARG, "src_dev is NULL");
-  const size_t nn = (size_t)c->n * (size_t)c->n;
+  const size_t nn = s_count(c);
   int rc = fp4_discard(c);  // S is replaced: what was buffered or in flight for the old S goes with it
   if (rc != PCOA_OK) return rc;
   if (!c->s64) HIP_TRY(c, hipMalloc((void**)&c->s64, sizeof(int64_t) * nn));
@@ -1241,7 +1277,7 @@ int pcoa_gram_import_device_i64(pcoa_ctx* c, const int64_t* src_dev) {
 int pcoa_gram_read_i64(pcoa_ctx* c, int64_t* out_nxn) {
   CHECK_CTX(c);
   if (!out_nxn) return fail(c, PCOA_ERR_INVALID_ARG, "out is NULL");
-  const size_t nn = (size_t)c->n * (size_t)c->n;
+  const size_t nn = s_count(c);
   if (!c->xfer) HIP_TRY(c, hipMalloc((void**)&c->xfer, sizeof(int64_t) * nn));
   int rc = pcoa_gram_export_device_i64(c, c->xfer);
   if (rc != PCOA_OK) return rc;
@@ -1251,22 +1287,22 @@ int pcoa_gram_read_i64(pcoa_ctx* c, int64_t* out_nxn) {
 
 int pcoa_gram_read_block_i64(pcoa_ctx* c, int32_t row0, int32_t col0, int32_t rows, int32_t cols, int64_t* out) {
   CHECK_CTX(c);
-  if (!out || rows < 0 || cols < 0 || row0 < 0 || col0 < 0 || (int64_t)row0 + rows > c->n || (int64_t)col0 + cols > c->n)
-    return fail(c, PCOA_ERR_INVALID_ARG, "block outside the N x N matrix or out is NULL");
+  if (!out || rows < 0 || cols < 0 || row0 < 0 || col0 < 0 || (int64_t)row0 + rows > c->n || (int64_t)col0 + cols > c->s_cols)
+    return fail(c, PCOA_ERR_INVALID_ARG, "block outside the matrix the ctx holds (N x N, or N x cols of a strip) or out is NULL");
   if (rows == 0 || cols == 0) return PCOA_OK;
   int rc = finalize_impl(c);
   if (rc != PCOA_OK) return rc;
   // int32 partial and (if folded) int64 total are copied as strided blocks and summed on the host:
   // no N x N exchange buffer, so this also works when N^2 * 8 B would not fit (N = 100k: 80 GB)
   std::vector<int32_t> a((size_t)rows * (size_t)cols);
-  HIP_TRY(c, hipMemcpy2DAsync(a.data(), sizeof(int32_t) * (size_t)cols, c->s32 + (size_t)row0 * c->n + col0,
-                              sizeof(int32_t) * (size_t)c->n, sizeof(int32_t) * (size_t)cols, (size_t)rows,
+  HIP_TRY(c, hipMemcpy2DAsync(a.data(), sizeof(int32_t) * (size_t)cols, c->s32 + (size_t)row0 * c->s_cols + col0,
+                              sizeof(int32_t) * (size_t)c->s_cols, sizeof(int32_t) * (size_t)cols, (size_t)rows,
                               hipMemcpyDeviceToHost, c->stream));
   std::vector<int64_t> b;
   if (c->s64) {
     b.resize(a.size());
-    HIP_TRY(c, hipMemcpy2DAsync(b.data(), sizeof(int64_t) * (size_t)cols, c->s64 + (size_t)row0 * c->n + col0,
-                                sizeof(int64_t) * (size_t)c->n, sizeof(int64_t) * (size_t)cols, (size_t)rows,
+    HIP_TRY(c, hipMemcpy2DAsync(b.data(), sizeof(int64_t) * (size_t)cols, c->s64 + (size_t)row0 * c->s_cols + col0,
+                                sizeof(int64_t) * (size_t)c->s_cols, sizeof(int64_t) * (size_t)cols, (size_t)rows,
                                 hipMemcpyDeviceToHost, c->stream));
   }
   rc = check_device_flags(c);  // synchronises the stream
@@ -1278,7 +1314,7 @@ int pcoa_gram_read_block_i64(pcoa_ctx* c, int32_t row0, int32_t col0, int32_t ro
 int pcoa_gram_load_i64(pcoa_ctx* c, const int64_t* in_nxn) {
   CHECK_CTX(c);
   if (!in_nxn) return fail(c, PCOA_ERR_INVALID_ARG, "in is NULL");
-  const size_t nn = (size_t)c->n * (size_t)c->n;
+  const size_t nn = s_count(c);
   if (!c->xfer) HIP_TRY(c, hipMalloc((void**)&c->xfer, sizeof(int64_t) * nn));
   HIP_TRY(c, hipMemcpyAsync(c->xfer, in_nxn, sizeof(int64_t) * nn, hipMemcpyHostToDevice, c->stream));
   int rc = pcoa_gram_import_device_i64(c, c->xfer);
@@ -1320,7 +1356,7 @@ int pcoa_gram_allreduce_rccl(pcoa_ctx* c, void* nccl_comm) {
   CHECK_CTX(c);
   if (!nccl_comm) return fail(c, PCOA_ERR_INVALID_ARG, "nccl_comm is NULL");
   ncclComm_t comm = (ncclComm_t)nccl_comm;
-  const size_t nn = (size_t)c->n * (size_t)c->n;
+  const size_t nn = s_count(c);
   int rc = finalize_impl(c);
   if (rc != PCOA_OK) return rc;
   // All ranks must take the same branch: agree on {total variants held in int32 partials, anyone folded}.
@@ -1350,6 +1386,7 @@ int pcoa_gram_allreduce_rccl(pcoa_ctx* c, void* nccl_comm) {
 int pcoa_center_read_f64(pcoa_ctx* c, double* out_b, double* out_row_sums, int32_t* out_nonzero_rows,
                          double* out_matrix_mean) {
   CHECK_CTX(c);
+  if (c->is_strip) return fail(c, PCOA_ERR_STATE, "a strip owner holds N x cols of S: use pcoa_strip_col_sums / pcoa_strip_matvec");
   int rc = finalize_impl(c);
   if (rc != PCOA_OK) return rc;
   if ((rc = check_device_flags(c)) != PCOA_OK) return rc;
@@ -1385,6 +1422,9 @@ int pcoa_compute(pcoa_ctx* c, int32_t num_pc, double* out_components, double* ou
     return fail(c, PCOA_ERR_INVALID_ARG, buf);
   }
   if (!out_components) return fail(c, PCOA_ERR_INVALID_ARG, "out_components is NULL");
+  if (c->is_strip)
+    return fail(c, PCOA_ERR_STATE, "a strip owner holds N x cols of S: the eigensolve over strips is driven by the host "
+                                   "(pcoa_strip_col_sums / pcoa_strip_matvec; spark-examples_amd/strips.py)");
   int rc = finalize_impl(c);
   if (rc != PCOA_OK) return rc;
   rc = check_device_flags(c);
@@ -1516,6 +1556,53 @@ int pcoa_compute(pcoa_ctx* c, int32_t num_pc, double* out_components, double* ou
   if (out_eigenvalues)
     for (int32_t t = 0; t < num_pc; ++t) out_eigenvalues[t] = sel[(size_t)t];
   if (out_nonzero_rows) *out_nonzero_rows = nzh;
+  return PCOA_OK;
+}
+
+int pcoa_strip_info(const pcoa_ctx* c, int32_t* col0_out, int32_t* cols_out) {
+  if (!c) return fail(nullptr, PCOA_ERR_INVALID_ARG, "ctx is NULL");
+  if (col0_out) *col0_out = c->strip_col0;
+  if (cols_out) *cols_out = c->s_cols;
+  return c->is_strip ? 1 : 0;
+}
+
+int pcoa_strip_col_sums(pcoa_ctx* c, double* out_cols) {
+  CHECK_CTX(c);
+  if (!c->is_strip) return fail(c, PCOA_ERR_STATE, "not a strip owner (pcoa_create_strip)");
+  if (!out_cols) return fail(c, PCOA_ERR_INVALID_ARG, "out_cols is NULL");
+  int rc = finalize_impl(c);
+  if (rc != PCOA_OK) return rc;
+  if ((rc = check_device_flags(c)) != PCOA_OK) return rc;
+  const int64_t need = strip_ws_doubles(c->n, c->s_cols);
+  if ((rc = ensure(c, &c->strip_ws, &c->strip_ws_cap, need)) != PCOA_OK) return rc;
+  {
+    ScopedTimer t(c, T_CENTER);
+    HIP_TRY(c, launch_strip_col_sums(c->s32, c->s64, c->n, c->s_cols, c->strip_ws, c->stream));
+  }
+  HIP_TRY(c, hipMemcpyAsync(out_cols, c->strip_ws, sizeof(double) * (size_t)c->s_cols, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return PCOA_OK;
+}
+
+int pcoa_strip_matvec(pcoa_ctx* c, const double* v, const double* means, double matrix_mean, double* y_out) {
+  CHECK_CTX(c);
+  if (!c->is_strip) return fail(c, PCOA_ERR_STATE, "not a strip owner (pcoa_create_strip)");
+  if (!v || !means || !y_out) return fail(c, PCOA_ERR_INVALID_ARG, "v, means or y_out is NULL");
+  int rc = finalize_impl(c);
+  if (rc != PCOA_OK) return rc;
+  const int64_t need = strip_ws_doubles(c->n, c->s_cols) + 2 * (int64_t)c->n;
+  if ((rc = ensure(c, &c->strip_ws, &c->strip_ws_cap, need)) != PCOA_OK) return rc;
+  double* v_dev = c->strip_ws + strip_ws_doubles(c->n, c->s_cols);
+  double* m_dev = v_dev + c->n;
+  HIP_TRY(c, hipMemcpyAsync(v_dev, v, sizeof(double) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(m_dev, means, sizeof(double) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));
+  {
+    ScopedTimer t(c, T_LANCZOS);
+    HIP_TRY(c, launch_strip_matvec(c->s32, c->s64, c->n, c->strip_col0, c->s_cols, v_dev, m_dev, matrix_mean, c->strip_ws,
+                                   c->stream));
+  }
+  HIP_TRY(c, hipMemcpyAsync(y_out, c->strip_ws, sizeof(double) * (size_t)c->s_cols, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return PCOA_OK;
 }
 

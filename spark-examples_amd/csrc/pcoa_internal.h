@@ -72,10 +72,17 @@ hipError_t launch_pack_fp4(const void* x, int is_u8, int64_t ld, int64_t nv, int
 bool pack_fp4_ring_ok(const void* x, int64_t ld);
 hipError_t launch_pack_fp4_ring(const float* x, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
                                 hipStream_t stream, int64_t nkb_out, int wgs, int nt);
+// Strip owner (SURVEY 8e, N beyond one HBM): the launch computes S[:, col0 .. col0 + cols) -- every row block against the
+// column blocks of the strip, BOTH triangles -- into a row-major [n][cols] matrix.  cols == 0: the ordinary symmetric job.
+struct GramStrip {
+  int col0 = 0, cols = 0;
+  int cb0 = 0;  // first column block (filled in by the launcher)
+};
 // skip (optional, device): the launch does nothing when *skip != 0 -- the auto mode's device-side predicate (a pre-pass
 // found a value other than 0 / 1 in the buffered tiles; the host learns it later and redoes them on the int8 kernel)
 hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, int32_t* s32, int num_cu,
-                              hipStream_t stream, int* splitk_out, const int32_t* skip = nullptr);
+                              hipStream_t stream, int* splitk_out, const int32_t* skip = nullptr,
+                              GramStrip strip = GramStrip{});
 // Lock-step launch: all tiles of `splitk` k-streams resident at once, one workgroup per CU for the whole launch.
 // gram_lockstep_splitk: the k-stream count that fits `cus` CUs (8 XCDs), 0 if the shape does not fit.
 int gram_lockstep_splitk(int32_t n, int cus);
@@ -104,6 +111,17 @@ hipError_t launch_synth_fill_f32(uint64_t seed, const uint32_t* thresholds_dev, 
 hipError_t launch_col_means(const double* row_sums, int32_t n, double* cm, hipStream_t stream);
 hipError_t launch_center(const int32_t* s32, const int64_t* s64_or_null, int32_t n, double* row_sums,
                          double* stats, int32_t* nz, double* b, hipStream_t stream);
+
+// ---- strip owner reductions (center.hip): S is [n][cols], column jj = sample col0 + jj
+// ws: strip_ws_doubles(n, cols) doubles; the result (cols doubles) lands at ws[0 .. cols)
+int64_t strip_ws_doubles(int32_t n, int32_t cols);
+// column sums = the row sums of S for the strip's samples (S symmetric), exact integers as doubles
+hipError_t launch_strip_col_sums(const int32_t* s32, const int64_t* s64_or_null, int32_t n, int32_t cols, double* ws,
+                                 hipStream_t stream);
+// y[jj] = sum_i B(col0 + jj, i) v[i],  B(j, i) = ((S(i, jj) - means[j]) - means[i]) + matrix_mean: row j of the centred
+// matrix in the reference's operation order (VariantsPca.scala:216-221), from the strip's column (S is symmetric)
+hipError_t launch_strip_matvec(const int32_t* s32, const int64_t* s64_or_null, int32_t n, int32_t col0, int32_t cols,
+                               const double* v, const double* means, double matrix_mean, double* ws, hipStream_t stream);
 
 // ---- symmetric eigensolver (eig.hip) ----------------------------------------------------------
 struct EigWorkspace {

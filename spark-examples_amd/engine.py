@@ -26,10 +26,11 @@ def _ptr(a):
 
 
 class PcoaEngine(object):
-    def __init__(self, n_samples, device=0, flags=L.PCOA_FLAG_DEFAULT, gram_kernel=None, eig=None):
+    def __init__(self, n_samples, device=0, flags=L.PCOA_FLAG_DEFAULT, gram_kernel=None, eig=None, strip=None):
         """gram_kernel: None/"auto" (MX-FP4 MFMA for binary tiles, int8 MFMA for multiplicities; both exact),
         "fp4", "i8" (force one of them) or "f32" (fp32-MFMA path).
-        eig: None/"auto" (Lanczos with verified residual, Householder fallback), "householder", "lanczos"."""
+        eig: None/"auto" (Lanczos with verified residual, Householder fallback), "householder", "lanczos".
+        strip: None, or (col0, cols): a strip owner holding S[:, col0:col0+cols] (pcoa_create_strip; see strips.py)."""
         if eig == "householder":
             flags |= L.PCOA_FLAG_EIG_HOUSEHOLDER
         elif eig == "lanczos":
@@ -46,12 +47,18 @@ class PcoaEngine(object):
             raise ValueError("gram_kernel must be 'auto', 'fp4', 'i8' or 'f32'")
         self._lib = L.load()
         self._ctx = ctypes.c_void_p()
-        rc = self._lib.pcoa_create(ctypes.byref(self._ctx), int(n_samples), int(device), int(flags))
+        self.strip = None if strip is None else (int(strip[0]), int(strip[1]))
+        if self.strip is None:
+            rc = self._lib.pcoa_create(ctypes.byref(self._ctx), int(n_samples), int(device), int(flags))
+        else:
+            rc = self._lib.pcoa_create_strip(ctypes.byref(self._ctx), int(n_samples), self.strip[0], self.strip[1],
+                                             int(device), int(flags))
         if rc != L.PCOA_OK:
             msg = self._lib.pcoa_last_error(None)
             self._ctx = None
             raise PcoaError(rc, msg.decode() if msg else "pcoa_create failed")
         self.n = int(n_samples)
+        self.cols = self.n if self.strip is None else self.strip[1]   # columns of S this ctx holds
         self.device = int(device)
         self._keepalive = []
 
@@ -214,7 +221,7 @@ class PcoaEngine(object):
 
     def gram(self):
         """All N^2 entries of S as int64 (zeros included, as matrix.iterator emits them, :189)."""
-        out = np.zeros((self.n, self.n), dtype=np.int64)
+        out = np.zeros((self.n, self.cols), dtype=np.int64)   # a strip owner holds N x cols
         self._check(self._lib.pcoa_gram_read_i64(self._ctx, _ptr(out)))
         return out
 
@@ -226,8 +233,8 @@ class PcoaEngine(object):
 
     def load_gram(self, s):
         a = np.ascontiguousarray(s, dtype=np.int64)
-        if a.shape != (self.n, self.n):
-            raise ValueError("expected an %d x %d matrix" % (self.n, self.n))
+        if a.shape != (self.n, self.cols):
+            raise ValueError("expected an %d x %d matrix" % (self.n, self.cols))
         self._check(self._lib.pcoa_gram_load_i64(self._ctx, _ptr(a)))
 
     def export_device(self, dst_ptr):
@@ -254,6 +261,23 @@ class PcoaEngine(object):
 
     def allreduce_rccl(self, comm):
         self._check(self._lib.pcoa_gram_allreduce_rccl(self._ctx, comm))
+
+    # ------------------------------------------------------------------ strip owner
+    def strip_col_sums(self):
+        """rowSums (VariantsPca.scala:206) of the strip's samples: column sums of the held N x cols block."""
+        out = np.zeros(self.cols, dtype=np.float64)
+        self._check(self._lib.pcoa_strip_col_sums(self._ctx, _ptr(out)))
+        return out
+
+    def strip_matvec(self, v, means, matrix_mean):
+        """(B v)[col0:col0+cols] with B evaluated on the fly from the strip (VariantsPca.scala:216-221 order)."""
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        means = np.ascontiguousarray(means, dtype=np.float64)
+        if v.shape != (self.n,) or means.shape != (self.n,):
+            raise ValueError("v and means must have N = %d entries" % self.n)
+        out = np.zeros(self.cols, dtype=np.float64)
+        self._check(self._lib.pcoa_strip_matvec(self._ctx, _ptr(v), _ptr(means), float(matrix_mean), _ptr(out)))
+        return out
 
     # ------------------------------------------------------------------ computePca
     def center(self, want_matrix=True):

@@ -1,0 +1,143 @@
+"""computePca over a similarity matrix that is TILED ACROSS GPUs (BASELINE configs[4]).
+
+When N x N does not fit one HBM (N = 250,000: 250 GB of int32), the variant-sharded layout of dist.py -- every GPU a
+full partial S, one all-reduce -- no longer applies.  The matrix is then tiled by columns: owner g holds
+S[:, c_g : c_g + w_g] (pcoa_create_strip), every owner is fed ALL variants (bitsets: 31 KB per variant at N = 250,000),
+and nothing N x N ever moves.  computePca (VariantsPca.scala:198-231) becomes
+
+  rowSums, matrixMean (:206-211)   column sums of the strips, concatenated (all-gather of N doubles); exact integers
+  centring (:216-221)              never materialised: each owner evaluates its rows of B inside its mat-vec, in the
+                                   reference's operation order
+  principal components (:224-227)  Lanczos with full re-orthogonalisation on B: one mat-vec per step = one
+                                   pcoa_strip_matvec per owner + an all-gather of the N-vector; the Krylov basis
+                                   (N x m doubles) and the m x m tridiagonal live on the host, replicated on every rank;
+                                   a Ritz pair is accepted on its TRUE residual ||B u - theta u||, as in the single-GPU
+                                   engine (csrc/eig_lanczos.hip)
+
+A dense Householder factorisation of a 250 GB matrix "on rank 0" is not an option, which is why this path has no
+dense fallback: no verified pair -> RuntimeError.
+
+The strip owners are anything with .n, .strip = (col0, cols), .strip_col_sums() and .strip_matvec(v, means, mean):
+PcoaEngine(strip=...) on a GPU, or a numpy stand-in in the CPU tests.  `gather` concatenates the per-owner pieces over
+the ranks of a process group (identity for a single process).
+"""
+import numpy as np
+
+
+def strip_ranges(n_samples, n_owners, align=256):
+    """Column ranges of `n_owners` strips tiling [0, N): balanced, cut at multiples of `align` (the contraction's tile
+    width) wherever that leaves every owner something."""
+    n, g = int(n_samples), int(n_owners)
+    if g <= 0 or g > n:
+        raise ValueError("need 1 <= owners <= N")
+    cuts = [0]
+    for k in range(1, g):
+        c = n * k // g
+        a = (c + align // 2) // align * align
+        cuts.append(a if cuts[-1] < a < n else c)
+    cuts.append(n)
+    if any(cuts[i + 1] <= cuts[i] for i in range(g)):
+        cuts = [n * k // g for k in range(g + 1)]
+    return [(cuts[i], cuts[i + 1] - cuts[i]) for i in range(g)]
+
+
+def gather_concat(pieces, group=None):
+    """Concatenation, in rank order, of every rank's list of 1-D float64 arrays (torch.distributed all_gather_object
+    for the ragged widths: an N-vector per Lanczos step is small).  A single process returns its own concatenation."""
+    local = np.concatenate([np.asarray(p, dtype=np.float64) for p in pieces]) if pieces else np.zeros(0)
+    try:
+        import torch.distributed as dist
+    except Exception:  # pragma: no cover
+        return local
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    out = [None] * dist.get_world_size(group)
+    dist.all_gather_object(out, local, group=group)
+    return np.concatenate(out)
+
+
+def _sign_normalize(u):
+    """largest-magnitude entry positive, ties -> lowest index (the engine's and the oracle's convention)"""
+    u = np.array(u, dtype=np.float64, copy=True)
+    for c in range(u.shape[1]):
+        i = int(np.argmax(np.abs(u[:, c])))
+        if u[i, c] < 0:
+            u[:, c] = -u[:, c]
+    return u
+
+
+def compute_pca_over_strips(owners, num_pc=2, group=None, max_steps=512, tol=1e-11, first_check=12, trace=None):
+    """computePca for strip owners.  `owners`: this rank's owners in column order; over all ranks (in rank order) the
+    strips must tile [0, N).  Returns (components [N, k] sign-normalised unit columns, eigenvalues [k], nonzero_rows).
+    MLlib ranks components by |lambda| (singular values of the covariance); B = J S J is positive semi-definite up to
+    rounding, so the largest eigenvalues are taken, as the engine's Lanczos path does."""
+    if not owners:
+        raise ValueError("no strip owners on this rank")
+    n = int(owners[0].n)
+    k = int(num_pc)
+    if not (0 < k <= n):
+        raise ValueError("num_pc = %d out of range (0, n = %d]" % (k, n))    # MLlib: require(k > 0 && k <= n)
+    rs = gather_concat([o.strip_col_sums() for o in owners], group)
+    if rs.shape != (n,):
+        raise ValueError("the strips cover %d columns, N = %d" % (rs.shape[0], n))
+    nonzero = int((rs > 0).sum())                                            # :207
+    rc = float(n)
+    matrix_mean = float(rs.sum()) / rc / rc                                  # :210-211 (integers < 2^53: any order)
+    means = rs / rc                                                          # rowSums(i) / N, reused as column means
+
+    def matvec(v):
+        return gather_concat([o.strip_matvec(v, means, matrix_mean) for o in owners], group)
+
+    # deterministic start vector (the same LCG stream on every rank)
+    idx = np.arange(1, n + 1, dtype=np.uint64)
+    s = (idx * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)
+    s = (s * np.uint64(1103515245) + np.uint64(12345)) & np.uint64(0xFFFFFFFF)
+    s ^= s >> np.uint64(15)
+    s = (s * np.uint64(1103515245) + np.uint64(12345)) & np.uint64(0xFFFFFFFF)
+    v = (s >> np.uint64(8)).astype(np.float64) * (1.0 / 8388608.0) - 1.0
+    v /= np.linalg.norm(v)
+
+    mmax = int(min(max_steps, n))
+    basis = np.zeros((mmax + 1, n), dtype=np.float64)
+    basis[0] = v
+    alpha, beta = [], []
+    next_check = max(k + 1, min(first_check, mmax))
+    for j in range(mmax):
+        w = matvec(basis[j])
+        a = float(basis[j] @ w)
+        alpha.append(a)
+        # full re-orthogonalisation, twice (classical Gram-Schmidt x 2)
+        for _ in range(2):
+            w -= basis[:j + 1].T @ (basis[:j + 1] @ w)
+        b = float(np.linalg.norm(w))
+        m = j + 1
+        breakdown = b <= 1e-14 * max(1.0, max(abs(x) for x in alpha))
+        if m >= next_check or breakdown or m == mmax:
+            t = np.diag(alpha) + np.diag(beta, 1) + np.diag(beta, -1)
+            lam, y = np.linalg.eigh(t)
+            order = np.argsort(-lam)[:k]
+            theta = lam[order]
+            scale = float(np.max(np.abs(lam)))
+            est = np.abs(b * y[-1, order])
+            gaps = np.array([np.min(np.abs(np.delete(lam, order[c]) - theta[c])) if m > 1 else scale for c in range(len(order))])
+            ok = len(order) == k and bool(np.all(est <= tol * scale) and np.all(est <= 1e-8 * gaps))
+            if trace is not None:
+                trace.append((m, theta.copy(), est.copy()))
+            if ok or breakdown:
+                u = basis[:m].T @ y[:, order]
+                u /= np.linalg.norm(u, axis=0)
+                # accept only on the TRUE residual (one more mat-vec per vector)
+                good = len(order) == k
+                for c in range(len(order)):
+                    r = matvec(u[:, c]) - theta[c] * u[:, c]
+                    res = float(np.linalg.norm(r))
+                    good = good and res <= max(tol * scale * 10.0, 1e-9 * abs(theta[c])) and res <= 1e-6 * max(gaps[c], 1e-300)
+                if good:
+                    return _sign_normalize(u), theta.copy(), nonzero
+            next_check = m + (4 if m < 24 else 8)
+        if breakdown or m == mmax:
+            break
+        beta.append(b)
+        basis[j + 1] = w / b
+    raise RuntimeError("Lanczos over strips did not reach a verified residual in %d steps (tiny spectral gaps?); "
+                       "there is no dense fallback for a matrix tiled across GPUs" % len(alpha))

@@ -1,0 +1,89 @@
+"""GPU tests of the strip-owner mode (SURVEY 8e / BASELINE configs[4]: S tiled across HBMs).  One GPU plays every
+owner in turn: the strips must tile the full engine's S bit for bit, and computePca over the strips must agree with the
+single-engine path and the oracle."""
+import numpy as np
+import pytest
+
+from conftest import align_sign, load_oracle, load_pkg, planted_callsets
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P():
+    return load_pkg()
+
+
+@pytest.fixture(scope="module")
+def O():
+    return load_oracle()
+
+
+def test_strips_tile_the_full_similarity_matrix_and_give_the_same_pca(P, O):
+    """N = 6000 (24 tile columns), three owners with ragged, non-tile-aligned strips, each fed the whole cohort through a
+    different boundary (fp32 tile, bitsets, carrier lists)."""
+    strips = load_pkg("strips")
+    ingest = load_pkg("ingest")
+    rng = np.random.default_rng(60)
+    n, v = 6000, 4000
+    x = planted_callsets(rng, n, v, k=4)
+    with P.PcoaEngine(n) as full:
+        full.accumulate_dense(x)
+        s_full = full.gram()
+        comps_full, lam_full, nz_full = full.compute(2)
+    ranges = [(0, 1000), (1000, 2777), (3777, 2223)]
+    offs = np.concatenate([[0], np.cumsum(x.sum(axis=1, dtype=np.int64))]).astype(np.int64)
+    idx = np.nonzero(x)[1].astype(np.int32)
+    feeders = [lambda e: e.accumulate_dense(x), lambda e: e.accumulate_bits(ingest.pack_bits(x)),
+               lambda e: e.accumulate_calls(idx, offs)]
+    owners = [P.PcoaEngine(n, strip=r) for r in ranges]
+    try:
+        for e, feed in zip(owners, feeders):
+            feed(e)
+        tiled = np.concatenate([e.gram() for e in owners], axis=1)
+        assert tiled.shape == (n, n) and np.array_equal(tiled, s_full)             # bit for bit, both triangles
+        for e, (c0, w) in zip(owners, ranges):
+            assert np.array_equal(e.strip_col_sums(), s_full[:, c0:c0 + w].sum(axis=0).astype(np.float64))
+            assert np.array_equal(e.gram_block(17, 5, 40, min(30, w - 5)), s_full[17:57, c0 + 5:c0 + 5 + min(30, w - 5)])
+        comps, lam, nz = strips.compute_pca_over_strips(owners, 2)
+        assert nz == nz_full
+        assert np.max(np.abs(lam - lam_full) / np.abs(lam_full)) < 1e-10
+        assert np.abs(align_sign(comps, comps_full) - comps_full).max() < 1e-9
+        ref = O.compute_pca(s_full, 2)
+        assert np.max(np.abs(lam - ref["eigenvalues"]) / np.abs(ref["eigenvalues"])) < 1e-6
+        got = align_sign(comps, ref["components"])
+        for c in range(2):
+            assert np.linalg.norm(got[:, c] - ref["components"][:, c]) < 1e-6
+        # a strip is additive and resumable like the full matrix; multiplicities take its int8 path
+        e = owners[1]
+        before = e.gram()
+        xm = x[:50].copy()
+        xm[3, 1500] = 4.0
+        e.accumulate_dense(xm)
+        want = before + (xm.T.astype(np.int64) @ xm.astype(np.int64))[:, 1000:3777]
+        assert np.array_equal(e.gram(), want)
+        e.load_gram(before)
+        assert np.array_equal(e.gram(), before)
+        # what a strip owner cannot do says so
+        with pytest.raises(P.PcoaError) as ei:
+            e.compute(2)
+        assert ei.value.code == -8
+        with pytest.raises(P.PcoaError):
+            e.center()
+    finally:
+        for e in owners:
+            e.close()
+
+
+def test_strip_creation_is_validated(P):
+    for bad in ((-1, 10), (0, 0), (90, 20), (100, 1)):
+        with pytest.raises(P.PcoaError):
+            P.PcoaEngine(100, strip=bad)
+    with pytest.raises(P.PcoaError):
+        P.PcoaEngine(100, strip=(0, 50), gram_kernel="f32")
+    with P.PcoaEngine(100, strip=(99, 1)) as e:
+        e.accumulate_callsets([[0, 99], [99], [5, 6]])
+        assert e.gram().ravel().tolist() == [1 if i == 0 else (2 if i == 99 else 0) for i in range(100)]
+    with P.PcoaEngine(100) as e:
+        with pytest.raises(P.PcoaError):
+            e.strip_col_sums()

@@ -1,0 +1,118 @@
+"""CPU tests of the strip-owner computePca (spark-examples_amd/strips.py): the host-driven Lanczos over
+column strips of S, with numpy stand-ins for the GPU strip owners (the same interface: .n, .strip, .strip_col_sums(),
+.strip_matvec()), single-process and over two gloo ranks."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, align_sign, load_oracle, load_pkg, planted_callsets
+
+
+class HostStrip(object):
+    """numpy stand-in for PcoaEngine(strip=(col0, cols)): holds S[:, col0:col0+cols] and evaluates the rows of B in the
+    reference's operation order, as csrc/center.hip: strip_band_kernel does."""
+
+    def __init__(self, s_full, col0, cols):
+        self.n = s_full.shape[0]
+        self.strip = (col0, cols)
+        self.s = np.ascontiguousarray(s_full[:, col0:col0 + cols]).astype(np.float64)
+
+    def strip_col_sums(self):
+        return self.s.sum(axis=0)
+
+    def strip_matvec(self, v, means, matrix_mean):
+        col0, cols = self.strip
+        b = ((self.s - means[col0:col0 + cols][None, :]) - means[:, None]) + matrix_mean   # B(j, i) at [i, jj]
+        return b.T @ v
+
+
+def _cohort(seed, n, v):
+    rng = np.random.default_rng(seed)
+    return planted_callsets(rng, n, v)
+
+
+def test_strip_ranges_tile_the_samples():
+    strips = load_pkg("strips")
+    for n, g in ((2504, 8), (250000, 8), (6000, 3), (10, 10), (7, 2), (300, 4)):
+        r = strips.strip_ranges(n, g)
+        assert len(r) == g and r[0][0] == 0 and sum(w for _, w in r) == n
+        assert all(r[i][0] + r[i][1] == r[i + 1][0] for i in range(g - 1)) and all(w > 0 for _, w in r)
+    assert all(c % 256 == 0 for c, _ in strips.strip_ranges(250000, 8))   # cut at tile edges when there is room
+    with pytest.raises(ValueError):
+        strips.strip_ranges(3, 5)
+
+
+@pytest.mark.parametrize("ranges", [[(0, 300)], [(0, 100), (100, 57), (157, 143)], [(0, 1), (1, 298), (299, 1)]])
+def test_lanczos_over_strips_matches_the_oracle(ranges):
+    strips = load_pkg("strips")
+    oracle = load_oracle()
+    x = _cohort(11, 300, 1500)
+    s = oracle.similarity_from_dense(x, 300)
+    ref = oracle.compute_pca(s, 3)
+    owners = [HostStrip(s, c0, w) for c0, w in ranges]
+    trace = []
+    comps, lam, nz = strips.compute_pca_over_strips(owners, 3, trace=trace)
+    assert nz == ref["nonzero_rows"] and len(trace) >= 1
+    assert np.max(np.abs(lam - ref["eigenvalues"]) / np.abs(ref["eigenvalues"])) < 1e-9
+    assert np.abs(align_sign(comps, ref["components"]) - ref["components"]).max() < 1e-8
+    assert np.allclose(np.linalg.norm(comps, axis=0), 1.0, atol=1e-12)
+    # sign convention: the largest-magnitude entry of every component is positive
+    assert all(comps[np.argmax(np.abs(comps[:, c])), c] > 0 for c in range(3))
+    with pytest.raises(ValueError):
+        strips.compute_pca_over_strips(owners[:1] if len(owners) > 1 else [HostStrip(s, 0, 299)], 2)   # strips do not tile N
+    with pytest.raises(ValueError):
+        strips.compute_pca_over_strips(owners, 0)
+
+
+def test_no_verified_pair_is_an_error_not_a_guess():
+    """identical samples: B = 0, every Ritz value is 0 with no gap -- nothing can be verified and nothing is returned"""
+    strips = load_pkg("strips")
+    s = np.full((40, 40), 7, dtype=np.int64)
+    with pytest.raises(RuntimeError):
+        strips.compute_pca_over_strips([HostStrip(s, 0, 40)], 2)
+
+
+def _free_port():
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    p = sk.getsockname()[1]
+    sk.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as td
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    strips = load_pkg("strips")
+    oracle = load_oracle()
+    oracle.set_num_threads(1)
+    x = _cohort(23, 257, 1200)
+    s = oracle.similarity_from_dense(x, 257)
+    ranges = strips.strip_ranges(257, 3, align=64)
+    mine = ranges[:2] if rank == 0 else ranges[2:]            # rank 0 owns two strips, rank 1 one: ragged all-gather
+    owners = [HostStrip(s, c0, w) for c0, w in mine]
+    comps, lam, nz = strips.compute_pca_over_strips(owners, 2)
+    np.savez(os.path.join(out_dir, "r%d.npz" % rank), comps=comps, lam=lam, nz=nz)
+    td.barrier()
+    td.destroy_process_group()
+
+
+def test_two_ranks_all_gather_their_strips(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    oracle = load_oracle()
+    x = _cohort(23, 257, 1200)
+    ref = oracle.compute_pca(oracle.similarity_from_dense(x, 257), 2)
+    got = [np.load(os.path.join(str(tmp_path), "r%d.npz" % r)) for r in range(2)]
+    assert np.array_equal(got[0]["comps"], got[1]["comps"]) and np.array_equal(got[0]["lam"], got[1]["lam"])   # replicated
+    assert int(got[0]["nz"]) == ref["nonzero_rows"]
+    assert np.max(np.abs(got[0]["lam"] - ref["eigenvalues"]) / np.abs(ref["eigenvalues"])) < 1e-9
+    assert np.abs(align_sign(got[0]["comps"], ref["components"]) - ref["components"]).max() < 1e-8
