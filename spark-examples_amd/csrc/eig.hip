@@ -205,6 +205,124 @@ __global__ __launch_bounds__(256) void tridiag_update_kernel(double* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// K3 fused: ONE launch per Householder step (the two-kernel form above pays two kernel boundaries per column and is
+// latency-bound: 17 us per column at N = 2504).  Every workgroup first recomputes the short serial part of step k for
+// itself, into LDS -- w_{k-1} from the raw mat-vec q_{k-1}, column k of the updated matrix, the reflector v_k -- and
+// then does its share of the parallel part with v_{k-1}, w_{k-1}, v_k served from LDS: the rank-2 update of step k-1 on
+// its rows and q_k = A v_k in the same pass.  Nothing a workgroup needs is produced by another workgroup of the same
+// launch: q and the current reflector are double-buffered across launches (q[k & 1], vbuf[k & 1]); workgroup 0 is the
+// one that publishes d, e, tau, v_k, and moves v_{k-1} into row k-1 of A (dead for everybody by then) for the
+// back-transform.  Rows are dealt to workgroups by ABSOLUTE index (row i -> workgroup i mod gridDim, so XCD i mod 8
+// whatever k is): a row's 20 KB stay in the same XCD's L2 from step to step instead of migrating as the trailing block
+// shrinks.  Same formulas as tridiag_hw_kernel / tridiag_update_kernel; only the order of the reductions differs.
+// LDS: 3 (n - k) doubles (v_{k-1}, w_{k-1}, v_k), i.e. n <= 2,730 without raising the dynamic-LDS limit, n <= 6,800 with.
+constexpr int FT = 512;  // threads of a fused-step workgroup: 8 waves share one copy of the three vectors
+__global__ __launch_bounds__(FT) void tridiag_fused_kernel(double* __restrict__ a, int n, int k, double* __restrict__ d,
+                                                            double* __restrict__ e, double* __restrict__ tau,
+                                                            const double* __restrict__ q_in, double* __restrict__ q_out,
+                                                            const double* __restrict__ v_in, double* __restrict__ v_out) {
+  extern __shared__ __attribute__((aligned(16))) double fl[];
+  __shared__ double red[24];
+  const int tid = threadIdx.x;
+  const int len = n - k;            // active indices k .. n-1 <-> 0 .. len-1
+  double* vp = fl;                  // v_{k-1}
+  double* wl = fl + len;            // w_{k-1}
+  double* vk = fl + 2 * len;        // v_k
+  const bool pending = k > 0;
+  double* rowk = a + (int64_t)k * n;
+  // ---- serial part of step k, redundantly per workgroup
+  double wk = 0.0, vpk = 0.0;
+  if (pending) {
+    const double tp = tau[k - 1];
+    double part = 0.0;
+    for (int j = tid; j < len; j += FT) {
+      const double vj = v_in[k + j];
+      vp[j] = vj;
+      part += q_in[k + j] * vj;
+    }
+    const double dot = block_reduce<0>(part, red);
+    const double c = 0.5 * tp * tp * dot;
+    for (int j = tid; j < len; j += FT) wl[j] = tp * q_in[k + j] - c * vp[j];
+    __syncthreads();
+    wk = wl[0];
+    vpk = vp[0];
+    if (blockIdx.x == 0) {  // the reflector of step k-1 moves to its final place: row k-1, columns k .. n-1
+      double* rowp = a + (int64_t)(k - 1) * n;
+      for (int j = tid; j < len; j += FT) rowp[k + j] = vp[j];
+    }
+  }
+  double part = 0.0, alpha = 0.0;
+  for (int j = 1 + tid; j < len; j += FT) {
+    double xj = rowk[k + j];
+    if (pending) xj -= vpk * wl[j] + wk * vp[j];
+    vk[j] = xj;
+    if (j == 1) alpha = xj; else part += xj * xj;
+  }
+  const double xnorm2 = block_reduce<0>(part, red);
+  if (tid == 0) red[21] = alpha;    // thread 0 owns j = 1
+  __syncthreads();
+  alpha = red[21];
+  double beta, t, scale;
+  if (xnorm2 == 0.0) {
+    beta = alpha; t = 0.0; scale = 0.0;
+  } else {
+    beta = -copysign(sqrt(alpha * alpha + xnorm2), alpha);
+    t = (beta - alpha) / beta;
+    scale = 1.0 / (alpha - beta);
+  }
+  for (int j = 1 + tid; j < len; j += FT) vk[j] = (j == 1) ? 1.0 : vk[j] * scale;
+  if (tid == 0) vk[0] = 0.0;
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    for (int j = tid; j < len; j += FT) v_out[k + j] = vk[j];
+    if (tid == 0) {
+      d[k] = pending ? rowk[k] - 2.0 * vpk * wk : rowk[k];
+      e[k] = beta;
+      tau[k] = t;
+    }
+  }
+  // ---- parallel part: rows i > k with i mod gridDim == blockIdx, one wave per row at a time
+  const int lane = tid & 63, wave = tid >> 6;
+  const int nb = (int)gridDim.x;
+  int first = (k + 1) + ((int)blockIdx.x - (k + 1) % nb + nb) % nb;   // smallest i >= k+1 with i mod nb == blockIdx
+  for (int i = first + wave * nb; i < n; i += (FT / 64) * nb) {
+    double* row = a + (int64_t)i * n + k;   // row[j] <-> column k + j
+    const double vpi = pending ? vp[i - k] : 0.0, wpi = pending ? wl[i - k] : 0.0;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    int j = 1 + lane;
+    if (pending) {
+      for (; j + 192 < len; j += 256) {
+        const double r0 = row[j], r1 = row[j + 64], r2 = row[j + 128], r3 = row[j + 192];
+        const double a0 = r0 - (vpi * wl[j] + wpi * vp[j]);
+        const double a1 = r1 - (vpi * wl[j + 64] + wpi * vp[j + 64]);
+        const double a2 = r2 - (vpi * wl[j + 128] + wpi * vp[j + 128]);
+        const double a3 = r3 - (vpi * wl[j + 192] + wpi * vp[j + 192]);
+        row[j] = a0; row[j + 64] = a1; row[j + 128] = a2; row[j + 192] = a3;
+        acc0 += a0 * vk[j];
+        acc1 += a1 * vk[j + 64];
+        acc2 += a2 * vk[j + 128];
+        acc3 += a3 * vk[j + 192];
+      }
+      for (; j < len; j += 64) {
+        const double aij = row[j] - (vpi * wl[j] + wpi * vp[j]);
+        row[j] = aij;
+        acc0 += aij * vk[j];
+      }
+    } else {
+      for (; j + 192 < len; j += 256) {
+        acc0 += row[j] * vk[j];
+        acc1 += row[j + 64] * vk[j + 64];
+        acc2 += row[j + 128] * vk[j + 128];
+        acc3 += row[j + 192] * vk[j + 192];
+      }
+      for (; j < len; j += 64) acc0 += row[j] * vk[j];
+    }
+    const double acc = wave_sum((acc0 + acc1) + (acc2 + acc3));
+    if (lane == 0) q_out[i] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K4a: eigenvalue number idx[b] (ascending, 0-based) of the symmetric tridiagonal T(d, e) by
 // multisection on the Sturm count (LAPACK dstebz's recurrence, 256 shifts per round).
 //   count(x) = #{ i : q_i < 0 },  q_0 = d_0 - x,  q_i = d_i - x - e_{i-1}^2 / q_{i-1}
@@ -474,7 +592,40 @@ hipError_t launch_tridiagonalize(const EigWorkspace& ws, int32_t n, hipStream_t 
                        ws.w);
     return hipGetLastError();
   }
-  for (int k = 0; k <= n - 2; ++k) {
+  // Fused form (one launch per column) while v_{k-1}, w_{k-1}, v_k fit the LDS: n <= 6,800.  ws.w is 2 n doubles and
+  // ws.scratch 6 n: q is double-buffered in ws.w, the current reflector in ws.scratch.
+  const size_t lds_full = 3 * (size_t)n * sizeof(double);
+  int kf = 0;  // columns [0, kf) take the fused kernel
+  if (n >= 8 && lds_full <= 160 * 1024 - 1024) {
+    if (lds_full > 64 * 1024) {
+      static bool raised = false;  // opt in to more than 64 KiB of dynamic LDS once
+      if (!raised) {
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(tridiag_fused_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (err != hipSuccess) return err;
+        raised = true;
+      }
+    }
+    kf = n - 2;  // steps 0 .. n-3 generate a reflector; step n-2 only closes d / e (tridiag_hw_kernel below)
+    double* qb[2] = {ws.w, ws.w + n};
+    double* vb[2] = {ws.scratch, ws.scratch + n};
+    for (int k = 0; k < kf; ++k) {
+      const int rows = n - k - 1;
+      int nb = (rows + FT / 64 - 1) / (FT / 64);   // at least one row per wave ...
+      if (nb > 256) nb = 256;                      // ... at most one workgroup per CU: every workgroup re-reads q and v
+      nb = (nb + 7) / 8 * 8;                       // a multiple of the XCD count keeps row -> XCD fixed
+      const size_t lds = 3 * (size_t)(n - k) * sizeof(double);
+      hipLaunchKernelGGL(tridiag_fused_kernel, dim3((unsigned)nb), dim3(FT), lds, stream, ws.a, n, k, ws.d, ws.e, ws.tau,
+                         qb[(k + 1) & 1], qb[k & 1], vb[(k + 1) & 1], vb[k & 1]);
+    }
+    // hand over to the closing step: it expects v_{n-3} in row n-3 and the raw mat-vec of step n-3 in ws.q
+    hipError_t err = hipMemcpyAsync(ws.a + (int64_t)(kf - 1) * n + kf, vb[(kf - 1) & 1] + kf, sizeof(double) * (size_t)(n - kf),
+                                    hipMemcpyDeviceToDevice, stream);
+    if (err != hipSuccess) return err;
+    err = hipMemcpyAsync(ws.q, qb[(kf - 1) & 1], sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream);
+    if (err != hipSuccess) return err;
+  }
+  for (int k = kf; k <= n - 2; ++k) {
     const int hw_threads = HW_T;  // 256 threads were measured slower (7.6 vs 6.0 us per step at N = 2504)
     hipLaunchKernelGGL(tridiag_hw_kernel, dim3(1), dim3(hw_threads), 0, stream, ws.a, n, k, ws.d, ws.e, ws.tau,
                        ws.q, ws.w);
