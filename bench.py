@@ -229,8 +229,9 @@ def main():
                 "pipeline_launches": int(tim["pipeline_launches"]), "lockstep_launches": int(tim["lockstep_launches"]),
                 "pipeline_pre_pass_cus": int(tim["pipeline_pre_pass_cus"]),
                 "pipeline_contraction_cus": int(tim["pipeline_contraction_cus"]),
-                "what": "fp32 tiles at this N: the pre-pass of operand buffer k+1 runs on a CU-masked stream beside the lock-step "
-                        "contraction of buffer k on the complementary CUs (DESIGN.md 4.1); PCOA_PIPELINE=0 disables it"}
+                "what": "fp32 tiles at this N: the pre-pass of operand buffer k+1 runs beside the lock-step contraction of buffer k "
+                        "(one workgroup per CU on pipeline_contraction_cus CUs, placed first; the pre-pass cannot share a CU "
+                        "with it and takes the rest) -- DESIGN.md 4.1; PCOA_PIPELINE=0 disables it"}
         kern_s = tim["gram_kernel_seconds"] / launches           # average Gram-kernel launch duration (HIP events)
         vpl = tim["gram_variants"] / launches                    # variants per contraction launch
         flops_per_launch = 2.0 * vpl * n * n                     # algorithmic 2*V*N^2
@@ -293,10 +294,10 @@ def main():
                          "kernel": "pack_fp4_kernel<float, 4, true>" if kind == 3 else "pack_f32_i8_kernel<4>",
                          "avg_launch_ms": 1e3 * pack_s, "launches": pl}
             if pipe:
-                roof_pack["note"] = ("fp32 pipeline: this kernel runs on %d of the %d CUs (CU-masked stream) BESIDE the "
-                                     "contraction on the other %d, so its launch duration ~ the step; alone on the whole chip "
-                                     "it takes ~2.0 ms per 10^6 variants (profiles/r02*_overlap_harness.txt)"
-                                     % (pack_cus, cus, gram_cus))
+                roof_pack["note"] = ("fp32 pipeline: this kernel runs BESIDE the lock-step contraction of the previous buffer -- on the "
+                                     "%d of %d CUs the contraction's %d workgroups leave, and on all of them once it is done -- "
+                                     "so its launch duration ~ the step; alone on the whole chip it takes ~2.0 ms per 10^6 "
+                                     "variants (profiles/r02*_overlap_harness.txt)" % (pack_cus, cus, gram_cus))
         # the dominant kernel (larger share of the step) goes into `roofline`, the other into `roofline_other`
         if roof_pack is not None and tim["pack_seconds"] > tim["gram_kernel_seconds"]:
             roofline, roofline_other = roof_pack, roof_gram

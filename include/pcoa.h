@@ -83,10 +83,10 @@ typedef struct pcoa_timings {
   int32_t lanczos_steps;        /* Krylov dimension reached by the last pcoa_compute                  */
   int64_t fp4_fallbacks;        /* chunks the auto mode re-ran on the int8 kernel (non-binary values) */
   int64_t lockstep_launches;    /* contraction launches in the lock-step form (all tiles of a k-stream resident)  */
-  int64_t pipeline_launches;    /* of those: launched on the CU-masked contraction stream beside a pre-pass
+  int64_t pipeline_launches;    /* of those: launched on the contraction stream beside the next buffer's pre-pass
                                    (fp32 pipeline)                                                  */
-  int32_t pipeline_pre_pass_cus;    /* CUs the pre-pass stream owns when the pipeline runs (0 = pipeline unavailable) */
-  int32_t pipeline_contraction_cus; /* CUs of the contraction stream                                             */
+  int32_t pipeline_pre_pass_cus;    /* CUs left to the pre-pass while such a contraction runs (0 = pipeline unavailable) */
+  int32_t pipeline_contraction_cus; /* CUs that contraction occupies (one workgroup each)                        */
 } pcoa_timings;
 
 /* Synthetic genotype model (bench / tests only; not part of the reference).  Sample i belongs to

@@ -27,6 +27,8 @@
 // Bounds: K3 is HBM/L2-bandwidth- and launch-latency-bound (BLAS-2), K4/K5 are latency-bound;
 // the eigensolver is reported as wall-clock, not against a roofline.
 #include <cfloat>
+#include <algorithm>
+#include <cmath>
 
 #include "pcoa_internal.h"
 
@@ -424,7 +426,12 @@ __global__ __launch_bounds__(64) void invit_kernel(const double* __restrict__ d,
   const double tiny = fmax(DBL_EPSILON * tn, DBL_MIN / DBL_EPSILON);
   const double ortol = 1e-3 * tn;
 
-  for (int c = 0; c < k; ++c) {
+  // gridDim.x == 1: the k vectors one after the other (re-orthogonalisation inside clusters needs the earlier ones);
+  // gridDim.x == k: one workgroup per vector -- the host launches that form when no two selected eigenvalues are
+  // within ortol of each other, so that no vector waits for another
+  const int c_begin = (gridDim.x == 1) ? 0 : (int)blockIdx.x;
+  const int c_end = (gridDim.x == 1) ? k : (int)blockIdx.x + 1;
+  for (int c = c_begin; c < c_end; ++c) {
     double* zc = z + (int64_t)c * n;
     const double lc = lam[c];
     if (n == 1) {
@@ -500,7 +507,7 @@ __global__ __launch_bounds__(64) void invit_kernel(const double* __restrict__ d,
       const double inv = (mx > 0.0) ? 1.0 / mx : 1.0;
       for (int i = lane; i < n; i += 64) y[i] *= inv;
       __syncthreads();
-      for (int p = 0; p < c; ++p) {
+      for (int p = (gridDim.x == 1) ? 0 : c; p < c; ++p) {
         if (fabs(lam[p] - lc) <= ortol) {
           const double* zp = z + (int64_t)p * n;
           double dot = 0.0;
@@ -667,8 +674,20 @@ hipError_t launch_inverse_iteration(const EigWorkspace& ws, int32_t n, const dou
       raised = true;
     }
   }
-  hipLaunchKernelGGL(invit_kernel, dim3(1), dim3(64), use_lds ? lds : 0, stream, ws.d, ws.e, n, ws.lam, k, ws.z,
-                     ws.scratch, ws.iscratch, use_lds);
+  // One workgroup per vector when each has its own scratch (LDS) and no two selected eigenvalues can fall into one
+  // cluster (the kernel's ortol = 1e-3 max|T|; |T| <= 3 max(|d|, |e|) is not known here, so the test is against the
+  // largest selected |lambda| -- a lower bound of max|T| would be the unsafe direction, this one is an upper bound of
+  // nothing: hence the conservative factor 1e-2)
+  bool separate = use_lds && k > 1;
+  if (separate) {
+    double big = 0.0;
+    for (int c = 0; c < k; ++c) big = std::max(big, std::fabs(lam_sel_host[c]));
+    for (int c = 0; c < k && separate; ++c)
+      for (int p = 0; p < c; ++p)
+        if (std::fabs(lam_sel_host[c] - lam_sel_host[p]) <= 1e-2 * big) { separate = false; break; }
+  }
+  hipLaunchKernelGGL(invit_kernel, dim3(separate ? (unsigned)k : 1u), dim3(64), use_lds ? lds : 0, stream, ws.d, ws.e, n,
+                     ws.lam, k, ws.z, ws.scratch, ws.iscratch, use_lds);
   return hipGetLastError();
 }
 

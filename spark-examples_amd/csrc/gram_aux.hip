@@ -177,4 +177,17 @@ hipError_t launch_synth_fill_f32(uint64_t seed, const uint32_t* thresholds_dev, 
   return hipGetLastError();
 }
 
+namespace {
+// one wave that does nothing for `ticks` of the 100-MHz wall clock
+__global__ void delay_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+}  // namespace
+
+hipError_t launch_delay_us(hipStream_t stream, int microseconds) {
+  hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, stream, (long long)microseconds * 100);
+  return hipGetLastError();
+}
+
 }  // namespace pcoa

@@ -96,7 +96,7 @@ struct pcoa_ctx {
   int fb_count = 1, fb_active = 0;
   int32_t* fb_flags = nullptr;       // device: the flag word of buffer b at fb_flags[16 * b]
   int32_t* fb_flags_host = nullptr;  // pinned host copy, written by an async D2H behind each contraction
-  // fp32 pipeline: pre-pass and contraction on two streams with disjoint CU masks (16 + 16 CUs of every XCD)
+  // fp32 pipeline: the pre-pass of one buffer beside the lock-step contraction of the other, on two side streams
   bool pipe_ok = false;
   int pipe_gram_cus = 0;
   hipStream_t pack_stream = nullptr, gram_stream = nullptr;
@@ -323,9 +323,7 @@ int fork_to(pcoa_ctx* c, hipStream_t side) {
 int int8_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64_t ld);
 
 // Lazily creates what the FP4 path needs besides the operand memory: the buffer flags (device + pinned host), the
-// events, and -- where the shape fits -- the two CU-masked streams of the fp32 pipeline.  hipExtStreamCreateWithCUMask
-// mask bit g = CU g / 8 of XCD g % 8 (measured: profiles/r02a, r02f): the pre-pass gets CUs 0..15 of every XCD, the
-// contraction CUs 16..31.
+// events, and -- where the shape fits -- the two side streams of the fp32 pipeline.
 int fp4_setup(pcoa_ctx* c) {
   if (c->fb_flags) return PCOA_OK;
   HIP_TRY(c, hipMalloc((void**)&c->fb_flags, 256));
@@ -343,25 +341,26 @@ int fp4_setup(pcoa_ctx* c) {
   c->lockstep_ok = !c->is_strip && ls > 0 && gram_lockstep_workgroups(c->n, ls) * 5 >= c->num_cu * 4;
   if (k.lockstep == 0) c->lockstep_ok = false;
   if (k.lockstep == 1) c->lockstep_ok = !c->is_strip && ls > 0;
-  // fp32 pipeline: MI355X geometry (8 XCDs x 32 CUs) and a lock-step contraction that fills >= 80 % of half the chip
+  // fp32 pipeline: a lock-step contraction sized for HALF the chip (split-K 2 at N = 2504: 110 workgroups, one per CU)
+  // that fills >= 80 % of that half, beside the pre-pass on every CU it leaves.  No CU masks: a contraction workgroup
+  // takes 2 x 224 of a SIMD's 512 VGPRs, a pre-pass wave needs 96, so the two never share a CU (sharing one is
+  // negative-sum: the CU's vector-memory path returns in order) -- provided the contraction's workgroups are placed
+  // FIRST, which a 10-us one-wave spin in front of a generation's first pre-pass ensures (fp4_reserve).  Against
+  // static 16 + 16 CU masks (hipExtStreamCreateWithCUMask) this is 5 % faster: the pre-pass gets the 18 CUs the
+  // contraction does not use, and the whole chip once the contraction is done (profiles/r02n_overlap_harness.txt).
   const int half = c->num_cu / 2;
-  const int lsh = (c->num_cu == 256) ? gram_lockstep_splitk(c->n, half) : 0;
-  bool want = !c->is_strip && lsh > 0 && gram_lockstep_workgroups(c->n, lsh) * 5 >= half * 4;
+  const int lsh = gram_lockstep_splitk(c->n, half);
+  bool want = !c->is_strip && c->num_cu >= 64 && lsh > 0 && gram_lockstep_workgroups(c->n, lsh) * 5 >= half * 4;
   if (k.pipeline == 0) want = false;
   if (k.pipeline == 1) want = !c->is_strip && lsh > 0;
   if (want) {
-    uint32_t mp[8] = {0}, mg[8] = {0};
-    for (int g = 0; g < 256; ++g) {
-      if (g / 8 < 16) mp[g / 32] |= 1u << (g % 32);
-      else mg[g / 32] |= 1u << (g % 32);
-    }
-    hipError_t e1 = hipExtStreamCreateWithCUMask(&c->pack_stream, 8, mp);
-    hipError_t e2 = (e1 == hipSuccess) ? hipExtStreamCreateWithCUMask(&c->gram_stream, 8, mg) : e1;
+    hipError_t e1 = hipStreamCreateWithFlags(&c->pack_stream, hipStreamNonBlocking);
+    hipError_t e2 = (e1 == hipSuccess) ? hipStreamCreateWithFlags(&c->gram_stream, hipStreamNonBlocking) : e1;
     if (e1 == hipSuccess && e2 == hipSuccess) {
       c->pipe_ok = true;
       c->pipe_gram_cus = half;
       c->fb_count = 2;
-    } else {  // no CU-mask streams on this runtime: the serial path is what ships anyway
+    } else {
       (void)hipGetLastError();
       if (c->pack_stream) (void)hipStreamDestroy(c->pack_stream);
       c->pack_stream = c->gram_stream = nullptr;
@@ -546,7 +545,13 @@ int fp4_reserve(pcoa_ctx* c, int64_t kb, int64_t chunk_variants, bool deferrable
     b->fill_stream = c->stream;
     if (want_side) {
       const pcoa_ctx::Fp4Buf& o = c->fb[c->fb_active ^ 1];
-      if (o.launched && hipEventQuery(o.consumed) == hipErrorNotReady) b->fill_stream = c->pack_stream;
+      if (o.launched && hipEventQuery(o.consumed) == hipErrorNotReady) {
+        b->fill_stream = c->pack_stream;
+        // head start for the contraction that becomes runnable when the pre-pass queued in front of this one ends: its
+        // workgroups must find the CUs empty, the pre-pass then takes the CUs that are left (fp4_setup)
+        if ((rc = fork_to(c, c->pack_stream)) != PCOA_OK) return rc;
+        HIP_TRY(c, launch_delay_us(c->pack_stream, 10));
+      }
       (void)hipGetLastError();
     }
   }
@@ -1633,8 +1638,12 @@ int pcoa_get_timings(pcoa_ctx* c, pcoa_timings* out) {
   out->fp4_fallbacks = c->fp4_fallbacks;
   out->lockstep_launches = c->lockstep_launches;
   out->pipeline_launches = c->pipeline_launches;
-  out->pipeline_pre_pass_cus = c->pipe_ok ? c->num_cu - c->pipe_gram_cus : 0;
-  out->pipeline_contraction_cus = c->pipe_ok ? c->pipe_gram_cus : 0;
+  {
+    const int ls = c->pipe_ok ? gram_lockstep_splitk(c->n, c->pipe_gram_cus) : 0;
+    const int wgs = ls > 0 ? gram_lockstep_workgroups(c->n, ls) : 0;   // one workgroup per CU
+    out->pipeline_pre_pass_cus = c->pipe_ok ? c->num_cu - wgs : 0;
+    out->pipeline_contraction_cus = wgs;
+  }
   out->pack_seconds = c->tsec[T_PACK];
   out->pack_launches = c->pack_launches;
   out->pack_bytes = c->pack_bytes;

@@ -96,6 +96,8 @@ hipError_t launch_gram_i8_packed(const int8_t* p, int64_t nv, int32_t n, int32_t
 hipError_t launch_densify_csr(const int32_t* idx_dev, const int64_t* offs_dev, int64_t v0, int64_t nv,
                               int64_t offs_base, float* x_dev, int64_t ld, int32_t n, int32_t* err_flag_dev,
                               hipStream_t stream);
+// a one-wave spin (fp32 pipeline: head start for the contraction, pcoa_capi.hip fp4_setup)
+hipError_t launch_delay_us(hipStream_t stream, int microseconds);
 hipError_t launch_symmetrize_i32(int32_t* s32, int32_t n, hipStream_t stream);
 hipError_t launch_fold_i32_to_i64(int32_t* s32, int64_t* s64, int64_t count, hipStream_t stream);
 hipError_t launch_export_i64(const int32_t* s32, const int64_t* s64_or_null, int64_t* dst, int64_t count,

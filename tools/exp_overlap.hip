@@ -53,6 +53,13 @@ __global__ void diff_kernel(const uint32_t* a, const uint32_t* b, int64_t words,
   if (d) atomicAdd(out, d);
 }
 
+__global__ void delay_kernel(long long cycles) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(8);
+}
+static int g_delay_us = 0;       // > 0: a one-wave spin of that length in front of every pre-pass (head start for the contraction)
+static int g_gram_cus_hint = 0;  // > 0: size the lock-step launch for that many CUs
+
 static double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -79,13 +86,14 @@ struct PackCfg {
 
 static void pack(const Ctx& c, const PackCfg& k, int buf, hipStream_t s, int64_t nv = -1) {
   if (nv < 0) nv = c.v;
+  if (g_delay_us > 0) hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, s, (long long)g_delay_us * 100);  // wall_clock64: 100 MHz
   if (k.kind == PACK_OLD) CK(launch_pack_fp4(c.x, 0, c.ld, nv, c.n, c.p[buf], c.flag, s, c.nkb));
   else CK(launch_pack_fp4_ring(c.x, c.ld, nv, c.n, c.p[buf], c.flag, s, c.nkb, k.wgs, k.nt));
 }
 static int g_lockstep = 0;  // 1: lock-step contraction launch (all tiles of 4 k-streams resident, one workgroup per CU)
 static void contract(const Ctx& c, int buf, hipStream_t s, int num_cu = 0) {
   if (g_lockstep) {
-    if (launch_gram_packed_lockstep(c.p[buf], 1, c.nkb * 32, c.n, c.s32, c.num_cu, s) != hipSuccess) {
+    if (launch_gram_packed_lockstep(c.p[buf], 1, c.nkb * 32, c.n, c.s32, g_gram_cus_hint ? g_gram_cus_hint : c.num_cu, s) != hipSuccess) {
       (void)hipGetLastError();
       CK(launch_gram_packed(c.p[buf], 1, c.nkb * 32, c.n, c.s32, c.num_cu, s, nullptr));  // shape does not fit: shipped launch
     }
@@ -288,10 +296,25 @@ int main(int argc, char** argv) {
     const float ms = time_events(s0, K, [&] { pack(c, packs[0], 0, s0); contract(c, 0, s0); });
     std::printf("serial step    [%s], pack old  %.3f ms/step\n", gname, ms);
   }
+  // ---- no masks: the contraction (lock-step, 112 workgroups = one per CU on 110 CUs) gets a head start of a few us, the
+  // pre-pass then fills every CU the contraction left (its 96-VGPR waves do not fit beside 2 x 224 on a SIMD)
+  g_lockstep = 1;
+  for (int hint : {128, 256}) {
+    g_gram_cus_hint = hint;
+    for (int dl : {0, 5, 20, 50, 200}) {
+      g_delay_us = dl;
+      std::printf("[no masks, contraction sized for %d CUs, pre-pass delayed %3d us] ", hint, dl);
+      timeline(c, packs[0], sp, sg, K, false);
+      std::fflush(stdout);
+    }
+  }
+  g_delay_us = 20; g_gram_cus_hint = 128;
+  timeline(c, packs[0], sp, sg, 6, true);
+  g_delay_us = 0; g_gram_cus_hint = 0; g_lockstep = 0;
   // ---- disjoint CU sets.  Mask bit g = (XCD g % 8, CU g / 8 of that XCD) -- decoded from r02a (12 bits per word gave
   // 16 CUs on XCDs 0-3 and 8 on XCDs 4-7).  Pre-pass on CUs [0, pc) of every XCD, contraction on CUs [pc, 32).
   // (pc, gc): pre-pass on CUs [0, pc) of every XCD, contraction on CUs [32 - gc, 32); pc + gc > 32 = overlapping sets
-  const int splits[][2] = {{16, 16}, {17, 15}, {18, 16}, {20, 16}, {24, 16}, {32, 16}};
+  const int splits[][2] = {{16, 16}};
   for (const auto& sp2 : splits) {
     const int pc = sp2[0], gc = sp2[1];
     uint32_t mp[8] = {0}, mg[8] = {0};
