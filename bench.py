@@ -362,6 +362,35 @@ def main():
             "eigenvalues": [float(t) for t in lam], "nonzero_rows": int(nz),
             "device": dev_name, "cu_count": cus,
         }
+        if not args.no_extras and info["pipeline"]:
+            # the two kernels STANDALONE (each alone on the whole chip, strictly serial on one stream): what their own
+            # rooflines look like without the other kernel beside them -- three steps on a PCOA_FLAG_NO_PIPELINE engine
+            with P.PcoaEngine(n, device=local_rank, gram_kernel=args.gram_kernel, pipeline=False) as es:
+                a0, b0 = batch_of(0)
+                es.accumulate_dense(x[a0:b0]); es.finalize(); es.sync()
+                es.reset(); es.reset_timings(); es.sync()
+                t1 = time.perf_counter()
+                for i in range(3):
+                    a0, b0 = batch_of(i)
+                    es.accumulate_dense(x[a0:b0])
+                es.finalize(); es.sync()
+                dts = time.perf_counter() - t1
+                ts = es.timings()
+            vs = (batch_of(0)[1] - batch_of(0)[0])
+            ps = ts["pack_seconds"] / max(int(ts["pack_launches"]), 1)
+            gs = ts["gram_kernel_seconds"] / max(int(ts["gram_kernel_launches"]), 1)
+            gv = ts["gram_variants"] / max(int(ts["gram_kernel_launches"]), 1)
+            out["roofline_standalone"] = {
+                "note": "the same two kernels without the pipeline (PCOA_FLAG_NO_PIPELINE engine, 3 steps): each alone on all %d "
+                        "CUs; ms_per_step is what the serial order costs on this box" % cus,
+                "ms_per_step": 1e3 * dts / 3, "variants_per_s": 3 * vs / dts,
+                "pre_pass": {"bound": "hbm", "avg_launch_ms": 1e3 * ps, "achieved": 4.0 * vs * n / ps / 1e9, "peak": PEAK_HBM_GBS,
+                             "unit": "GB/s", "frac": 4.0 * vs * n / ps / 1e9 / PEAK_HBM_GBS,
+                             "bytes_convention": "SURVEY 8(d): 4*V*N bytes of X read once per launch"},
+                "contraction": {"bound": "mfma", "avg_launch_ms": 1e3 * gs, "unit": "TFLOP/s", "peak": PEAK_FP4_MFMA_TFLOPS,
+                                "achieved": 2.0 * gv * n * n / gs / 1e12 * issued_fraction(n, 256),
+                                "frac": 2.0 * gv * n * n / gs / 1e12 * issued_fraction(n, 256) / PEAK_FP4_MFMA_TFLOPS,
+                                "convention": "issued matrix-core work", "variants_per_launch": gv}}
         if not args.no_extras:
             # north_star's literal kernel: the fp32-MFMA Gram (v_mfma_f32_32x32x2_f32) on a slice of the same batch, so that
             # the record carries its roofline fraction too ("at >= 40 % fp32-MFMA roofline")

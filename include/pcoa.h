@@ -56,6 +56,8 @@ typedef enum pcoa_status {
 #define PCOA_FLAG_NO_SIGN_NORM   0x10u /* keep the eigensolver's native sign instead of sign-normalising */
 #define PCOA_FLAG_EIG_HOUSEHOLDER 0x20u /* always use the dense Householder + bisection eigensolver        */
 #define PCOA_FLAG_EIG_LANCZOS    0x40u /* Lanczos only: PCOA_ERR_NOT_CONVERGED instead of falling back      */
+#define PCOA_FLAG_NO_PIPELINE    0x80u /* fp32 tiles: pre-pass and contraction strictly one after the other on the ctx
+                                           stream (the default overlaps them on two side streams where the shape fits) */
 
 /* Per-stage timings, filled by pcoa_get_timings(); times in seconds, measured with HIP events on
  * the ctx stream.  Counters are cumulative since pcoa_create / pcoa_reset_timings. */

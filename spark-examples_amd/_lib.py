@@ -26,6 +26,7 @@ PCOA_FLAG_GRAM_FP4_MFMA = 0x4
 PCOA_FLAG_NO_SIGN_NORM = 0x10
 PCOA_FLAG_EIG_HOUSEHOLDER = 0x20
 PCOA_FLAG_EIG_LANCZOS = 0x40
+PCOA_FLAG_NO_PIPELINE = 0x80
 
 
 class PcoaTimings(ctypes.Structure):

@@ -353,6 +353,7 @@ int fp4_setup(pcoa_ctx* c) {
   bool want = !c->is_strip && c->num_cu >= 64 && lsh > 0 && gram_lockstep_workgroups(c->n, lsh) * 5 >= half * 4;
   if (k.pipeline == 0) want = false;
   if (k.pipeline == 1) want = !c->is_strip && lsh > 0;
+  if (c->flags & PCOA_FLAG_NO_PIPELINE) want = false;
   if (want) {
     hipError_t e1 = hipStreamCreateWithFlags(&c->pack_stream, hipStreamNonBlocking);
     hipError_t e2 = (e1 == hipSuccess) ? hipStreamCreateWithFlags(&c->gram_stream, hipStreamNonBlocking) : e1;

@@ -26,11 +26,15 @@ def _ptr(a):
 
 
 class PcoaEngine(object):
-    def __init__(self, n_samples, device=0, flags=L.PCOA_FLAG_DEFAULT, gram_kernel=None, eig=None, strip=None):
+    def __init__(self, n_samples, device=0, flags=L.PCOA_FLAG_DEFAULT, gram_kernel=None, eig=None, strip=None,
+                 pipeline=True):
         """gram_kernel: None/"auto" (MX-FP4 MFMA for binary tiles, int8 MFMA for multiplicities; both exact),
         "fp4", "i8" (force one of them) or "f32" (fp32-MFMA path).
         eig: None/"auto" (Lanczos with verified residual, Householder fallback), "householder", "lanczos".
-        strip: None, or (col0, cols): a strip owner holding S[:, col0:col0+cols] (pcoa_create_strip; see strips.py)."""
+        strip: None, or (col0, cols): a strip owner holding S[:, col0:col0+cols] (pcoa_create_strip; see strips.py).
+        pipeline=False: PCOA_FLAG_NO_PIPELINE (fp32 pre-pass and contraction strictly serial; measurements)."""
+        if not pipeline:
+            flags |= L.PCOA_FLAG_NO_PIPELINE
         if eig == "householder":
             flags |= L.PCOA_FLAG_EIG_HOUSEHOLDER
         elif eig == "lanczos":
