@@ -1053,9 +1053,18 @@ __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram
     ks = b / ntri;
   }
   int row_blk, col_blk;
-  if (strip.cols > 0) {  // strip owner: ALL tiles (row block, column block of the strip), column-major over the strip
-    row_blk = tile % ntile;
-    col_blk = strip.cb0 + tile / ntile;
+  if (strip.cols > 0) {
+    // strip owner: ALL tiles (row block, column block of the strip), in BANDS of 16 tile rows, column by column inside a
+    // band -- workgroups that run together then cover ~16 x 16 tiles and share 16 + 16 operand panels (the ordering
+    // that keeps the symmetric job MFMA-bound at N = 100,000, tile_coords)
+    const int ctiles = ntri / ntile;
+    const int per_band = BAND * ctiles;
+    const int band = tile / per_band;
+    const int r0 = band * BAND;
+    const int h = (ntile - r0 < BAND) ? (ntile - r0) : BAND;
+    const int rem = tile - band * per_band;
+    row_blk = r0 + rem % h;
+    col_blk = strip.cb0 + rem / h;
   } else {
     tile_coords<NWM>(tile, ntile, row_blk, col_blk);
   }

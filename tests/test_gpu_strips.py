@@ -87,3 +87,41 @@ def test_strip_creation_is_validated(P):
     with P.PcoaEngine(100) as e:
         with pytest.raises(P.PcoaError):
             e.strip_col_sums()
+
+
+def test_strips_at_biobank_sample_count_match_the_single_engine(P):
+    """N = 100,000 (BASELINE configs[3] sample count; 391 tile rows, many bands): two strip owners with a cut that is
+    not tile-aligned against ONE engine holding all of S (40 GB) -- blocks on both sides of the diagonal and of the cut,
+    the row sums, and computePca over the strips against the single-engine Lanczos path."""
+    strips = load_pkg("strips")
+    synth = load_pkg("synth")
+    n, v, seed, chunk = 100000, 32768, 1005, 16384
+    offs = synth.pop_offsets(n)
+    cut = 49999
+    full = P.PcoaEngine(n)
+    owners = [P.PcoaEngine(n, strip=(0, cut)), P.PcoaEngine(n, strip=(cut, n - cut))]
+    try:
+        for v0 in range(0, v, chunk):
+            thr = synth.thresholds(seed, v0, chunk)
+            for e in [full] + owners:
+                e.accumulate_synthetic(seed, offs, thr, v0)
+        for (r0, c0) in ((0, 0), (70000, 123), (123, 70000), (49900, 49900), (99700, 99700), (60000, 49990), (20000, 30000)):
+            want = full.gram_block(r0, c0, 290, 290)
+            got = np.zeros_like(want)
+            for e, (s0, w) in zip(owners, ((0, cut), (cut, n - cut))):
+                a, b = max(c0, s0), min(c0 + 290, s0 + w)
+                if a < b:
+                    got[:, a - c0:b - c0] = e.gram_block(r0, a - s0, 290, b - a)
+            assert np.array_equal(got, want), (r0, c0)
+            assert int(want.sum()) > 0
+        _, rs, nz_full, _ = full.center(want_matrix=False)
+        assert np.array_equal(np.concatenate([e.strip_col_sums() for e in owners]), rs)
+        comps_full, lam_full, nz = full.compute(2)
+        comps, lam, nz2 = strips.compute_pca_over_strips(owners, 2)
+        assert nz2 == nz == nz_full
+        assert np.max(np.abs(lam - lam_full) / np.abs(lam_full)) < 1e-10
+        assert np.abs(align_sign(comps, comps_full) - comps_full).max() < 1e-8
+    finally:
+        full.close()
+        for e in owners:
+            e.close()
