@@ -352,7 +352,9 @@ class VariantsPcaDriver(object):
         reverse = dict((v, k) for (k, v) in self.indexes.items())
         return [(reverse[i], float(comps[i, 0]), float(comps[i, 1])) for i in range(n)]
 
-    # emitResult, VariantsPca.scala:233-246
+    # emitResult, VariantsPca.scala:233-246.  stdout: name, dataset, pc1, pc2 sorted by name, as the reference prints.
+    # File: the reference hands the rows to Spark's saveAsTextFile, i.e. a DIRECTORY <output-path>-pca.tsv/ of unsorted
+    # part-* files (name, pc1, pc2, dataset per line); here the same lines go, sorted by name, into ONE file of that name.
     def emitResult(self, result, out=None):
         out = out or sys.stdout
         rows = []

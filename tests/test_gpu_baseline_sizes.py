@@ -323,6 +323,38 @@ with P.PcoaEngine(n) as eng:
     z.fill_(7.0); del z
     torch.cuda.synchronize()
     out["released_exact"] = bool(np.array_equal(eng.gram(), O.similarity_from_dense_blas(x[:150000].cpu().numpy())))
+    # (4) S replaced / zeroed while contractions are in flight: what was buffered or running belongs to the old S
+    want_a = O.similarity_from_dense_blas(x[:140000].cpu().numpy())
+    eng.reset()
+    eng.accumulate_dense(x)                      # several generations in flight
+    eng.reset()                                  # ... dropped
+    eng.accumulate_dense(x[:140000])
+    out["reset_exact"] = bool(np.array_equal(eng.gram(), want_a))
+    eng.accumulate_dense(x)                      # in flight again
+    eng.load_gram(want_a)                        # S replaced by a checkpoint
+    eng.accumulate_dense(x[:140000])
+    out["load_exact"] = bool(np.array_equal(eng.gram(), 2 * want_a))
+    # (5) the engine on a caller-provided stream, and a second engine interleaved with it
+    st = torch.cuda.Stream()
+    eng.reset()
+    eng.set_stream(st.cuda_stream)
+    with P.PcoaEngine(n) as other:
+        for a in range(0, 280000, 70000):
+            eng.accumulate_dense(x[a:a + 70000])
+            other.accumulate_dense(x[a:a + 70000])
+        s_a = eng.gram(); s_b = other.gram()
+    eng.set_stream(0)
+    want_b = O.similarity_from_dense_blas(x[:280000].cpu().numpy())
+    out["stream_exact"] = bool(np.array_equal(s_a, want_b) and np.array_equal(s_b, want_b))
+    # (6) a bad carrier index between device tiles: rejected before it touches S, the tiles around it still count
+    eng.reset()
+    eng.accumulate_dense(x[:140000])
+    try:
+        eng.accumulate_calls(np.array([0, n], dtype=np.int32), np.array([0, 2], dtype=np.int64))
+        out["index_error"] = False
+    except IndexError:
+        out["index_error"] = True
+    out["after_error_exact"] = bool(np.array_equal(eng.gram(), want_a))
 print(json.dumps(out))
 '''
 
@@ -346,3 +378,5 @@ def test_fp32_pipeline_and_deferred_verification_on_device_tiles(env):
     assert out["mult_exact"], out
     assert out["mult_fallbacks"] >= 1 and out["mult_variants"] == 350000
     assert out["released_exact"]
+    assert out["reset_exact"] and out["load_exact"] and out["stream_exact"]
+    assert out["index_error"] and out["after_error_exact"]
