@@ -17,7 +17,12 @@
  *     host buffer passed in; a ctx is used from one host thread at a time, different ctxs are
  *     independent (one per Spark task / per rank);
  *   - matrices are row-major unless stated; "device pointer" means HIP device memory on the ctx's GPU;
- *   - accumulate calls are asynchronous on the ctx stream; read/compute calls synchronise.
+ *   - accumulate calls only queue work (on the ctx stream and, for fp32 tiles, on two side streams the ctx owns and
+ *     orders against it); the SYNCHRONISING calls are pcoa_sync, pcoa_gram_finalize, every read / load / export /
+ *     import / all-reduce / compute call, pcoa_get_timings / pcoa_reset_timings and pcoa_set_stream.  A DEVICE input of an
+ *     accumulate call must stay valid and unchanged until the next synchronising call returns: its pre-pass may still be
+ *     running, and in the default (auto) mode a tile whose pre-pass met a carrier multiplicity is read a second time by
+ *     the int8 path.  HOST inputs are consumed before the accumulate call returns.
  */
 #ifndef PCOA_H_
 #define PCOA_H_
@@ -48,7 +53,9 @@ typedef enum pcoa_status {
 
 /* flags for pcoa_create */
 #define PCOA_FLAG_DEFAULT        0u     /* auto: MX-FP4 MFMA for binary (0/1) tiles, int8 MFMA for tiles that
-                                           hold carrier multiplicities 2..127 (decided per chunk, both exact)  */
+                                           hold carrier multiplicities 2..127 (decided per operand-buffer
+                                           generation, both exact; int32 launches and int64 folds are sized by the
+                                           largest multiplicity met, so counts never wrap)                      */
 #define PCOA_FLAG_GRAM_F32_MFMA  0x1u  /* fp32-MFMA Gram kernel (v_mfma_f32_32x32x2_f32): any small ints */
 #define PCOA_FLAG_GRAM_I8_MFMA   0x2u  /* int8-MFMA Gram kernel only (v_mfma_i32_32x32x32_i8), values 0..127 */
 #define PCOA_FLAG_GRAM_FP4_MFMA  0x4u  /* MX-FP4 Gram kernel only (v_mfma_f32_32x32x64_f8f6f4): a value
