@@ -350,7 +350,8 @@ int fp4_setup(pcoa_ctx* c) {
   // contraction does not use, and the whole chip once the contraction is done (profiles/r02n_overlap_harness.txt).
   const int half = c->num_cu / 2;
   const int lsh = gram_lockstep_splitk(c->n, half);
-  bool want = !c->is_strip && c->num_cu >= 64 && lsh > 0 && gram_lockstep_workgroups(c->n, lsh) * 5 >= half * 4;
+  // (worth it whenever the contraction is a real share of the step: from ~5 tile columns, N > 1024)
+  bool want = !c->is_strip && c->num_cu >= 64 && lsh > 0 && gram_packed_npad(c->n) >= 5 * 256;
   if (k.pipeline == 0) want = false;
   if (k.pipeline == 1) want = !c->is_strip && lsh > 0;
   if (c->flags & PCOA_FLAG_NO_PIPELINE) want = false;
@@ -372,7 +373,7 @@ int fp4_setup(pcoa_ctx* c) {
 }
 
 // Queue the contraction of buffer b's current generation.  overlapped: more fp32 pre-passes are coming, so the
-// contraction goes to the masked contraction stream; otherwise it takes the whole chip on the ctx stream.
+// contraction goes to the contraction stream, sized for half the chip; otherwise it takes the whole chip on the ctx stream.
 int fp4_launch(pcoa_ctx* c, int bi, bool overlapped) {
   pcoa_ctx::Fp4Buf& b = c->fb[bi];
   if (b.kb == 0) return PCOA_OK;
