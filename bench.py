@@ -330,7 +330,7 @@ def main():
             "vs_baseline": None, "dtype": {1: "f32", 2: "i8->i32", 3: "fp4(e2m1)->f32->i32"}[kind], "data": "synthetic",
             "config": {"workload": ("configs[1]: synthetic %d samples x %d variants fp32 per step and GPU, resident in HBM "
                                     "(Gram + eig on rank 0); %s" % (
-                                        n, v, ("weak scaling, %d distinct resident batches per GPU (configs[2]: 5M variants per "
+                                        n, v if args.scaling == "weak" else resident // steps, ("weak scaling, %d distinct resident batches per GPU (configs[2]: 5M variants per "
                                                "GPU), step i takes batch i mod %d" % (resident // v, resident // v))
                                         if args.scaling == "weak" else
                                         "STRONG scaling: fixed cohort of %d variants sharded over %d ranks, K steps = one pass"
