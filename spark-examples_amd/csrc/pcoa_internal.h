@@ -137,6 +137,7 @@ struct EigWorkspace {
   double* z;        // [kmax][n] eigenvectors of T, then of A (column c at z + c*n)
   double* scratch;  // [6][n] LU factors for inverse iteration
   int32_t* iscratch;// [2n + 64] pivots / eigenvalue indices
+  double* wy;       // blocked back-transform: wy_workspace_doubles(n, kmax) doubles, or nullptr (serial form)
   // Implicit form of B for the Lanczos path: B(i,j) = ((S(i,j) - rowmean(i)) - colmean(j)) + mean is evaluated on
   // the fly from the integer S (the same expression, operation order and rounding as center_kernel, so the matvec sees
   // bit-identical entries) and the N x N fp64 matrix is never written.  a == nullptr then.
@@ -153,6 +154,7 @@ hipError_t launch_bisect(const EigWorkspace& ws, int32_t n, const int32_t* idx_h
 hipError_t launch_inverse_iteration(const EigWorkspace& ws, int32_t n, const double* lam_sel_host, int32_t k,
                                     hipStream_t stream);
 // ws.z <- Q * ws.z (if apply_reflectors), normalise, sign-normalise (optional); out_dev[c*n + i] column-major
+size_t wy_workspace_doubles(int32_t n, int32_t k);
 hipError_t launch_backtransform(const EigWorkspace& ws, int32_t n, int32_t k, int sign_normalize,
                                 int apply_reflectors, double* out_dev, hipStream_t stream);
 
