@@ -47,6 +47,17 @@ def pkg():
     return load_pkg()
 
 
+def int_gram(x):
+    """X^T X of a small-integer matrix as int64, through the fp64 BLAS (numpy's integer matmul is a scalar loop: 30 s at
+    2504 x 3000).  Exact: every product and partial sum is an integer below 2^53, which is asserted."""
+    xf = np.asarray(x, dtype=np.float64)
+    assert xf.size == 0 or float(xf.max()) ** 2 * xf.shape[0] < 2.0 ** 53
+    g = xf.T @ xf
+    out = g.astype(np.int64)
+    assert np.array_equal(out.astype(np.float64), g)
+    return out
+
+
 def align_sign(v, ref):
     """Eigenvectors are defined up to sign: flip columns of v to match ref."""
     v = np.array(v, dtype=np.float64, copy=True)

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import load_pkg
+from conftest import int_gram, load_pkg
 
 pytestmark = pytest.mark.gpu
 
@@ -35,7 +35,7 @@ def test_every_boundary_agrees_with_integer_matmul(P, seed):
     import torch
     ingest = load_pkg("ingest")
     rng, n, v, x = _case(1000 + seed)
-    want = x.T.astype(np.int64) @ x.astype(np.int64)
+    want = int_gram(x)
     pad = int(rng.integers(0, 9))
     kernel = ["auto", "auto", "fp4", "i8"][seed % 4]
     with P.PcoaEngine(n, gram_kernel=kernel) as eng:

@@ -12,7 +12,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT, align_sign, golden_cases, load_golden, load_oracle, load_pkg, planted_callsets
+from conftest import ROOT, align_sign, golden_cases, int_gram, load_golden, load_oracle, load_pkg, planted_callsets
 
 pytestmark = pytest.mark.gpu
 
@@ -167,7 +167,7 @@ def test_bit_packed_boundary_matches_oracle_host_and_device(P, O, n, v):
     ingest = load_pkg("ingest")
     rng = np.random.default_rng(5 * n + v)
     x = (rng.random((v, n)) < 0.3).astype(np.uint8)
-    want = x.T.astype(np.int64) @ x.astype(np.int64)
+    want = int_gram(x)
     bits = ingest.pack_bits(x)
     assert bits.shape == (v, (n + 31) // 32)
     with P.PcoaEngine(n) as eng:

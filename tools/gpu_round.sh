@@ -18,7 +18,7 @@ for s in $STEPS; do
       timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
       echo "smoke exit $?" | tee -a $OUT/summary.txt; tail -3 $OUT/smoke.log | tee -a $OUT/summary.txt ;;
     tests)
-      timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 600 -rA > $OUT/tests.log 2>&1
+      timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 600 -rA --durations=40 > $OUT/tests.log 2>&1
       echo "tests exit $?" | tee -a $OUT/summary.txt; grep -E "passed|failed|error" $OUT/tests.log | tail -3 | tee -a $OUT/summary.txt
       grep -E "^(FAILED|ERROR)|PCoA wall" $OUT/tests.log | head -40 | tee -a $OUT/summary.txt ;;
     bench)
