@@ -66,7 +66,7 @@ __device__ __forceinline__ double block_reduce(double v, double* red) {
   __syncthreads();
   if (threadIdx.x < 64) {
     const double ident = (OP == 0) ? 0.0 : (OP == 1) ? -DBL_MAX : DBL_MAX;
-    double t = (threadIdx.x < nw) ? red[threadIdx.x] : ident;
+    double t = ((int)threadIdx.x < nw) ? red[threadIdx.x] : ident;
     t = (OP == 0) ? wave_sum(t) : (OP == 1) ? wave_max(t) : wave_min(t);
     if (threadIdx.x == 0) red[16] = t;
   }

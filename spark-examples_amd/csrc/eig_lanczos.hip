@@ -41,7 +41,7 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   if ((threadIdx.x & 63) == 0) red[w] = v;
   __syncthreads();
   if (threadIdx.x < 64) {
-    double t = (threadIdx.x < nw) ? red[threadIdx.x] : 0.0;
+    double t = ((int)threadIdx.x < nw) ? red[threadIdx.x] : 0.0;
     t = wave_sum(t);
     if (threadIdx.x == 0) red[16] = t;
   }

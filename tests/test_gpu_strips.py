@@ -77,6 +77,26 @@ def test_strips_tile_the_full_similarity_matrix_and_give_the_same_pca(P, O):
             e.close()
 
 
+def test_bitset_shards_reach_every_strip_owner_through_the_feeding_step(P):
+    """strips.feed_owners_from_variant_shards on the device (single process: a chunked feed of device-resident bitsets);
+    the two-rank exchange is covered on gloo in tests/test_strips_cpu.py"""
+    import torch
+    strips = load_pkg("strips")
+    ingest = load_pkg("ingest")
+    rng = np.random.default_rng(61)
+    n, v = 1100, 3000
+    x = planted_callsets(rng, n, v, k=3)
+    want = int_gram(x)
+    bits = torch.from_numpy(ingest.pack_bits(x).view(np.int32)).cuda()
+    owners = [P.PcoaEngine(n, strip=r) for r in strips.strip_ranges(n, 2)]
+    try:
+        assert strips.feed_owners_from_variant_shards(owners, bits, chunk_variants=1024) == v
+        assert np.array_equal(np.concatenate([e.gram() for e in owners], axis=1), want)
+    finally:
+        for e in owners:
+            e.close()
+
+
 def test_strip_creation_is_validated(P):
     for bad in ((-1, 10), (0, 0), (90, 20), (100, 1)):
         with pytest.raises(P.PcoaError):

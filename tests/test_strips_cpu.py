@@ -20,6 +20,19 @@ class HostStrip(object):
         self.strip = (col0, cols)
         self.s = np.ascontiguousarray(s_full[:, col0:col0 + cols]).astype(np.float64)
 
+    @classmethod
+    def empty(cls, n, col0, cols):
+        return cls(np.zeros((n, n), dtype=np.int64), col0, cols)
+
+    def accumulate_bits(self, bits):
+        """carrier bitsets [v][ceil(n/32)] uint32 (pcoa_accumulate_bits): S[:, strip] += X^T X[:, strip]"""
+        bits = np.asarray(bits)
+        assert bits.dtype == np.uint32 and bits.ndim == 2 and bits.shape[1] == (self.n + 31) // 32
+        x = ((bits[:, :, None] >> np.arange(32, dtype=np.uint32)[None, None, :]) & 1).reshape(bits.shape[0], -1)[:, :self.n]
+        x = x.astype(np.float64)
+        col0, cols = self.strip
+        self.s += x.T @ x[:, col0:col0 + cols]
+
     def strip_col_sums(self):
         return self.s.sum(axis=0)
 
@@ -102,6 +115,56 @@ def _worker(rank, world, port, out_dir):
     np.savez(os.path.join(out_dir, "r%d.npz" % rank), comps=comps, lam=lam, nz=nz)
     td.barrier()
     td.destroy_process_group()
+
+
+def _feed_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as td
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    strips = load_pkg("strips")
+    ingest = load_pkg("ingest")
+    n = 200
+    x = _cohort(29, n, 1200)
+    shard = x[:700] if rank == 0 else x[700:]                 # ragged variant shards: 700 and 500 rows
+    ranges = strips.strip_ranges(n, 3, align=64)
+    mine = ranges[:1] if rank == 0 else ranges[1:]
+    owners = [HostStrip.empty(n, c0, w) for c0, w in mine]
+    fed = strips.feed_owners_from_variant_shards(owners, ingest.pack_bits(shard), chunk_variants=256)   # 3 rounds
+    comps, lam, nz = strips.compute_pca_over_strips(owners, 2)
+    np.savez(os.path.join(out_dir, "f%d.npz" % rank), comps=comps, lam=lam, nz=nz, fed=fed,
+             s=np.concatenate([o.s for o in owners], axis=1), c0=mine[0][0])
+    td.barrier()
+    td.destroy_process_group()
+
+
+def test_variant_shards_are_all_gathered_to_every_strip_owner(tmp_path):
+    """SURVEY 8e, the C5 layout end to end on two gloo ranks: variants sharded over the ranks (ragged), columns of S
+    tiled over the ranks (rank 0 one strip, rank 1 two), bitsets exchanged in three rounds, then the Lanczos over strips."""
+    import torch.multiprocessing as mp
+    strips = load_pkg("strips")
+    ingest = load_pkg("ingest")
+    port = _free_port()
+    mp.spawn(_feed_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    oracle = load_oracle()
+    x = _cohort(29, 200, 1200)
+    s = oracle.similarity_from_dense(x, 200)
+    ref = oracle.compute_pca(s, 2)
+    got = [np.load(os.path.join(str(tmp_path), "f%d.npz" % r)) for r in range(2)]
+    assert int(got[0]["fed"]) == int(got[1]["fed"]) == 1200
+    tiled = np.concatenate([got[0]["s"], got[1]["s"]], axis=1)
+    assert np.array_equal(tiled, s.astype(np.float64))                         # every owner saw every variant once
+    assert np.array_equal(got[0]["comps"], got[1]["comps"])
+    assert np.max(np.abs(got[0]["lam"] - ref["eigenvalues"]) / np.abs(ref["eigenvalues"])) < 1e-9
+    assert np.abs(align_sign(got[0]["comps"], ref["components"]) - ref["components"]).max() < 1e-8
+    # single process: the same call is a chunked feed
+    o = HostStrip.empty(200, 0, 200)
+    assert strips.feed_owners_from_variant_shards([o], ingest.pack_bits(x), chunk_variants=500) == 1200
+    assert np.array_equal(o.s, s.astype(np.float64))
+    with pytest.raises(ValueError):
+        strips.feed_owners_from_variant_shards([o], ingest.pack_bits(x).astype(np.int64))
 
 
 def test_two_ranks_all_gather_their_strips(tmp_path):
