@@ -762,22 +762,33 @@ hipError_t launch_bisect(const EigWorkspace& ws, int32_t n, const int32_t* idx_h
   return hipGetLastError();
 }
 
+namespace {
+// dynamic LDS of invit_kernel for an n x n tridiagonal, or 0 when its five arrays go to global scratch
+hipError_t invit_lds_bytes(int32_t n, size_t* lds_out) {
+  const size_t lds = (size_t)n * (5 * sizeof(double) + sizeof(int)) + 16;
+  const bool use_lds = lds <= 150 * 1024;
+  if (use_lds && lds > 64 * 1024) {
+    static bool raised = false;  // opt in to more than 64 KiB of dynamic LDS once
+    if (!raised) {
+      hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(invit_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (err != hipSuccess) return err;
+      raised = true;
+    }
+  }
+  *lds_out = use_lds ? lds : 0;
+  return hipSuccess;
+}
+}  // namespace
+
 hipError_t launch_inverse_iteration(const EigWorkspace& ws, int32_t n, const double* lam_sel_host, int32_t k,
                                     hipStream_t stream) {
   // selected eigenvalues go to ws.lam[0..k) (the candidates there have been consumed by the host)
   hipError_t err = hipMemcpyAsync(ws.lam, lam_sel_host, sizeof(double) * k, hipMemcpyHostToDevice, stream);
   if (err != hipSuccess) return err;
-  const size_t lds = (size_t)n * (5 * sizeof(double) + sizeof(int)) + 16;
-  const int use_lds = lds <= 150 * 1024;
-  if (use_lds && lds > 64 * 1024) {
-    static bool raised = false;  // opt in to more than 64 KiB of dynamic LDS once
-    if (!raised) {
-      err = hipFuncSetAttribute(reinterpret_cast<const void*>(invit_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (err != hipSuccess) return err;
-      raised = true;
-    }
-  }
+  size_t lds = 0;
+  if ((err = invit_lds_bytes(n, &lds)) != hipSuccess) return err;
+  const int use_lds = lds > 0;
   // One workgroup per vector when each has its own scratch (LDS) and no two selected eigenvalues can fall into one
   // cluster (the kernel's ortol = 1e-3 max|T|; |T| <= 3 max(|d|, |e|) is not known here, so the test is against the
   // largest selected |lambda| -- a lower bound of max|T| would be the unsafe direction, this one is an upper bound of
@@ -790,8 +801,17 @@ hipError_t launch_inverse_iteration(const EigWorkspace& ws, int32_t n, const dou
       for (int p = 0; p < c; ++p)
         if (std::fabs(lam_sel_host[c] - lam_sel_host[p]) <= 1e-2 * big) { separate = false; break; }
   }
-  hipLaunchKernelGGL(invit_kernel, dim3(separate ? (unsigned)k : 1u), dim3(64), use_lds ? lds : 0, stream, ws.d, ws.e, n,
+  hipLaunchKernelGGL(invit_kernel, dim3(separate ? (unsigned)k : 1u), dim3(64), lds, stream, ws.d, ws.e, n,
                      ws.lam, k, ws.z, ws.scratch, ws.iscratch, use_lds);
+  return hipGetLastError();
+}
+
+hipError_t launch_inverse_iteration_dev(const EigWorkspace& ws, int32_t n, int32_t k, hipStream_t stream) {
+  size_t lds = 0;
+  hipError_t err = invit_lds_bytes(n, &lds);
+  if (err != hipSuccess) return err;
+  hipLaunchKernelGGL(invit_kernel, dim3(1), dim3(64), lds, stream, ws.d, ws.e, n, ws.lam, k, ws.z, ws.scratch,
+                     ws.iscratch, lds > 0 ? 1 : 0);
   return hipGetLastError();
 }
 

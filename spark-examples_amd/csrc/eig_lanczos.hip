@@ -5,15 +5,17 @@
 // few dozen vectors is built; every step is one read of B (50 MB fp64 at N = 2504, resident in the
 // 256 MB Infinity Cache):
 //
-//   w = B v_j                                   symv_kernel        one wave per row, HBM/MALL-bound
-//   w -= V_j (V_j^T w)   twice (CGS2)           cgs_dots / cgs_update
-//   alpha_j = v_j^T B v_j, beta_j = ||w||, v_{j+1} = w / beta_j      lanczos_finish_kernel
+//   w = B v_j                                   symv_kernel / symv_centered_kernel   one wave per row, MALL-bound
+//   h1 = V_j^T w                                cgs_dots_kernel          (pass 1 of CGS2)
+//   w -= V_j h1;  slice shares of V_j^T w       cgs_update_dots_kernel   (pass 2's dots on the way out)
+//   w -= V_j h2;  slice shares of ||w||^2       cgs_update_norm_kernel
+//   alpha_j = h1_j + h2_j, beta_j = ||w||, v_{j+1} = w / beta_j      lanczos_finish_kernel
 //
 // The small tridiagonal T_m (alpha, beta) goes through the SAME bisection + inverse-iteration
 // kernels as the dense path (eig.hip) to give Ritz values theta and vectors y; the residual of a
-// Ritz pair is |beta_m y_m| and costs nothing.  When every wanted pair has converged the Ritz
-// vectors u = V_m y are formed and the TRUE residual ||B u - theta u|| is measured with one more
-// symv; only a pair that passes that test is returned.  Anything else (slow convergence because of
+// Ritz pair is |beta_m y_m| and costs nothing.  The Ritz vectors u = V_m y and the TRUE residual
+// ||B u - theta u|| (one more symv per vector) are queued behind it speculatively and the whole check is
+// read back in one record; only a pair whose estimate AND true residual pass is returned.  Anything else (slow convergence because of
 // a tiny spectral gap, breakdown) makes the caller fall back to the Householder solver, so the fast
 // path can never return a wrong answer silently.
 #include <algorithm>
@@ -67,30 +69,77 @@ __global__ __launch_bounds__(1024) void lanczos_init_kernel(double* __restrict__
   for (int i = threadIdx.x; i < n; i += 1024) v0[i] *= rn;
 }
 
-// y = A x, A symmetric dense row-major: one wave per row, 8 loads in flight per lane
+// Row i of a symmetric mat-vec, one wave per row: sum_j entry(i, j) x[j], valid in lane 0.  `quad(j, out)` yields the
+// four matrix entries of columns j .. j+3 (n % 4 == 0: 16- / 32-byte loads, four groups = 1024 columns of the row in
+// flight per wave -- with 4-byte loads the wave had 2 KB in flight and the kernel ran at 1.9 TB/s out of the Infinity
+// Cache); `one(j)` a single entry (any n).  The explicit and the implicit (centred on the fly) kernel share this
+// function, i.e. the same association of every sum: their results are identical bit for bit when their entries are.
+template <class Quad, class One>
+__device__ __forceinline__ double row_dot(Quad quad, One one, const double* __restrict__ x, int n, int lane) {
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+  if ((n & 3) == 0) {
+    int j = 4 * lane;
+    for (; j + 768 < n; j += 1024) {
+      double e0[4], e1[4], e2[4], e3[4];
+      quad(j, e0);
+      quad(j + 256, e1);
+      quad(j + 512, e2);
+      quad(j + 768, e3);
+      const double2 xa0 = *reinterpret_cast<const double2*>(x + j), xb0 = *reinterpret_cast<const double2*>(x + j + 2);
+      const double2 xa1 = *reinterpret_cast<const double2*>(x + j + 256), xb1 = *reinterpret_cast<const double2*>(x + j + 258);
+      const double2 xa2 = *reinterpret_cast<const double2*>(x + j + 512), xb2 = *reinterpret_cast<const double2*>(x + j + 514);
+      const double2 xa3 = *reinterpret_cast<const double2*>(x + j + 768), xb3 = *reinterpret_cast<const double2*>(x + j + 770);
+      acc0 += e0[0] * xa0.x + e2[0] * xa2.x;
+      acc1 += e0[1] * xa0.y + e2[1] * xa2.y;
+      acc2 += e0[2] * xb0.x + e2[2] * xb2.x;
+      acc3 += e0[3] * xb0.y + e2[3] * xb2.y;
+      acc0 += e1[0] * xa1.x + e3[0] * xa3.x;
+      acc1 += e1[1] * xa1.y + e3[1] * xa3.y;
+      acc2 += e1[2] * xb1.x + e3[2] * xb3.x;
+      acc3 += e1[3] * xb1.y + e3[3] * xb3.y;
+    }
+    for (; j < n; j += 256) {
+      double e0[4];
+      quad(j, e0);
+      const double2 xa0 = *reinterpret_cast<const double2*>(x + j), xb0 = *reinterpret_cast<const double2*>(x + j + 2);
+      acc0 += e0[0] * xa0.x;
+      acc1 += e0[1] * xa0.y;
+      acc2 += e0[2] * xb0.x;
+      acc3 += e0[3] * xb0.y;
+    }
+  } else {
+    int j = lane;
+    for (; j + 448 < n; j += 512) {
+      const double r0 = one(j), r1 = one(j + 64), r2 = one(j + 128), r3 = one(j + 192);
+      const double r4 = one(j + 256), r5 = one(j + 320), r6 = one(j + 384), r7 = one(j + 448);
+      acc0 += r0 * x[j] + r4 * x[j + 256];
+      acc1 += r1 * x[j + 64] + r5 * x[j + 320];
+      acc2 += r2 * x[j + 128] + r6 * x[j + 384];
+      acc3 += r3 * x[j + 192] + r7 * x[j + 448];
+    }
+    for (; j < n; j += 64) acc0 += one(j) * x[j];
+  }
+  return wave_sum((acc0 + acc1) + (acc2 + acc3));
+}
+
+// y = A x, A symmetric dense row-major: one wave per row
 __global__ __launch_bounds__(256) void symv_kernel(const double* __restrict__ a, int n,
                                                    const double* __restrict__ x, double* __restrict__ y) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
   const double* row = a + (int64_t)i * n;
-  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-  int j = lane;
-  for (; j + 448 < n; j += 512) {
-    const double r0 = row[j], r1 = row[j + 64], r2 = row[j + 128], r3 = row[j + 192];
-    const double r4 = row[j + 256], r5 = row[j + 320], r6 = row[j + 384], r7 = row[j + 448];
-    acc0 += r0 * x[j] + r4 * x[j + 256];
-    acc1 += r1 * x[j + 64] + r5 * x[j + 320];
-    acc2 += r2 * x[j + 128] + r6 * x[j + 384];
-    acc3 += r3 * x[j + 192] + r7 * x[j + 448];
-  }
-  for (; j < n; j += 64) acc0 += row[j] * x[j];
-  const double acc = wave_sum((acc0 + acc1) + (acc2 + acc3));
+  auto quad = [&](int j, double* out) {
+    const double2 lo = *reinterpret_cast<const double2*>(row + j), hi = *reinterpret_cast<const double2*>(row + j + 2);
+    out[0] = lo.x; out[1] = lo.y; out[2] = hi.x; out[3] = hi.y;
+  };
+  auto one = [&](int j) -> double { return row[j]; };
+  const double acc = row_dot(quad, one, x, n, lane);
   if (lane == 0) y[i] = acc;
 }
 
 // y = B x with B evaluated on the fly from the integer similarity matrix (EigWorkspace, implicit form): the same
-// loop structure as symv_kernel, the same per-entry expression as center_kernel (no fused multiply-add in the
+// row_dot as symv_kernel, the same per-entry expression as center_kernel (no fused multiply-add in the
 // centring), so the result equals symv_kernel on the materialised B bit for bit -- at 4 (12) instead of 8 bytes per
 // entry and without the N x N fp64 matrix (80 GB at N = 100,000).
 template <bool HAS64>
@@ -105,26 +154,30 @@ __global__ __launch_bounds__(256) void symv_centered_kernel(const int32_t* __res
   const int64_t base = (int64_t)i * n;
   const double row_mean = cm[i];
   const double mmean = stats[1];
-  auto entry = [&](int j) -> double {
+  auto centre = [&](double data, double col_mean) -> double {
 #pragma clang fp contract(off)
-    const double data = HAS64 ? (double)((int64_t)s32[base + j] + s64[base + j]) : (double)s32[base + j];
     double t = data - row_mean;
-    t = t - cm[j];
+    t = t - col_mean;
     t = t + mmean;
     return t;
   };
-  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-  int j = lane;
-  for (; j + 448 < n; j += 512) {
-    const double r0 = entry(j), r1 = entry(j + 64), r2 = entry(j + 128), r3 = entry(j + 192);
-    const double r4 = entry(j + 256), r5 = entry(j + 320), r6 = entry(j + 384), r7 = entry(j + 448);
-    acc0 += r0 * x[j] + r4 * x[j + 256];
-    acc1 += r1 * x[j + 64] + r5 * x[j + 320];
-    acc2 += r2 * x[j + 128] + r6 * x[j + 384];
-    acc3 += r3 * x[j + 192] + r7 * x[j + 448];
-  }
-  for (; j < n; j += 64) acc0 += entry(j) * x[j];
-  const double acc = wave_sum((acc0 + acc1) + (acc2 + acc3));
+  auto quad = [&](int j, double* out) {
+    const int4 s = *reinterpret_cast<const int4*>(s32 + base + j);
+    double d0 = (double)s.x, d1 = (double)s.y, d2 = (double)s.z, d3 = (double)s.w;
+    if (HAS64) {
+      const longlong2 l = *reinterpret_cast<const longlong2*>(s64 + base + j);
+      const longlong2 h = *reinterpret_cast<const longlong2*>(s64 + base + j + 2);
+      d0 = (double)((int64_t)s.x + l.x); d1 = (double)((int64_t)s.y + l.y);
+      d2 = (double)((int64_t)s.z + h.x); d3 = (double)((int64_t)s.w + h.y);
+    }
+    const double2 ca = *reinterpret_cast<const double2*>(cm + j), cb = *reinterpret_cast<const double2*>(cm + j + 2);
+    out[0] = centre(d0, ca.x); out[1] = centre(d1, ca.y); out[2] = centre(d2, cb.x); out[3] = centre(d3, cb.y);
+  };
+  auto one = [&](int j) -> double {
+    const double data = HAS64 ? (double)((int64_t)s32[base + j] + s64[base + j]) : (double)s32[base + j];
+    return centre(data, cm[j]);
+  };
+  const double acc = row_dot(quad, one, x, n, lane);
   if (lane == 0) y[i] = acc;
 }
 
@@ -152,25 +205,69 @@ __global__ __launch_bounds__(256) void cgs_dots_kernel(const double* __restrict_
   if (threadIdx.x == 0) h[blockIdx.x] = t;
 }
 
-// w[i] -= sum_p h[p] V[p][i]
-__global__ __launch_bounds__(256) void cgs_update_kernel(const double* __restrict__ v, int n, int count,
-                                                         const double* __restrict__ h, double* __restrict__ w) {
+constexpr int kMaxKrylov = 512;   // largest Krylov dimension (LDS arrays of the fused re-orthogonalisation kernels)
+
+// Pass 1 of CGS2 on slice b = blockIdx.x of w (256 entries):  w[i] -= sum_p h[p] V[p][i],  and on the way out the dot
+// products pass 2 needs, restricted to the slice:  part[b][q] = sum_{i in slice} V[q][i] w_new[i].  The next kernel
+// adds the slices in a fixed order -- one launch less per Lanczos step than a second cgs_dots_kernel, no atomics.
+__global__ __launch_bounds__(256) void cgs_update_dots_kernel(const double* __restrict__ v, int n, int count,
+                                                              const double* __restrict__ h, double* __restrict__ w,
+                                                              double* __restrict__ part) {
+  __shared__ double red[4][kMaxKrylov + 8];
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool in = i < n;
+  const int ic = in ? i : n - 1;
   double acc = 0.0;
-  for (int p = 0; p < count; ++p) acc += h[p] * v[(int64_t)p * n + i];
-  w[i] -= acc;
+  for (int p = 0; p < count; ++p) acc += h[p] * v[(int64_t)p * n + ic];
+  const double wi = in ? w[ic] - acc : 0.0;
+  if (in) w[i] = wi;
+  for (int q = 0; q < count; ++q) {
+    const double t = wave_sum(v[(int64_t)q * n + ic] * wi);
+    if (lane == 0) red[wave][q] = t;
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < count; q += 256)
+    part[(int64_t)blockIdx.x * count + q] = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
 }
 
-// alpha[j] = h1[j] + h2[j]; beta[j] = ||w||; V[j+1] = w / beta[j]   (single workgroup)
+// Pass 2 on slice b:  h2[q] = sum_b part[b][q] (fixed order; every workgroup forms it for itself, workgroup 0 also
+// publishes it),  w[i] -= sum_q h2[q] V[q][i],  pnorm[b] = sum_{i in slice} w_new[i]^2.
+__global__ __launch_bounds__(256) void cgs_update_norm_kernel(const double* __restrict__ v, int n, int count,
+                                                              const double* __restrict__ part, int nb,
+                                                              double* __restrict__ w, double* __restrict__ h2,
+                                                              double* __restrict__ pnorm) {
+  __shared__ double hs[kMaxKrylov + 8];
+  __shared__ double red[24];
+  for (int q = threadIdx.x; q < count; q += 256) {
+    double t = 0.0;
+    for (int b = 0; b < nb; ++b) t += part[(int64_t)b * count + q];
+    hs[q] = t;
+    if (blockIdx.x == 0) h2[q] = t;
+  }
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double wi = 0.0;
+  if (i < n) {
+    double acc = 0.0;
+    for (int p = 0; p < count; ++p) acc += hs[p] * v[(int64_t)p * n + i];
+    wi = w[i] - acc;
+    w[i] = wi;
+  }
+  const double t = block_sum(wi * wi, red);
+  if (threadIdx.x == 0) pnorm[blockIdx.x] = t;
+}
+
+// alpha[j] = h1[j] + h2[j]; beta[j] = ||w|| (from the slices' partial sums); V[j+1] = w / beta[j]   (single workgroup)
 __global__ __launch_bounds__(1024) void lanczos_finish_kernel(double* __restrict__ v, int n, int j,
                                                               const double* __restrict__ w,
+                                                              const double* __restrict__ pnorm, int nb,
                                                               const double* __restrict__ h1,
                                                               const double* __restrict__ h2,
                                                               double* __restrict__ alpha, double* __restrict__ beta) {
   __shared__ double red[24];
   double part = 0.0;
-  for (int i = threadIdx.x; i < n; i += 1024) part += w[i] * w[i];
+  for (int b = threadIdx.x; b < nb; b += 1024) part += pnorm[b];
   const double nrm = sqrt(block_sum(part, red));
   const double rn = (nrm > 0.0) ? 1.0 / nrm : 0.0;
   double* vn = v + (int64_t)(j + 1) * n;
@@ -179,6 +276,39 @@ __global__ __launch_bounds__(1024) void lanczos_finish_kernel(double* __restrict
     alpha[j] = h1[j] + h2[j];
     beta[j] = nrm;
   }
+}
+
+// The k Ritz values of largest magnitude among cand[0..count) -> sel[0..k), in the order the host derives from the
+// same numbers afterwards (|.| descending, then value descending, then position): MLlib ranks by |lambda|.
+__global__ __launch_bounds__(64) void ritz_select_kernel(const double* __restrict__ cand, int count, int k,
+                                                         double* __restrict__ sel) {
+  if (threadIdx.x != 0) return;
+  // strict total order: a before b  <=>  |a| > |b|, or equal and a > b, or equal again and position(a) < position(b);
+  // the t-th pick is the first element of that order behind the previous pick
+  auto before = [&](int a, int b) {
+    const double fa = fabs(cand[a]), fb = fabs(cand[b]);
+    if (fa != fb) return fa > fb;
+    if (cand[a] != cand[b]) return cand[a] > cand[b];
+    return a < b;
+  };
+  int prev = -1;
+  for (int t = 0; t < k && t < count; ++t) {
+    int best = -1;
+    for (int c = 0; c < count; ++c) {
+      if (prev >= 0 && !before(prev, c)) continue;
+      if (best < 0 || before(c, best)) best = c;
+    }
+    if (best < 0) break;
+    sel[t] = cand[best];
+    prev = best;
+  }
+}
+
+// rec[0] = beta[m-1]; rec[1 + t] = last component of the t-th eigenvector of T_m (z[t][m-1])
+__global__ __launch_bounds__(64) void ritz_collect_kernel(const double* __restrict__ beta, const double* __restrict__ z,
+                                                          int m, int k, double* __restrict__ rec) {
+  if (threadIdx.x == 0) rec[0] = beta[m - 1];
+  for (int t = threadIdx.x; t < k; t += 64) rec[1 + t] = z[(int64_t)t * m + (m - 1)];
 }
 
 // u[c][i] = sum_p y[c][p] V[p][i]    (Ritz vectors), grid (ceil(n/256), k)
@@ -215,8 +345,11 @@ __global__ __launch_bounds__(1024) void residual_kernel(const double* __restrict
 }  // namespace
 
 size_t lanczos_workspace_doubles(int32_t n, int32_t k, int32_t mmax) {
-  // V[(mmax+1)][n], w[n], bu[k][n], alpha[mmax], beta[mmax], h1[mmax+1], h2[mmax+1], small: lam[2k+2], res[k]
-  return (size_t)(mmax + 1) * n + (size_t)n + (size_t)k * n + 4 * (size_t)(mmax + 2) + 2 * (size_t)k + 8;
+  // V[(mmax+1)][n], w[n], bu[k][n], alpha[mmax], beta[mmax], h1[mmax+1], h2[mmax+1], the check record
+  // (cand[2k+2], beta_m, ylast[k], res[k]), part[nb][mmax+1] + pnorm[nb] of the fused re-orthogonalisation
+  const size_t nb = ((size_t)n + 255) / 256;
+  return (size_t)(mmax + 1) * n + (size_t)n + (size_t)k * n + 4 * (size_t)(mmax + 2) + 4 * (size_t)k + 16 +
+         nb * (size_t)(mmax + 2);
 }
 
 // Returns hipSuccess on a clean run; *converged tells whether ws.z[0..k) holds verified eigenvectors of
@@ -227,7 +360,9 @@ hipError_t lanczos_topk(const EigWorkspace& ws, double* lz, int32_t n, int32_t k
   *converged = 0;
   if (steps_out) *steps_out = 0;
   if (mmax > n) mmax = n;
+  if (mmax > kMaxKrylov) mmax = kMaxKrylov;
   if (mmax < k + 2 || n < 8) return hipSuccess;  // tiny problems go to the dense path
+  const unsigned nb = (unsigned)((n + 255) / 256);
   double* V = lz;
   double* w = V + (size_t)(mmax + 1) * n;
   double* bu = w + n;
@@ -235,57 +370,81 @@ hipError_t lanczos_topk(const EigWorkspace& ws, double* lz, int32_t n, int32_t k
   double* beta = alpha + (mmax + 2);
   double* h1 = beta + (mmax + 2);
   double* h2 = h1 + (mmax + 2);
-  double* res = h2 + (mmax + 2);
+  double* rec = h2 + (mmax + 2);                 // cand[2k+2] | beta_m | ylast[k] | res[k]
+  double* part = rec + (4 * (size_t)k + 16);     // [nb][count] partial dot products of pass 2
+  double* pnorm = part + (size_t)nb * (mmax + 1);
 
   EigWorkspace small = ws;  // T_m goes through the dense path's bisection / inverse iteration
   small.d = alpha;
   small.e = beta;
 
   hipLaunchKernelGGL(lanczos_init_kernel, dim3(1), dim3(1024), 0, stream, V, n);
-  const unsigned nb = (unsigned)((n + 255) / 256);
   // Ritz pairs are examined at m = 12, 16, 20, 24, then every 8 steps up to 64, then every m / 2: a check costs about
-  // four steps (bisection + inverse iteration on T_m + two host round trips), and population structure converges
-  // early (configs[1] stand-in: estimate 1e-14 at m = 12, true relative residual 3.7e-9)
+  // three steps, and population structure converges early (configs[1] stand-in: estimate 1e-14 at m = 12, true
+  // relative residual 3.7e-9)
   int next_check = 12;
   if (debug_knobs().lanczos_first_check > 0) next_check = std::max(4, debug_knobs().lanczos_first_check);
   if (next_check > mmax) next_check = mmax;
-  std::vector<double> cand, ylast((size_t)k), hres((size_t)k);
+  std::vector<double> cand, pageable;
   std::vector<int32_t> idx;
   for (int j = 0; j < mmax; ++j) {
     const double* vj = V + (size_t)j * n;
+    const int cnt = j + 1;
     launch_symv(ws, n, vj, w, stream);
-    // (the five small kernels below fused into ONE workgroup were measured slower: 30 vs 24 us per step -- a single
-    // CU cannot stream the ~2 MB of basis vectors a step touches as fast as j+1 workgroups can)
-    hipLaunchKernelGGL(cgs_dots_kernel, dim3((unsigned)(j + 1)), dim3(256), 0, stream, V, n, w, h1);
-    hipLaunchKernelGGL(cgs_update_kernel, dim3(nb), dim3(256), 0, stream, V, n, j + 1, h1, w);
-    hipLaunchKernelGGL(cgs_dots_kernel, dim3((unsigned)(j + 1)), dim3(256), 0, stream, V, n, w, h2);
-    hipLaunchKernelGGL(cgs_update_kernel, dim3(nb), dim3(256), 0, stream, V, n, j + 1, h2, w);
-    hipLaunchKernelGGL(lanczos_finish_kernel, dim3(1), dim3(1024), 0, stream, V, n, j, w, h1, h2, alpha, beta);
+    // CGS2 in three launches: dots of pass 1 (one workgroup per basis vector), then per 256-entry slice of w the update
+    // of pass 1 fused with the slice's share of the dots of pass 2, then the update of pass 2 fused with the slice's
+    // share of ||w||^2.  (All of it in ONE workgroup was measured slower: 30 vs 24 us per step -- a single CU cannot
+    // stream the ~2 MB of basis vectors a step touches as fast as many can.)
+    hipLaunchKernelGGL(cgs_dots_kernel, dim3((unsigned)cnt), dim3(256), 0, stream, V, n, w, h1);
+    hipLaunchKernelGGL(cgs_update_dots_kernel, dim3(nb), dim3(256), 0, stream, V, n, cnt, h1, w, part);
+    hipLaunchKernelGGL(cgs_update_norm_kernel, dim3(nb), dim3(256), 0, stream, V, n, cnt, part, (int)nb, w, h2, pnorm);
+    hipLaunchKernelGGL(lanczos_finish_kernel, dim3(1), dim3(1024), 0, stream, V, n, j, w, pnorm, (int)nb, h1, h2, alpha,
+                       beta);
     const int m = j + 1;
     if (m != next_check && m != mmax) continue;
     next_check = (m < 24) ? m + 4 : (m < 64) ? m + 8 : m + m / 2;
     if (next_check > mmax) next_check = mmax;
     if (steps_out) *steps_out = m;
 
-    // Ritz values of T_m: k largest and k smallest, keep the k of largest magnitude (MLlib ranks by |lambda|)
-    // (one extra value at each end so that the spectral gap of every kept pair can be estimated)
+    // ---- the check, queued as a whole and read back ONCE (one host round trip instead of three): Ritz values of T_m
+    // (k + 1 at each end: the k of largest magnitude are kept -- MLlib ranks by |lambda| -- and the extra ones bound
+    // their gaps), their selection on the device, the eigenvectors y of T_m, the free estimate |beta_m y_last|, and --
+    // speculatively, they are cheap -- the Ritz vectors u = V_m y and their TRUE residuals ||B u - theta u||.
     idx.clear();
     for (int t = 0; t <= k && t < m; ++t) idx.push_back(m - 1 - t);
     for (int t = 0; t <= k; ++t)
       if (t < m - 1 - k) idx.push_back(t);
-    cand.resize(idx.size());
-    hipError_t e = launch_bisect(small, m, idx.data(), (int32_t)idx.size(), ws.lam, stream);
+    const int nc = (int)idx.size();
+    double* rec_beta = rec + nc;          // beta_m, ylast[k]
+    double* rec_res = rec_beta + 1 + k;   // res[k]
+    hipError_t e = launch_bisect(small, m, idx.data(), nc, rec, stream);
     if (e != hipSuccess) return e;
-    double beta_m = 0.0;
-    if ((e = hipMemcpyAsync(cand.data(), ws.lam, sizeof(double) * cand.size(), hipMemcpyDeviceToHost, stream)) !=
-        hipSuccess)
+    hipLaunchKernelGGL(ritz_select_kernel, dim3(1), dim3(64), 0, stream, rec, nc, k, ws.lam);
+    if ((e = launch_inverse_iteration_dev(small, m, k, stream)) != hipSuccess) return e;
+    hipLaunchKernelGGL(ritz_collect_kernel, dim3(1), dim3(64), 0, stream, beta, ws.z, m, k, rec_beta);
+    hipLaunchKernelGGL(ritz_kernel, dim3(nb, (unsigned)k), dim3(256), 0, stream, V, n, m, ws.z, bu);
+    // ws.z <- u (ritz_kernel read y from ws.z, so it wrote to bu first)
+    if ((e = hipMemcpyAsync(ws.z, bu, sizeof(double) * (size_t)k * n, hipMemcpyDeviceToDevice, stream)) != hipSuccess)
       return e;
-    if ((e = hipMemcpyAsync(&beta_m, beta + (m - 1), sizeof(double), hipMemcpyDeviceToHost, stream)) != hipSuccess)
-      return e;
+    for (int t = 0; t < k; ++t)
+      launch_symv(ws, n, ws.z + (size_t)t * n, bu + (size_t)t * n, stream);
+    hipLaunchKernelGGL(residual_kernel, dim3((unsigned)k), dim3(1024), 0, stream, bu, ws.z, n, ws.lam, rec_res);
+    const size_t rec_count = (size_t)nc + 1 + 2 * (size_t)k;
+    double* hrec = ws.host_rec;
+    if (!hrec || rec_count > ws.host_rec_cap) {
+      pageable.resize(rec_count);
+      hrec = pageable.data();
+    }
+    if ((e = hipMemcpyAsync(hrec, rec, sizeof(double) * rec_count, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+    cand.assign(hrec, hrec + nc);
+    const double beta_m = hrec[nc];
+    const double* ylast = hrec + nc + 1;
+    const double* hres = ylast + k;
+
     std::vector<int> order(cand.size());
     for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {   // == ritz_select_kernel's order
       const double fa = fabs(cand[a]), fb = fabs(cand[b]);
       if (fa != fb) return fa > fb;
       return cand[a] > cand[b];
@@ -294,13 +453,6 @@ hipError_t lanczos_topk(const EigWorkspace& ws, double* lz, int32_t n, int32_t k
     for (double c : cand) scale = fmax(scale, fabs(c));
     for (int t = 0; t < k; ++t) lam_sel_host[t] = cand[order[t]];
     if (!(scale > 0.0) || !std::isfinite(scale)) return hipSuccess;  // B == 0 or garbage: dense path decides
-    // Ritz vectors y of T_m and the free residual estimate |beta_m * y_last|
-    if ((e = launch_inverse_iteration(small, m, lam_sel_host, k, stream)) != hipSuccess) return e;
-    for (int t = 0; t < k; ++t)
-      if ((e = hipMemcpyAsync(&ylast[t], ws.z + (size_t)t * m + (m - 1), sizeof(double), hipMemcpyDeviceToHost,
-                              stream)) != hipSuccess)
-        return e;
-    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
     // A Ritz pair is accepted when its residual is small against the spectrum AND against its own
     // gap (eigenvector error ~ residual / gap): target 1e-8, two orders inside the 1e-6 parity bar.
     std::vector<double> gap((size_t)k);
@@ -314,34 +466,18 @@ hipError_t lanczos_topk(const EigWorkspace& ws, double* lz, int32_t n, int32_t k
     bool ok = true;
     for (int t = 0; t < k; ++t) ok = ok && accept(fabs(beta_m * ylast[t]), t);
     const bool breakdown = beta_m <= 1e-14 * scale;  // invariant subspace: T_m holds exact eigenvalues
-    const bool trace = debug_knobs().lanczos_trace != 0;
-    if (trace) {
-      std::fprintf(stderr, "[lanczos] m=%d beta_m=%.3e scale=%.6e", m, beta_m, scale);
-      for (int t = 0; t < k; ++t)
-        std::fprintf(stderr, "  theta%d=%.10e est=%.3e gap=%.3e", t, lam_sel_host[t], fabs(beta_m * ylast[t]), gap[(size_t)t]);
-      std::fprintf(stderr, "  ok=%d\n", (int)ok);
-    }
-    if (!ok && !breakdown) {
-      if (m == mmax) return hipSuccess;
-      continue;
-    }
-    // u = V_m y, true residual with one more pass over B per vector
-    hipLaunchKernelGGL(ritz_kernel, dim3(nb, (unsigned)k), dim3(256), 0, stream, V, n, m, ws.z, bu);
-    // ws.z <- u (ritz_kernel read y from ws.z, so it wrote to bu first)
-    if ((e = hipMemcpyAsync(ws.z, bu, sizeof(double) * (size_t)k * n, hipMemcpyDeviceToDevice, stream)) != hipSuccess)
-      return e;
-    for (int t = 0; t < k; ++t)
-      launch_symv(ws, n, ws.z + (size_t)t * n, bu + (size_t)t * n, stream);
-    hipLaunchKernelGGL(residual_kernel, dim3((unsigned)k), dim3(1024), 0, stream, bu, ws.z, n, ws.lam, res);
-    if ((e = hipMemcpyAsync(hres.data(), res, sizeof(double) * k, hipMemcpyDeviceToHost, stream)) != hipSuccess)
-      return e;
-    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
     bool verified = true;
     for (int t = 0; t < k; ++t) verified = verified && std::isfinite(hres[t]) && accept(hres[t] * 0.125, t);
-    if (trace) {
-      std::fprintf(stderr, "[lanczos] m=%d true residuals:", m);
-      for (int t = 0; t < k; ++t) std::fprintf(stderr, " %.3e", hres[t]);
-      std::fprintf(stderr, "  verified=%d\n", (int)verified);
+    if (debug_knobs().lanczos_trace != 0) {
+      std::fprintf(stderr, "[lanczos] m=%d beta_m=%.3e scale=%.6e", m, beta_m, scale);
+      for (int t = 0; t < k; ++t)
+        std::fprintf(stderr, "  theta%d=%.10e est=%.3e gap=%.3e true=%.3e", t, lam_sel_host[t], fabs(beta_m * ylast[t]),
+                     gap[(size_t)t], hres[t]);
+      std::fprintf(stderr, "  ok=%d verified=%d\n", (int)ok, (int)verified);
+    }
+    if (!ok && !breakdown) {   // the estimate says not yet: the speculative residual is not consulted
+      if (m == mmax) return hipSuccess;
+      continue;
     }
     if (verified) {
       *converged = 1;

@@ -764,7 +764,18 @@ int ensure_workspace(pcoa_ctx* c, int32_t k) {
     if (c->ws.z) (void)hipFree(c->ws.z);
     if (c->out_dev) (void)hipFree(c->out_dev);
     if (c->ws.wy) (void)hipFree(c->ws.wy);
+    if (c->ws.host_rec) (void)hipHostFree(c->ws.host_rec);
     c->ws.lam = nullptr; c->ws.z = nullptr; c->out_dev = nullptr; c->ws.wy = nullptr; c->kmax = 0;
+    c->ws.host_rec = nullptr; c->ws.host_rec_cap = 0;
+    {  // pinned landing zone of the Lanczos check record (without it the read-back goes through pageable memory)
+      const size_t cap = 4 * (size_t)k + 16;
+      if (hipHostMalloc((void**)&c->ws.host_rec, sizeof(double) * cap, hipHostMallocDefault) == hipSuccess)
+        c->ws.host_rec_cap = cap;
+      else {
+        (void)hipGetLastError();
+        c->ws.host_rec = nullptr;
+      }
+    }
     HIP_TRY(c, hipMalloc((void**)&c->ws.wy, sizeof(double) * wy_workspace_doubles(c->n, k)));
     HIP_TRY(c, hipMalloc((void**)&c->ws.lam, sizeof(double) * (size_t)(2 * k + 8)));
     HIP_TRY(c, hipMalloc((void**)&c->ws.z, sizeof(double) * (size_t)((int64_t)k * n)));
@@ -949,6 +960,7 @@ void pcoa_destroy(pcoa_ctx* c) {
   }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->fb_flags_host) (void)hipHostFree(c->fb_flags_host);
+  if (c->ws.host_rec) (void)hipHostFree(c->ws.host_rec);
   void* bufs[] = {c->s32, c->s64, c->zeros, c->err_flag, c->tile, c->csr_idx, c->csr_offs, c->thr_dev,
                   c->sample_pop, c->xfer, c->coll, c->fb_flags, c->strip_ws, c->pack_buf, c->lanczos_ws, c->ws.a, c->ws.d, c->ws.e, c->ws.tau, c->ws.q, c->ws.w, c->ws.lam,
                   c->ws.z, c->ws.wy, c->ws.scratch, c->ws.iscratch, c->row_sums, c->colmean, c->stats, c->nz,

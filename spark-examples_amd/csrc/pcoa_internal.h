@@ -138,6 +138,8 @@ struct EigWorkspace {
   double* scratch;  // [6][n] LU factors for inverse iteration
   int32_t* iscratch;// [2n + 64] pivots / eigenvalue indices
   double* wy;       // blocked back-transform: wy_workspace_doubles(n, kmax) doubles, or nullptr (serial form)
+  double* host_rec = nullptr;   // pinned host memory for the Lanczos check record (host_rec_cap doubles), or nullptr
+  size_t host_rec_cap = 0;
   // Implicit form of B for the Lanczos path: B(i,j) = ((S(i,j) - rowmean(i)) - colmean(j)) + mean is evaluated on
   // the fly from the integer S (the same expression, operation order and rounding as center_kernel, so the matvec sees
   // bit-identical entries) and the N x N fp64 matrix is never written.  a == nullptr then.
@@ -153,6 +155,8 @@ hipError_t launch_bisect(const EigWorkspace& ws, int32_t n, const int32_t* idx_h
 // eigenvectors of T for lam_sel[0..k) (host values) -> ws.z
 hipError_t launch_inverse_iteration(const EigWorkspace& ws, int32_t n, const double* lam_sel_host, int32_t k,
                                     hipStream_t stream);
+// the same with lam_sel already in ws.lam[0..k) on the device (one workgroup, vectors in sequence)
+hipError_t launch_inverse_iteration_dev(const EigWorkspace& ws, int32_t n, int32_t k, hipStream_t stream);
 // ws.z <- Q * ws.z (if apply_reflectors), normalise, sign-normalise (optional); out_dev[c*n + i] column-major
 size_t wy_workspace_doubles(int32_t n, int32_t k);
 hipError_t launch_backtransform(const EigWorkspace& ws, int32_t n, int32_t k, int sign_normalize,
