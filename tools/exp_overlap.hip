@@ -57,6 +57,21 @@ __global__ void delay_kernel(long long cycles) {
   const long long t0 = wall_clock64();
   while (wall_clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(8);
 }
+// one wave that watches the shader clock: a fixed chain of dependent VALU operations (4 cycles each on a wave64) timed
+// with s_memrealtime (100 MHz); s_memtime (clock64) is reported beside it
+__global__ void clock_probe_kernel(long long iters, long long* out) {
+  const long long w0 = wall_clock64(), c0 = clock64();
+  unsigned v = threadIdx.x;
+  for (long long i = 0; i < iters; ++i) {
+    asm volatile("v_add_u32 %0, %0, 1\n\tv_add_u32 %0, %0, 1\n\tv_add_u32 %0, %0, 1\n\tv_add_u32 %0, %0, 1\n\t"
+                 "v_add_u32 %0, %0, 1\n\tv_add_u32 %0, %0, 1\n\tv_add_u32 %0, %0, 1\n\tv_add_u32 %0, %0, 1" : "+v"(v));
+  }
+  if (threadIdx.x == 0) {
+    out[0] = clock64() - c0;
+    out[1] = wall_clock64() - w0;
+    out[2] = v;
+  }
+}
 static int g_delay_us = 0;       // > 0: a one-wave spin of that length in front of every pre-pass (head start for the contraction)
 static int g_gram_cus_hint = 0;  // > 0: size the lock-step launch for that many CUs
 
@@ -218,6 +233,83 @@ int main(int argc, char** argv) {
 
   hipStream_t s0;
   CK(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking));
+
+  if (argc > 3 && std::string(argv[3]) == "clocks") {
+    // ---- what the shader clock does under each load: a one-wave probe on its own stream beside (a) nothing, (b) the
+    // pre-pass, (c) the lock-step contraction on half the chip, (d) both (the pipeline's steady state)
+    hipStream_t sp, sg, sc;
+    CK(hipStreamCreateWithFlags(&sp, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&sg, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&sc, hipStreamNonBlocking));
+    long long* probe = nullptr;
+    CK(hipMalloc((void**)&probe, 64));
+    const PackCfg old_pack{PACK_OLD, 0, 0};
+    pack(c, old_pack, 0, s0);
+    pack(c, old_pack, 1, s0);
+    CK(hipStreamSynchronize(s0));
+    g_lockstep = 1;
+    g_gram_cus_hint = 128;
+    const char* names[] = {"idle", "pre-pass alone", "contraction alone (112 CUs)", "pre-pass + contraction", "contraction alone (whole chip)"};
+    for (int round = 0; round < 2; ++round)
+      for (int mode = 0; mode < 5; ++mode) {
+        g_gram_cus_hint = (mode == 4) ? 0 : 128;
+        const int reps = 6;
+        // load first (a few launches deep), then the probe for 4 ms in the middle of it
+        if (mode == 1 || mode == 3) for (int i = 0; i < reps; ++i) pack(c, old_pack, 0, sp);
+        if (mode == 2 || mode == 3) for (int i = 0; i < reps; ++i) contract(c, 1, sg);
+        if (mode == 4) for (int i = 0; i < 2 * reps; ++i) contract(c, 1, sg);
+        hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, sc, 150000LL);        // 1.5 ms: let the load ramp up
+        const long long iters = 250000;   // 2 M dependent adds = 8 M cycles: ~3.5 ms at 2.4 GHz
+        hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, sc, iters, probe);
+        long long h[3] = {0, 0, 0};
+        CK(hipMemcpyAsync(h, probe, 24, hipMemcpyDeviceToHost, sc));
+        CK(hipStreamSynchronize(sc));
+        CK(hipStreamSynchronize(sp));
+        CK(hipStreamSynchronize(sg));
+        std::printf("[clock] %-32s 2,000,000 dependent v_add_u32 in %.3f ms -> %.0f MHz at 4 cycles each; s_memtime / s_memrealtime = %.3f\n",
+                    names[mode], (double)h[1] * 1e-5, 8.0 * (double)iters * 4.0 / ((double)h[1] * 1e-2), (double)h[0] / (double)h[1]);
+        std::fflush(stdout);
+      }
+    std::printf("done\n");
+    return 0;
+  }
+  if (argc > 3 && std::string(argv[3]) == "balanced") {
+    // ---- focused A/B: tile deal of the half-chip lock-step contraction (row-major cut vs 6 panels per XCD), alone and in
+    // the shipped pipeline (no masks, 10-us head start), interleaved rounds
+    hipStream_t sp, sg;
+    CK(hipStreamCreateWithFlags(&sp, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&sg, hipStreamNonBlocking));
+    const PackCfg old_pack{PACK_OLD, 0, 0};
+    pack(c, old_pack, 0, s0);
+    pack(c, old_pack, 1, s0);
+    g_lockstep = 1;
+    g_gram_cus_hint = 128;
+    const size_t nn = (size_t)c.n * c.n;
+    std::vector<int32_t> a(nn), b(nn);
+    for (int map : {2, 3}) {
+      g_lockstep_map = map;
+      CK(hipMemsetAsync(c.s32, 0, nn * 4, s0));
+      contract(c, 0, s0);
+      CK(hipMemcpyAsync(map == 2 ? a.data() : b.data(), c.s32, nn * 4, hipMemcpyDeviceToHost, s0));
+      CK(hipStreamSynchronize(s0));
+    }
+    size_t diff = 0; long long sum = 0;
+    for (size_t i = 0; i < nn; ++i) { diff += a[i] != b[i]; sum += a[i]; }
+    std::printf("balanced deal vs row-major cut: %zu differing entries of %zu (sum %lld)  %s\n", diff, nn, sum,
+                diff == 0 && sum > 0 ? "OK" : "MISMATCH");
+    for (int round = 0; round < 3; ++round)
+      for (int map : {2, 3}) {
+        g_lockstep_map = map;
+        g_delay_us = 0;
+        const float alone = time_events(s0, 4, [&] { contract(c, 0, s0); });
+        g_delay_us = 10;
+        std::printf("[deal %s] contraction alone (sized for 128 CUs) %.3f ms | ", map == 3 ? "balanced " : "row-major", alone);
+        timeline(c, old_pack, sp, sg, K, false);
+        std::fflush(stdout);
+      }
+    std::printf("done\n");
+    return 0;
+  }
 
   // ---- 1. bit-identity of the two pre-passes (full tile, and a ragged variant count: rows beyond nv in the last k-block)
   for (int64_t nv : {c.v, c.v - 13}) {
