@@ -391,6 +391,13 @@ def main():
                                 "achieved": 2.0 * gv * n * n / gs / 1e12 * issued_fraction(n, 256),
                                 "frac": 2.0 * gv * n * n / gs / 1e12 * issued_fraction(n, 256) / PEAK_FP4_MFMA_TFLOPS,
                                 "convention": "issued matrix-core work", "variants_per_launch": gv}}
+            # the same two figures next to the co-running ones, where a reader of `roofline` looks first
+            for obj in (out.get("roofline"), out.get("roofline_other")):
+                if not isinstance(obj, dict):
+                    continue
+                alone = out["roofline_standalone"]["pre_pass" if obj.get("bound") == "hbm" else "contraction"]
+                obj["alone_on_the_chip"] = {"avg_launch_ms": alone["avg_launch_ms"], "achieved": alone["achieved"],
+                                            "frac": alone["frac"], "source": "roofline_standalone (same run, same box)"}
         if not args.no_extras:
             # north_star's literal kernel: the fp32-MFMA Gram (v_mfma_f32_32x32x2_f32) on a slice of the same batch, so that
             # the record carries its roofline fraction too ("at >= 40 % fp32-MFMA roofline")
