@@ -179,3 +179,36 @@ def test_two_ranks_all_gather_their_strips(tmp_path):
     assert int(got[0]["nz"]) == ref["nonzero_rows"]
     assert np.max(np.abs(got[0]["lam"] - ref["eigenvalues"]) / np.abs(ref["eigenvalues"])) < 1e-9
     assert np.abs(align_sign(got[0]["comps"], ref["components"]) - ref["components"]).max() < 1e-8
+
+
+def _config5_worker(rank, world, port, out_dir, exchange):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    import importlib
+    tool = importlib.import_module("config5_strips")
+    out = tool.main(["--standin", "--samples", "260", "--variants", "1500", "--chunk", "400", "--exchange", exchange])
+    if rank == 0:
+        import json
+        json.dump(out, open(os.path.join(out_dir, "c5_%s.json" % exchange), "w"))
+
+
+@pytest.mark.parametrize("exchange", ["bits", "none"])
+def test_config5_driver_control_flow_on_two_gloo_ranks(tmp_path, exchange):
+    """tools/config5_strips.py (one strip owner per rank, the launcher of the configs[4] layout) with numpy stand-in
+    owners: variants sharded and exchanged as bitsets / regenerated by every owner, Lanczos over the strips; the result
+    is held to the oracle on the whole cohort."""
+    import json
+    import torch.multiprocessing as mp
+    synth = load_pkg("synth")
+    port = _free_port()
+    mp.spawn(_config5_worker, args=(2, port, str(tmp_path), exchange), nprocs=2, join=True)
+    out = json.load(open(os.path.join(str(tmp_path), "c5_%s.json" % exchange)))
+    oracle = load_oracle()
+    n, v = 260, 1500
+    x = synth.genotypes(1005, 0, synth.thresholds(1005, 0, v), synth.pop_offsets(n), dtype=np.uint8)
+    ref = oracle.compute_pca(oracle.similarity_from_dense(x, n), 2)
+    assert out["variants_fed_to_every_owner"] == v and out["nonzero_rows"] == ref["nonzero_rows"]
+    assert np.max(np.abs(np.array(out["eigenvalues"]) - ref["eigenvalues"]) / np.abs(ref["eigenvalues"])) < 1e-9
+    assert max(out["relative_residuals"]) < 1e-8
