@@ -52,12 +52,35 @@ class NumpyStrip(object):
         pass
 
 
+def device_bitsets(owner, seed, offs, thr, first, n, dev):
+    """This rank's variants [first, first + len(thr)) as carrier bitsets on the device: the engine's generator fills an
+    fp32 tile (the same Philox stream as synth.genotypes), torch packs it 32 samples to a word (sample i -> bit i & 31
+    of word i >> 5, the layout of pcoa_accumulate_bits)."""
+    import torch
+    cnt = int(thr.shape[0])
+    words = (n + 31) // 32
+    if cnt == 0:
+        return torch.zeros((0, words), dtype=torch.int32, device=dev)
+    xf = torch.empty((cnt, n), dtype=torch.float32, device=dev)
+    owner.synth_fill(seed, offs, thr, first, xf.data_ptr(), n)
+    owner.sync()
+    xb = xf > 0
+    del xf
+    if words * 32 != n:
+        xb = torch.nn.functional.pad(xb, (0, words * 32 - n))
+    w = (xb.view(cnt, words, 32).to(torch.int64) << torch.arange(32, device=dev, dtype=torch.int64)).sum(dim=2)
+    w = torch.where(w >= (1 << 31), w - (1 << 32), w)          # the same 32 bits as a signed word
+    return w.to(torch.int32).contiguous()
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--samples", type=int, default=250000)
     ap.add_argument("--variants", type=int, default=10000000)
     ap.add_argument("--seed", type=int, default=1005)
-    ap.add_argument("--chunk", type=int, default=65536, help="variants per generation / exchange round")
+    ap.add_argument("--chunk", type=int, default=8192,
+                    help="variants per generation / exchange round (the fp32 tile the generator fills is chunk x N x 4 "
+                         "bytes: 8 GB at N = 250,000)")
     ap.add_argument("--exchange", choices=("bits", "none"), default="bits")
     ap.add_argument("--num-pc", type=int, default=2)
     ap.add_argument("--standin", action="store_true", help="numpy strip owners on the CPU (gloo); tests only")
@@ -110,10 +133,11 @@ def main(argv=None):
             a = min(s1, s0 + r * args.chunk)
             b = min(s1, a + args.chunk)
             thr = synth.thresholds(seed, a, b - a)
-            bits = ingest.pack_bits(synth.genotypes(seed, a, thr, offs, dtype=np.uint8)) if b > a else \
-                np.zeros((0, (n + 31) // 32), dtype=np.uint32)
-            if not args.standin:
-                bits = torch.from_numpy(bits.view(np.int32)).cuda(local_rank)
+            if args.standin:
+                bits = ingest.pack_bits(synth.genotypes(seed, a, thr, offs, dtype=np.uint8)) if b > a else \
+                    np.zeros((0, (n + 31) // 32), dtype=np.uint32)
+            else:
+                bits = device_bitsets(owner, seed, offs, thr, a, n, torch.device("cuda", local_rank))
             fed += strips.feed_owners_from_variant_shards([owner], bits, chunk_variants=args.chunk)
     if not args.standin:
         owner.sync()
