@@ -3,7 +3,6 @@
 Bars (BASELINE.json north_star): Gram bit-exact (integers); centred matrix bit-exact (fp64, same
 operation order); sign-normalised eigenpairs within 1e-6 relative.
 """
-import io
 import json
 import os
 import subprocess
