@@ -123,6 +123,69 @@ def load_vcf(path, references=None):
     return indexes, dict(zip(ids, samples)), [("csr", idx, np.asarray(offs, dtype=np.int64))]
 
 
+def load_plink(path, references=None, ref_allele="a2", chunk_variants=4096):
+    """PLINK 1 binary fileset (<prefix>.bed / .bim / .fam; `path` is the prefix or any of the three files).  The .bed is
+    variant-major, two bits per genotype, four samples to a byte (sample s in bits 2 (s % 4) of byte s // 4):
+    00 homozygous A1, 01 missing, 10 heterozygous, 11 homozygous A2.  hasVariation (VariantsPca.scala:56-60: some allele
+    index > 0) = the genotype carries a non-reference allele; the reference allele is A2 (what `plink --keep-allele-order`
+    and `plink2 --make-bed` write for a VCF's REF; ref_allele="a1" for filesets written the other way round), so codes
+    00 and 10 count and a missing call does not (its allele indices are -1).  Returns what load_vcf returns: CSR carrier
+    lists of the variants that have a carrier, callset index = row of the .fam, name = its IID.  The contig rule and the
+    --references filter are the VCF reader's (0-based start = bp - 1)."""
+    prefix = path[:-4] if path[-4:] in (".bed", ".bim", ".fam") else path
+    regions = parse_references(references)
+    set_id = set_id_of(prefix + ".bed")
+    with open(prefix + ".fam") as f:
+        names = [ln.split()[1] for ln in f if ln.strip()]
+    n = len(names)
+    if n == 0:
+        raise ValueError("no samples in %s.fam" % prefix)
+    keep = []
+    with open(prefix + ".bim") as f:
+        for ln in f:
+            if not ln.strip():
+                continue
+            t = ln.split()
+            contig = normalize_contig(t[0])
+            ok = contig is not None
+            if ok and regions:
+                start = int(t[3]) - 1
+                ok = any(c == contig and s0 <= start < e for (c, s0, e) in regions)
+            keep.append(ok)
+    keep = np.asarray(keep, dtype=bool)
+    bpv = (n + 3) // 4                                          # bytes per variant
+    raw = np.fromfile(prefix + ".bed", dtype=np.uint8)
+    if raw.size < 3 or raw[0] != 0x6c or raw[1] != 0x1b:
+        raise ValueError("%s.bed: not a PLINK 1 binary file" % prefix)
+    if raw[2] != 1:
+        raise ValueError("%s.bed is sample-major; only the variant-major layout (plink >= 1.07 default) is read" % prefix)
+    if raw.size - 3 != keep.size * bpv:
+        raise ValueError("%s.bed holds %d bytes of genotypes, %d variants x %d samples need %d"
+                         % (prefix, raw.size - 3, keep.size, n, keep.size * bpv))
+    geno = raw[3:].reshape(keep.size, bpv)
+    varies = (0, 2) if ref_allele == "a2" else (3, 2)           # codes that carry a non-reference allele
+    shifts = np.array([0, 2, 4, 6], dtype=np.uint8)
+    idx_chunks, counts = [], []
+    for v0 in range(0, keep.size, chunk_variants):
+        g = geno[v0:v0 + chunk_variants]
+        k = keep[v0:v0 + chunk_variants]
+        if not k.any():
+            continue
+        g = g[k]
+        codes = ((g[:, :, None] >> shifts[None, None, :]) & 3).reshape(g.shape[0], -1)[:, :n]
+        has = (codes == varies[0]) | (codes == varies[1])
+        cnt = has.sum(axis=1)
+        rows, cols = np.nonzero(has)
+        idx_chunks.append(cols.astype(np.int32))
+        counts.append(cnt[cnt > 0])                             # variants without a carrier are dropped (:164-167)
+    idx = np.concatenate(idx_chunks) if idx_chunks else np.zeros(0, dtype=np.int32)
+    cnts = np.concatenate(counts) if counts else np.zeros(0, dtype=np.int64)
+    offs = np.concatenate(([0], np.cumsum(cnts))).astype(np.int64)
+    ids = ["%s-%d" % (set_id, i) for i in range(n)]
+    indexes = dict((cid, i) for i, cid in enumerate(ids))
+    return indexes, dict(zip(ids, names)), [("csr", idx, offs)]
+
+
 def load_vcf_records(path, references=None, set_id=None):
     """VCF -> variant records shaped like the reference's Variant case class (VariantsRDD.scala:46-54):
     contig, start, end, referenceBases, alternateBases, info, calls[{callSetId, genotype}].

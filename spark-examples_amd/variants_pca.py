@@ -389,18 +389,20 @@ def load_dataset(conf):
     if conf.synthetic:
         return ingest.synthetic_dataset(conf.synthetic)
     if not conf.inputPath:
-        raise SystemExit("--input-path (local .npz or .vcf[.gz]) or --synthetic V,N,seed is required: "
+        raise SystemExit("--input-path (local .vcf[.gz], PLINK .bed/.bim/.fam or .npz) or --synthetic V,N,seed is required: "
                          "the Google Genomics API the reference read from has been shut down")
     paths = conf.inputPath if isinstance(conf.inputPath, (list, tuple)) else [conf.inputPath]
     refs = None if conf.all_references else conf.references
     if len(paths) == 1 and conf.minAlleleFrequency is None:
         if paths[0].endswith(".npz"):
             return ingest.load_npz(paths[0])
+        if paths[0][-4:] in (".bed", ".bim", ".fam"):
+            return ingest.load_plink(paths[0], refs)
         return ingest.load_vcf(paths[0], refs)
     # several variant sets (or the AF filter): full variant records are needed for keys and INFO/AF
-    if any(p.endswith(".npz") for p in paths):
-        raise SystemExit("joining variant sets or filtering by allele frequency needs VCF inputs: a .npz dataset holds "
-                         "carriers only (no contig/start/end/ref/alt keys, no INFO/AF)")
+    if any(p.endswith(".npz") or p[-4:] in (".bed", ".bim", ".fam") for p in paths):
+        raise SystemExit("joining variant sets or filtering by allele frequency needs VCF inputs: a .npz dataset or a PLINK "
+                         "fileset is read as carriers only (no contig/start/end/ref/alt keys, no INFO/AF)")
     print("Running PCA on %d datasets." % len(paths))  # VariantsCommon.scala:57
     indexes, names, data = {}, {}, []
     used = set()

@@ -98,3 +98,45 @@ def write_golden_vcf(g, path, gz=False):
                 cells[col[call["callSetId"]]] = ("|" if k % 2 else "/").join(str(a) for a in call["genotype"])
             f.write("chr17\t%d\t.\tA\tC\t.\tPASS\t.\tGT\t%s\n" % (41196312 + 7 * k, "\t".join(cells)))
     return len(ids)
+
+
+def write_golden_plink(g, prefix, flip=False):
+    """The same records as a PLINK 1 fileset (<prefix>.bed/.bim/.fam).  PLINK holds diploid biallelic genotypes only, so a
+    genotype is mapped to the code with the same hasVariation (VariantsPca.scala:56-60): every allele > 0 -> homozygous
+    non-reference, some allele > 0 -> heterozygous, no allele > 0 and one missing -> missing, else homozygous reference.
+    A2 is the reference allele (flip=True: A1 is, i.e. the codes 00 and 11 trade places).  A callset without a call in a
+    record is missing."""
+    import json
+    ids = [str(s) for s in g["callset_ids"]]
+    col = dict((cid, i) for i, cid in enumerate(ids))
+    variants = json.loads(str(g["variants_json"]))
+    n = len(ids)
+    hom_alt, het, missing, hom_ref = (3, 2, 1, 0) if flip else (0, 2, 1, 3)
+    with open(prefix + ".fam", "w") as f:
+        for i in range(n):
+            f.write("FAM%d S%04d 0 0 0 -9\n" % (i, i))
+    with open(prefix + ".bim", "w") as f:
+        for k in range(len(variants)):
+            f.write("17\trs%d\t0\t%d\tC\tA\n" % (k, 41196312 + 7 * k))
+    bpv = (n + 3) // 4
+    out = np.zeros((len(variants), bpv), dtype=np.uint8)
+    for k, var in enumerate(variants):
+        codes = np.full(bpv * 4, hom_ref, dtype=np.uint8)     # padding bits of the last byte: anything
+        codes[:n] = missing
+        for call in var.get("calls", []):
+            gt = call["genotype"]
+            if gt and all(a > 0 for a in gt):
+                c = hom_alt
+            elif any(a > 0 for a in gt):
+                c = het
+            elif any(a < 0 for a in gt) or not gt:
+                c = missing
+            else:
+                c = hom_ref
+            codes[col[call["callSetId"]]] = c
+        quad = codes.reshape(bpv, 4)
+        out[k] = quad[:, 0] | (quad[:, 1] << 2) | (quad[:, 2] << 4) | (quad[:, 3] << 6)
+    with open(prefix + ".bed", "wb") as f:
+        f.write(bytes([0x6c, 0x1b, 0x01]))
+        f.write(out.tobytes())
+    return n

@@ -375,6 +375,60 @@ def test_vcf_ingest_of_both_hosts_reproduces_the_reference_carrier_rows(name, tm
         assert got == want
 
 
+@pytest.mark.parametrize("name", golden_cases())
+def test_plink_fileset_ingest_reproduces_the_reference_carrier_rows(name, tmp_path):
+    """SURVEY 8(f) rank 1, the cohort format PCA users actually hold: the records of each golden fixture as a PLINK 1
+    fileset (.bed two bits per genotype, all four codes present); ingest.load_plink must return the carrier rows the
+    reference's own prepare_call_data produced, whichever allele the fileset calls the reference."""
+    from conftest import write_golden_plink
+    g = load_golden(name)
+    offs = g["row_offsets"]
+    want = [g["sample_idx"][offs[k]:offs[k + 1]].tolist() for k in range(len(offs) - 1)]
+    n = int(g["n_samples"])
+    ingest = load_pkg("ingest")
+    for flip in (False, True):
+        prefix = str(tmp_path / ("flip" if flip else "plain"))
+        assert write_golden_plink(g, prefix, flip=flip) == n
+        indexes, names, parts = ingest.load_plink(prefix + ".bed", ["chr17:41196311:41277499"],
+                                                  ref_allele="a1" if flip else "a2", chunk_variants=7)
+        kind, idx, o = parts[0]
+        assert kind == "csr" and idx.dtype == np.int32 and o.dtype == np.int64
+        assert [idx[o[k]:o[k + 1]].tolist() for k in range(len(o) - 1)] == want
+        assert len(indexes) == n and sorted(indexes.values()) == list(range(n))
+        stem = "flip" if flip else "plain"
+        assert indexes["%s-3" % stem] == 3 and names["%s-3" % stem] == "S0003"
+        # the prefix and the .fam name the same fileset; a region that holds nothing gives no rows
+        assert np.array_equal(ingest.load_plink(prefix, None, ref_allele="a1" if flip else "a2")[2][0][1], idx)
+        empty = ingest.load_plink(prefix + ".fam", ["chr17:1:100"])[2][0]
+        assert empty[1].size == 0 and empty[2].tolist() == [0]
+
+
+def test_plink_reader_refuses_what_it_cannot_read(tmp_path):
+    from conftest import write_golden_plink
+    ingest = load_pkg("ingest")
+    g = load_golden(golden_cases()[0])
+    prefix = str(tmp_path / "p")
+    write_golden_plink(g, prefix)
+    raw = open(prefix + ".bed", "rb").read()
+    open(prefix + ".bed", "wb").write(raw[:2] + bytes([0]) + raw[3:])           # sample-major flag
+    with pytest.raises(ValueError):
+        ingest.load_plink(prefix)
+    open(prefix + ".bed", "wb").write(raw[:-1])                                 # truncated
+    with pytest.raises(ValueError):
+        ingest.load_plink(prefix)
+    open(prefix + ".bed", "wb").write(b"BCF" + raw[3:])                         # another format
+    with pytest.raises(ValueError):
+        ingest.load_plink(prefix)
+    # the driver front end: one PLINK fileset is a carrier source like a .npz; joins and the AF filter need VCF records
+    vp = load_pkg("variants_pca")
+    open(prefix + ".bed", "wb").write(raw)
+    conf = vp.PcaConf(["--input-path", prefix + ".bed", "--all-references"])
+    indexes, names, data = vp.load_dataset(conf)
+    assert len(indexes) == int(g["n_samples"]) and data[0][0] == "csr"
+    with pytest.raises(SystemExit):
+        vp.load_dataset(vp.PcaConf(["--input-path", prefix + ".bed", prefix + ".bed", "--all-references"]))
+
+
 def test_variant_sets_with_the_same_file_stem_keep_distinct_callsets(tmp_path):
     """a/cohort.chr17.vcf + b/cohort.chr17.vcf used to collapse to one set of callset ids in the
     Python host (N = 2 instead of 4, indices out of range).  Both hosts: positional indices, unique ids, same rows."""
