@@ -123,7 +123,7 @@ def load_vcf(path, references=None):
     return indexes, dict(zip(ids, samples)), [("csr", idx, np.asarray(offs, dtype=np.int64))]
 
 
-def load_plink(path, references=None, ref_allele="a2", chunk_variants=4096):
+def load_plink(path, references=None, ref_allele="a2", chunk_variants=4096, as_bits=False):
     """PLINK 1 binary fileset (<prefix>.bed / .bim / .fam; `path` is the prefix or any of the three files).  The .bed is
     variant-major, two bits per genotype, four samples to a byte (sample s in bits 2 (s % 4) of byte s // 4):
     00 homozygous A1, 01 missing, 10 heterozygous, 11 homozygous A2.  hasVariation (VariantsPca.scala:56-60: some allele
@@ -131,7 +131,10 @@ def load_plink(path, references=None, ref_allele="a2", chunk_variants=4096):
     and `plink2 --make-bed` write for a VCF's REF; ref_allele="a1" for filesets written the other way round), so codes
     00 and 10 count and a missing call does not (its allele indices are -1).  Returns what load_vcf returns: CSR carrier
     lists of the variants that have a carrier, callset index = row of the .fam, name = its IID.  The contig rule and the
-    --references filter are the VCF reader's (0-based start = bp - 1)."""
+    --references filter are the VCF reader's (0-based start = bp - 1).
+    as_bits=True returns [("bits", uint32 [variants][ceil(N / 32)])] instead: the carrier bitsets pcoa_accumulate_bits
+    takes (sample i -> bit i & 31 of word i >> 5), one table look-up per .bed byte and no CSR in between -- 1 bit per
+    genotype instead of 4 bytes per carrier; rows without a carrier stay (they add nothing to S)."""
     prefix = path[:-4] if path[-4:] in (".bed", ".bim", ".fam") else path
     regions = parse_references(references)
     set_id = set_id_of(prefix + ".bed")
@@ -163,6 +166,28 @@ def load_plink(path, references=None, ref_allele="a2", chunk_variants=4096):
         raise ValueError("%s.bed holds %d bytes of genotypes, %d variants x %d samples need %d"
                          % (prefix, raw.size - 3, keep.size, n, keep.size * bpv))
     geno = raw[3:].reshape(keep.size, bpv)
+    ids = ["%s-%d" % (set_id, i) for i in range(n)]
+    indexes = dict((cid, i) for i, cid in enumerate(ids))
+    if as_bits:
+        # a genotype varies iff the LOW bit of its code is 0 (A2 = reference: codes 00, 10) / the HIGH bit is 1 (A1 =
+        # reference: codes 10, 11): one nibble of carrier bits per .bed byte, eight nibbles to a word
+        b = np.arange(256, dtype=np.uint32)
+        if ref_allele == "a2":
+            lut = sum((1 - ((b >> (2 * q)) & 1)) << q for q in range(4))
+        else:
+            lut = sum(((b >> (2 * q + 1)) & 1) << q for q in range(4))
+        lut = lut.astype(np.uint32)
+        words = (n + 31) // 32
+        g = geno[keep]
+        nib = np.zeros((g.shape[0], words * 8), dtype=np.uint32)
+        nib[:, :bpv] = lut[g]
+        bits = np.zeros((g.shape[0], words), dtype=np.uint32)
+        nib = nib.reshape(g.shape[0], words, 8)
+        for k in range(8):
+            bits |= nib[:, :, k] << np.uint32(4 * k)
+        if n % 32:
+            bits[:, -1] &= np.uint32((1 << (n % 32)) - 1)        # the codes behind the last sample are padding
+        return indexes, dict(zip(ids, names)), [("bits", bits)]
     varies = (0, 2) if ref_allele == "a2" else (3, 2)           # codes that carry a non-reference allele
     shifts = np.array([0, 2, 4, 6], dtype=np.uint8)
     idx_chunks, counts = [], []
@@ -181,8 +206,6 @@ def load_plink(path, references=None, ref_allele="a2", chunk_variants=4096):
     idx = np.concatenate(idx_chunks) if idx_chunks else np.zeros(0, dtype=np.int32)
     cnts = np.concatenate(counts) if counts else np.zeros(0, dtype=np.int64)
     offs = np.concatenate(([0], np.cumsum(cnts))).astype(np.int64)
-    ids = ["%s-%d" % (set_id, i) for i in range(n)]
-    indexes = dict((cid, i) for i, cid in enumerate(ids))
     return indexes, dict(zip(ids, names)), [("csr", idx, offs)]
 
 

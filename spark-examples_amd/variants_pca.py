@@ -155,7 +155,11 @@ def calculate_similarity_matrix(call_rdd, matrix_size, engine=None, device=0):
     (VariantsPca.scala:182-191).  call_rdd: list of index lists, or a (sample_idx, row_offsets) CSR
     pair.  Returns the PcoaEngine holding S in HBM (use .gram() for the N^2 entries)."""
     eng = engine if engine is not None else PcoaEngine(matrix_size, device=device)
-    if isinstance(call_rdd, tuple):
+    if isinstance(call_rdd, tuple) and isinstance(call_rdd[0], str) and call_rdd[0] == "bits":
+        bits = call_rdd[1]                          # carrier bitsets [variants][ceil(N / 32)] (a PLINK fileset)
+        for v0 in range(0, bits.shape[0], 1 << 20):
+            eng.accumulate_bits(bits[v0:v0 + (1 << 20)])
+    elif isinstance(call_rdd, tuple):
         eng.accumulate_calls(call_rdd[0], call_rdd[1])
     else:
         eng.accumulate_callsets(call_rdd)
@@ -314,8 +318,8 @@ class VariantsPcaDriver(object):
         variant_set_count = len(data)
         if variant_set_count == 1:
             d = data[0]
-            if isinstance(d, tuple):  # pre-extracted carriers (CSR): already filtered
-                return (d[1], d[2])
+            if isinstance(d, tuple):  # pre-extracted carriers: CSR rows (already filtered) or bitsets
+                return ("bits", d[1]) if d[0] == "bits" else (d[1], d[2])
             return prepare_call_data(d, self.indexes)
         if any(isinstance(d, tuple) for d in data):
             raise ValueError("joining datasets needs variant records (contig/start/end/ref/alt), not CSR carriers")
@@ -397,7 +401,7 @@ def load_dataset(conf):
         if paths[0].endswith(".npz"):
             return ingest.load_npz(paths[0])
         if paths[0][-4:] in (".bed", ".bim", ".fam"):
-            return ingest.load_plink(paths[0], refs)
+            return ingest.load_plink(paths[0], refs, as_bits=True)
         return ingest.load_vcf(paths[0], refs)
     # several variant sets (or the AF filter): full variant records are needed for keys and INFO/AF
     if any(p.endswith(".npz") or p[-4:] in (".bed", ".bim", ".fam") for p in paths):

@@ -397,6 +397,14 @@ def test_plink_fileset_ingest_reproduces_the_reference_carrier_rows(name, tmp_pa
         assert len(indexes) == n and sorted(indexes.values()) == list(range(n))
         stem = "flip" if flip else "plain"
         assert indexes["%s-3" % stem] == 3 and names["%s-3" % stem] == "S0003"
+        # the bitset form (what the driver feeds to pcoa_accumulate_bits): the same carriers, every variant kept
+        _, _, bparts = ingest.load_plink(prefix + ".bed", ["chr17:41196311:41277499"],
+                                         ref_allele="a1" if flip else "a2", as_bits=True)
+        assert bparts[0][0] == "bits" and bparts[0][1].dtype == np.uint32 and bparts[0][1].shape[1] == (n + 31) // 32
+        rows = [np.nonzero((np.asarray(r)[:, None] >> np.arange(32, dtype=np.uint32)[None, :]).reshape(-1)[:n] & 1)[0].tolist()
+                for r in bparts[0][1]]
+        assert [r for r in rows if r] == want
+        assert all((np.asarray(r)[-1] >> np.uint32(n % 32)) == 0 for r in bparts[0][1]) if n % 32 else True
         # the prefix and the .fam name the same fileset; a region that holds nothing gives no rows
         assert np.array_equal(ingest.load_plink(prefix, None, ref_allele="a1" if flip else "a2")[2][0][1], idx)
         empty = ingest.load_plink(prefix + ".fam", ["chr17:1:100"])[2][0]
@@ -424,7 +432,23 @@ def test_plink_reader_refuses_what_it_cannot_read(tmp_path):
     open(prefix + ".bed", "wb").write(raw)
     conf = vp.PcaConf(["--input-path", prefix + ".bed", "--all-references"])
     indexes, names, data = vp.load_dataset(conf)
-    assert len(indexes) == int(g["n_samples"]) and data[0][0] == "csr"
+    assert len(indexes) == int(g["n_samples"]) and data[0][0] == "bits"
+
+    class Recorder(object):                     # what the front end hands to the engine, without a GPU
+        def __init__(self):
+            self.bits, self.finalized = [], False
+
+        def accumulate_bits(self, b):
+            self.bits.append(np.array(b))
+
+        def finalize(self):
+            self.finalized = True
+
+    driver = vp.VariantsPcaDriver(conf, indexes, names, data)
+    rec = Recorder()
+    out = vp.calculate_similarity_matrix(driver.getCallsRdd([driver.filterDataset(d) for d in driver.data]),
+                                         len(indexes), engine=rec)
+    assert out is rec and rec.finalized and len(rec.bits) == 1 and np.array_equal(rec.bits[0], data[0][1])
     with pytest.raises(SystemExit):
         vp.load_dataset(vp.PcaConf(["--input-path", prefix + ".bed", prefix + ".bed", "--all-references"]))
 
