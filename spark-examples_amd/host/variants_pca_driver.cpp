@@ -424,11 +424,82 @@ void check(pcoa_ctx* ctx, int rc, const char* what) {
 
 }  // namespace
 
+bool is_plink_path(const std::string& p) {
+  if (p.size() < 4) return false;
+  const std::string ext = p.substr(p.size() - 4);
+  return ext == ".bed" || ext == ".bim" || ext == ".fam";
+}
+
+// PLINK 1 binary fileset (<prefix>.bed / .bim / .fam), the twin of the Python mirror's ingest.load_plink: variant-major
+// .bed, two bits per genotype, four samples to a byte (sample s in bits 2 (s % 4) of byte s / 4): 00 homozygous A1,
+// 01 missing, 10 heterozygous, 11 homozygous A2.  A2 is the reference allele (plink --keep-allele-order / plink2
+// --make-bed), so hasVariation (:56-60) = code 00 or 10; a missing call has none.  Callset index = row of the .fam,
+// name = its IID.  Contig rule and --references filter as for a VCF (0-based start = bp - 1).
+Dataset load_plink(const std::string& path, const std::string& stem, const std::vector<Region>& regions, int32_t index_base) {
+  const std::string prefix = path.substr(0, path.size() - 4);
+  Dataset d;
+  {
+    std::ifstream fam(prefix + ".fam");
+    if (!fam) die("cannot open " + prefix + ".fam");
+    std::string line;
+    while (std::getline(fam, line)) {
+      std::istringstream is(line);
+      std::string fid, iid;
+      if (!(is >> fid >> iid)) continue;
+      d.names.push_back(iid);
+      d.ids.push_back(stem + "-" + std::to_string(d.ids.size()));
+    }
+  }
+  const size_t n = d.ids.size();
+  if (n == 0) die("no samples in " + prefix + ".fam");
+  std::vector<char> keep;
+  {
+    std::ifstream bim(prefix + ".bim");
+    if (!bim) die("cannot open " + prefix + ".bim");
+    std::string line;
+    while (std::getline(bim, line)) {
+      std::istringstream is(line);
+      std::string chrom, id, cm;
+      long bp = 0;
+      if (!(is >> chrom >> id >> cm >> bp)) continue;
+      std::string contig;
+      bool ok = normalize_contig(chrom, contig);
+      if (ok && !regions.empty()) {
+        ok = false;
+        for (const auto& r : regions)
+          if (r.contig == contig && r.start <= bp - 1 && bp - 1 < r.end) { ok = true; break; }
+      }
+      keep.push_back(ok ? 1 : 0);
+    }
+  }
+  std::ifstream bed(prefix + ".bed", std::ios::binary);
+  if (!bed) die("cannot open " + prefix + ".bed");
+  unsigned char magic[3] = {0, 0, 0};
+  bed.read(reinterpret_cast<char*>(magic), 3);
+  if (!bed || magic[0] != 0x6c || magic[1] != 0x1b) die(prefix + ".bed: not a PLINK 1 binary file");
+  if (magic[2] != 1) die(prefix + ".bed is sample-major; only the variant-major layout is read");
+  const size_t bpv = (n + 3) / 4;
+  std::vector<unsigned char> row(bpv);
+  for (size_t v = 0; v < keep.size(); ++v) {
+    bed.read(reinterpret_cast<char*>(row.data()), (std::streamsize)bpv);
+    if ((size_t)bed.gcount() != bpv) die(prefix + ".bed is shorter than its .bim / .fam say");
+    if (!keep[v]) continue;
+    Variant var;
+    for (size_t s = 0; s < n; ++s) {
+      const unsigned code = (row[s >> 2] >> (2 * (s & 3))) & 3u;
+      if (code == 0u || code == 2u) var.carriers.push_back(index_base + (int32_t)s);
+    }
+    d.variants.push_back(std::move(var));
+  }
+  if (bed.peek() != std::ifstream::traits_type::eof()) die(prefix + ".bed is longer than its .bim / .fam say");
+  return d;
+}
+
 int main(int argc, char** argv) {
   const auto t_start = std::chrono::steady_clock::now();
   Conf conf = parse(argc, argv);
   if (conf.input_path.empty())
-    die("--input-path <file.vcf[.gz]> [more files] is required: the Google Genomics API the reference read "
+    die("--input-path <file.vcf[.gz]> [more files] or one PLINK fileset (<prefix>.bed) is required: the Google Genomics API the reference read "
         "from has been shut down");
   // VariantsCommon (VariantsCommon.scala:33-66): callset index/name maps + one dataset per variant set
   std::vector<Dataset> data;
@@ -439,8 +510,15 @@ int main(int argc, char** argv) {
     std::vector<Region> regions;
     if (!conf.all_references && !conf.references.empty())
       regions = parse_references(conf.references[std::min(k, conf.references.size() - 1)]);
-    data.push_back(load_vcf(conf.input_path[k], set_id_of(conf.input_path[k], k, used_stems), regions, (int32_t)ids.size(),
-                            conf.debug_datasets, conf.ingest_threads));
+    if (is_plink_path(conf.input_path[k])) {
+      if (conf.input_path.size() > 1 || conf.has_maf)
+        die("joining variant sets or filtering by allele frequency needs VCF inputs: a PLINK fileset is read as carriers "
+            "only (no ref/alt keys, no INFO/AF)");
+      data.push_back(load_plink(conf.input_path[k], set_id_of(conf.input_path[k], k, used_stems), regions, (int32_t)ids.size()));
+    } else {
+      data.push_back(load_vcf(conf.input_path[k], set_id_of(conf.input_path[k], k, used_stems), regions, (int32_t)ids.size(),
+                              conf.debug_datasets, conf.ingest_threads));
+    }
     ids.insert(ids.end(), data.back().ids.begin(), data.back().ids.end());
     names.insert(names.end(), data.back().names.begin(), data.back().names.end());
   }

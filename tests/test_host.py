@@ -405,6 +405,10 @@ def test_plink_fileset_ingest_reproduces_the_reference_carrier_rows(name, tmp_pa
                 for r in bparts[0][1]]
         assert [r for r in rows if r] == want
         assert all((np.asarray(r)[-1] >> np.uint32(n % 32)) == 0 for r in bparts[0][1]) if n % 32 else True
+        if not flip:   # the compiled host reads the same fileset (A2 = reference) and returns the same rows
+            stdout, got = _parse_only_rows(_driver_exe(), [prefix + ".bed"], str(tmp_path / "o"),
+                                           extra=["--references", "chr17:41196311:41277499"])
+            assert "Matrix size: %d." % n in stdout and got == want
         # the prefix and the .fam name the same fileset; a region that holds nothing gives no rows
         assert np.array_equal(ingest.load_plink(prefix, None, ref_allele="a1" if flip else "a2")[2][0][1], idx)
         empty = ingest.load_plink(prefix + ".fam", ["chr17:1:100"])[2][0]
@@ -427,6 +431,16 @@ def test_plink_reader_refuses_what_it_cannot_read(tmp_path):
     open(prefix + ".bed", "wb").write(b"BCF" + raw[3:])                         # another format
     with pytest.raises(ValueError):
         ingest.load_plink(prefix)
+    import subprocess
+    for bad in (raw[:2] + bytes([0]) + raw[3:], raw[:-1], raw + b"\x00", b"BCF" + raw[3:]):   # the compiled host says no too
+        open(prefix + ".bed", "wb").write(bad)
+        res = subprocess.run([_driver_exe(), "--input-path", prefix + ".bed", "--all-references", "--parse-only"],
+                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        assert res.returncode != 0
+    open(prefix + ".bed", "wb").write(raw)
+    res = subprocess.run([_driver_exe(), "--input-path", prefix + ".bed", prefix + ".bed", "--all-references", "--parse-only"],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert res.returncode != 0 and b"needs VCF inputs" in res.stdout
     # the driver front end: one PLINK fileset is a carrier source like a .npz; joins and the AF filter need VCF records
     vp = load_pkg("variants_pca")
     open(prefix + ".bed", "wb").write(raw)
