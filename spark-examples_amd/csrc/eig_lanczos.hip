@@ -384,6 +384,8 @@ hipError_t lanczos_topk(const EigWorkspace& ws, double* lz, int32_t n, int32_t k
   // relative residual 3.7e-9)
   int next_check = 12;
   if (debug_knobs().lanczos_first_check > 0) next_check = std::max(4, debug_knobs().lanczos_first_check);
+  // a check needs the k wanted Ritz values and one more for their gaps: T_m must have at least k + 2 rows (mmax does)
+  if (next_check < k + 2) next_check = k + 2;
   if (next_check > mmax) next_check = mmax;
   std::vector<double> cand, pageable;
   std::vector<int32_t> idx;
