@@ -560,6 +560,23 @@ def test_tiny_spectral_gap_falls_back_or_converges_correctly(P, O):
             assert np.linalg.norm(b @ comps[:, c] - lam[c] * comps[:, c]) <= 1e-8 * abs(lam[c])
 
 
+@pytest.mark.parametrize("n,k", [(300, 15), (300, 11)])
+def test_more_components_than_the_first_check_has_rows(P, O, n, k):
+    """num_pc >= 11: the first Ritz check (m = 12 by default) has fewer rows than k + 2, so it must wait for k + 2 Krylov
+    vectors (it used to index past its candidate list).  Eigenvalues vs a dense LAPACK solve of the oracle's B."""
+    rng = np.random.default_rng(5 + k)
+    x = planted_callsets(rng, n, 3000, k=6)
+    s = O.similarity_from_dense(x, n)
+    lam_ref = np.sort(np.linalg.eigvalsh(O.center_matrix(s)[0]))[::-1][:k]
+    with P.PcoaEngine(n) as eng:
+        eng.accumulate_dense(x)
+        comps, lam, _ = eng.compute(k)
+        t = eng.timings()
+    assert t["eig_method"] in (1, 2) and (t["eig_method"] == 2 or t["lanczos_steps"] >= k + 2)
+    assert np.max(np.abs(lam - lam_ref) / np.abs(lam_ref)) < 1e-9
+    assert np.abs(comps.T @ comps - np.eye(k)).max() < 1e-9
+
+
 def test_rank_deficient_inputs_through_the_lanczos_path(P, O):
     """Few variants => B has rank <= V: the Krylov space is exhausted after a handful of steps (breakdown).
     The fast path must either verify its pairs or fall back; the answer must be right either way."""
