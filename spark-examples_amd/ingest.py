@@ -157,7 +157,7 @@ def load_plink(path, references=None, ref_allele="a2", chunk_variants=4096, as_b
             keep.append(ok)
     keep = np.asarray(keep, dtype=bool)
     bpv = (n + 3) // 4                                          # bytes per variant
-    raw = np.fromfile(prefix + ".bed", dtype=np.uint8)
+    raw = np.memmap(prefix + ".bed", dtype=np.uint8, mode="r")     # a cohort's .bed can be tens of GB: read in chunks
     if raw.size < 3 or raw[0] != 0x6c or raw[1] != 0x1b:
         raise ValueError("%s.bed: not a PLINK 1 binary file" % prefix)
     if raw[2] != 1:
@@ -178,13 +178,20 @@ def load_plink(path, references=None, ref_allele="a2", chunk_variants=4096, as_b
             lut = sum(((b >> (2 * q + 1)) & 1) << q for q in range(4))
         lut = lut.astype(np.uint32)
         words = (n + 31) // 32
-        g = geno[keep]
-        nib = np.zeros((g.shape[0], words * 8), dtype=np.uint32)
-        nib[:, :bpv] = lut[g]
-        bits = np.zeros((g.shape[0], words), dtype=np.uint32)
-        nib = nib.reshape(g.shape[0], words, 8)
-        for k in range(8):
-            bits |= nib[:, :, k] << np.uint32(4 * k)
+        bits = np.zeros((int(keep.sum()), words), dtype=np.uint32)
+        done = 0
+        for v0 in range(0, keep.size, chunk_variants):
+            k = keep[v0:v0 + chunk_variants]
+            if not k.any():
+                continue
+            g = np.asarray(geno[v0:v0 + chunk_variants])[k]
+            nib = np.zeros((g.shape[0], words * 8), dtype=np.uint32)
+            nib[:, :bpv] = lut[g]
+            nib = nib.reshape(g.shape[0], words, 8)
+            out = bits[done:done + g.shape[0]]
+            for q in range(8):
+                out |= nib[:, :, q] << np.uint32(4 * q)
+            done += g.shape[0]
         if n % 32:
             bits[:, -1] &= np.uint32((1 << (n % 32)) - 1)        # the codes behind the last sample are padding
         return indexes, dict(zip(ids, names)), [("bits", bits)]
@@ -192,11 +199,10 @@ def load_plink(path, references=None, ref_allele="a2", chunk_variants=4096, as_b
     shifts = np.array([0, 2, 4, 6], dtype=np.uint8)
     idx_chunks, counts = [], []
     for v0 in range(0, keep.size, chunk_variants):
-        g = geno[v0:v0 + chunk_variants]
         k = keep[v0:v0 + chunk_variants]
         if not k.any():
             continue
-        g = g[k]
+        g = np.asarray(geno[v0:v0 + chunk_variants])[k]
         codes = ((g[:, :, None] >> shifts[None, None, :]) & 3).reshape(g.shape[0], -1)[:, :n]
         has = (codes == varies[0]) | (codes == varies[1])
         cnt = has.sum(axis=1)

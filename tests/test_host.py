@@ -399,7 +399,7 @@ def test_plink_fileset_ingest_reproduces_the_reference_carrier_rows(name, tmp_pa
         assert indexes["%s-3" % stem] == 3 and names["%s-3" % stem] == "S0003"
         # the bitset form (what the driver feeds to pcoa_accumulate_bits): the same carriers, every variant kept
         _, _, bparts = ingest.load_plink(prefix + ".bed", ["chr17:41196311:41277499"],
-                                         ref_allele="a1" if flip else "a2", as_bits=True)
+                                         ref_allele="a1" if flip else "a2", as_bits=True, chunk_variants=5)
         assert bparts[0][0] == "bits" and bparts[0][1].dtype == np.uint32 and bparts[0][1].shape[1] == (n + 31) // 32
         rows = [np.nonzero((np.asarray(r)[:, None] >> np.arange(32, dtype=np.uint32)[None, :]).reshape(-1)[:n] & 1)[0].tolist()
                 for r in bparts[0][1]]
