@@ -1,0 +1,681 @@
+// gram_kbits.inl -- FMT 2 of gram_packed.hip: the operand stays in HBM at ONE BIT per genotype and becomes MX-FP4 only
+// in registers, on the way into the matrix cores.  Included twice by gram_packed.hip (kernels inside its anonymous
+// namespace, launchers inside namespace pcoa); not a translation unit of its own.
+//
+// Why: the FP4 operand costs 1.28 GB written by the pre-pass and 4.3 GB re-read by
+// the contraction per 10^6 variants at N = 2504, and that L2-hit stream is what slows the fp32 pre-pass beside it.  A
+// genotype indicator is one bit; as bits the operand is 0.33 GB written and ~1.1 GB re-read.
+//
+// Operand layout K1[V/128][Npad][4 words] ("k-bits"): the 16 bytes at K1[blk][i] are sample i's indicators for the 128
+// variants of block blk, bit b of word j = variant 128 blk + 32 j + b.  A stage of the contraction is one block: 2 panels x
+// 256 samples x 16 B = 8 KiB (the FP4 stage is 32 KiB), one global_load_lds_dwordx4 per wave, and the LDS image IS the
+// global image.  A lane's operand of one MFMA (32 FP4 values = 4 dwords) comes from ONE word:
+//     d0 = (w << 1) & M,  d1 = w & M,  d2 = (w >> 1) & M,  d3 = (w >> 2) & M,   M = 0x22222222
+// i.e. bit b of the word lands in nibble b / 4 of dword b % 4 as 0x2 = E2M1 1.0 -- 7 VALU operations per fragment.  Which
+// variant sits in which of the MFMA's 64 k-slots does not matter: X^T X takes A and B from the same words through the
+// same function, so every product pairs a variant with itself (the remark on k-order in gram_packed.hip's header).
+// The wave layout, the accumulators, the ping-pong phases and the epilogue are those of gram_packed_kernel<1, ...>;
+// a wave reads its 6 operand rows of a stage with 6 ds_read_b64 (words of both k-steps at once, 3 KiB instead of the
+// 12 KiB of ds_read_b128 fragments) and expands them while its partner on the SIMD issues MFMAs.
+#ifdef PCOA_KBITS_KERNELS
+
+// ---------------------------------------------------------------------------------------------- pre-passes -> K1
+// fp32 / uint8 tile -> k-bits; verifies that every value is exactly 0 or 1 (flag bit 3), like pack_fp4_kernel.
+// One thread: 128 variants x 4 samples, in 8 batches of 16 rows (all 16 loads of a batch issued before the arithmetic).
+template <typename T, int VEC, bool NT = false>
+__global__ __launch_bounds__(256) void pack_kbits_kernel(const T* __restrict__ x, int64_t ld, int64_t nv, int n, int npad,
+                                                         int64_t nblk, uint32_t* __restrict__ p,
+                                                         int32_t* __restrict__ flag) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gw = npad >> 8;  // waves per block of 128 variants
+  const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t blk = wid / gw;
+  const int g = (int)(wid - blk * gw) * 64 + lane;
+  if (blk >= nblk) return;
+  const int i0 = g * 4;
+  bool bad = false;
+  uint32_t badw = 0;
+  uint32_t w[4][4];  // [sample][word]
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[s][q] = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if constexpr (VEC == 4) {
+        // ld % 4 == 0: a group of 4 columns is wholly inside the row or wholly padding (see pack_fp4_kernel)
+        typedef typename std::conditional<sizeof(T) == 4, f32x4_t, uint32_t>::type Raw;
+        Raw raw[16];
+        const int64_t col = (i0 < ld) ? i0 : 0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const int64_t row = blk * 128 + c * 32 + h * 16 + t;
+          const T* src = x + (row < nv ? row : nv - 1) * ld + col;
+          if constexpr (NT) raw[t] = __builtin_nontemporal_load(reinterpret_cast<const Raw*>(src));
+          else raw[t] = *reinterpret_cast<const Raw*>(src);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const int64_t row = blk * 128 + c * 32 + h * 16 + t;
+          const uint32_t valid = (uint32_t)(row < nv) & (uint32_t)(i0 < ld);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            uint32_t is1, is0;
+            if constexpr (sizeof(T) == 4) {
+              is1 = (uint32_t)(raw[t][s] == 1.0f);
+              is0 = (uint32_t)(raw[t][s] == 0.0f);
+            } else {
+              const uint32_t b = (raw[t] >> (8 * s)) & 0xffu;
+              is1 = (uint32_t)(b == 1u);
+              is0 = (uint32_t)(b == 0u);
+            }
+            const uint32_t live = valid & (uint32_t)(i0 + s < n);  // columns [n, ld) may hold anything
+            badw |= live & ((is1 | is0) ^ 1u);
+            w[s][c] |= (live & is1) << (h * 16 + t);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const int64_t row = blk * 128 + c * 32 + h * 16 + t;
+          if (row < nv) {
+            const T* src = x + row * ld + i0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              if (i0 + s < n) {  // (n <= ld) padding columns [n, ld) may hold anything: ignored
+                const T v = src[s];
+                const bool is1 = (v == (T)1);
+                bad |= !(is1 || v == (T)0);
+                w[s][c] |= (is1 ? 1u : 0u) << (h * 16 + t);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  uint4* dst = reinterpret_cast<uint4*>(p + ((size_t)blk * npad + i0) * 4);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) dst[s] = make_uint4(w[s][0], w[s][1], w[s][2], w[s][3]);
+  if (bad || badw) atomicOr(flag, 8);
+}
+
+// uint8 tile, 8-byte loads (ld % 8 == 0, 8-byte aligned base): one thread = 128 variants x 8 samples.  Per batch of 8 rows
+// the 0/1 bytes of row t are OR-ed in at bit t, which leaves one byte of 8 row-bits per sample: byte q of word c.
+__global__ __launch_bounds__(256) void pack_u8x8_kbits_kernel(const uint8_t* __restrict__ x, int64_t ld, int64_t nv, int n,
+                                                              int npad, int64_t nblk, uint32_t* __restrict__ p,
+                                                              int32_t* __restrict__ flag) {
+  const int groups = npad >> 3;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t blk = gid / groups;
+  const int g = (int)(gid - blk * groups);
+  if (blk >= nblk) return;
+  const int i0 = g * 8;
+  uint32_t m[2];  // byte masks of the columns that exist (< n); columns in [n, ld) may hold anything
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    uint32_t mm = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (i0 + 4 * d + b < n) mm |= 0xffu << (8 * b);
+    m[d] = mm;
+  }
+  const bool in_row = i0 < ld;
+  uint32_t o[8][4];
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[s][c] = 0;
+  uint32_t bad = 0;
+  // a real loop over the four k-blocks (32 rows in flight at a time): unrolled, all 128 row loads are hoisted to the top
+  // and the kernel needs 256 VGPRs + AGPR spills; the word index is then selected statically
+#pragma unroll 1
+  for (int c = 0; c < 4; ++c) {
+    uint32_t oc[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) oc[s] = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint32_t a0 = 0, a1 = 0;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int64_t row = blk * 128 + c * 32 + q * 8 + t;
+        uint2 u = make_uint2(0u, 0u);
+        if (row < nv && in_row) u = *reinterpret_cast<const uint2*>(x + row * ld + i0);
+        u.x &= m[0];
+        u.y &= m[1];
+        bad |= (u.x | u.y) & 0xfefefefeu;
+        a0 |= (u.x & 0x01010101u) << t;
+        a1 |= (u.y & 0x01010101u) << t;
+      }
+#pragma unroll
+      for (int sidx = 0; sidx < 4; ++sidx) {
+        oc[sidx] |= ((a0 >> (8 * sidx)) & 0xffu) << (8 * q);
+        oc[4 + sidx] |= ((a1 >> (8 * sidx)) & 0xffu) << (8 * q);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) o[s][cc] = (c == cc) ? oc[s] : o[s][cc];
+  }
+  uint4* dst = reinterpret_cast<uint4*>(p + ((size_t)blk * npad + i0) * 4);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) dst[s] = make_uint4(o[s][0], o[s][1], o[s][2], o[s][3]);
+  if (bad) atomicOr(flag, 8);
+}
+
+// Carrier bitsets (pcoa_accumulate_bits: row v = variant v, bit i & 31 of word i >> 5 = sample i) -> k-bits: 32 x 32 bit
+// transposes.  One wave = one block of 128 variants x 256 samples; lane (t, j) loads the 16 bytes of row t that hold
+// samples 128 j .. 128 j + 127 of the wave's range, as expand_bits_fp4_kernel does (32 contiguous bytes per row and wave).
+// Each of a lane's four dwords belongs to a 32 x 32 bit matrix held by the 32 lanes of its half (lane = variant, bit =
+// sample); five butterfly steps (exchange with lane ^ 16, 8, 4, 2, 1: ds_bpermute, v_alignbit, v_bfi) transpose it in
+// place, after which lane i holds sample i's word of the k-block.  4 k-blocks x 4 dwords = 16 transposes per lane, then
+// four coalesced 16-byte stores.
+template <int VEC>
+__global__ __launch_bounds__(256) void transpose_bits_kbits_kernel(const uint32_t* __restrict__ bits, int64_t ld_words,
+                                                                   int64_t nv, int n, int npad, int64_t nblk,
+                                                                   uint32_t* __restrict__ p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gpk = npad >> 8;  // 256-sample groups per block
+  const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t blk = wid / gpk;
+  const int G = (int)(wid - blk * gpk);
+  if (blk >= nblk) return;
+  const int t = lane & 31, j = lane >> 5;
+  const int64_t w0 = 8 * (int64_t)G + 4 * j;  // first of this lane's four dwords of a row
+  // per-lane constants of the five butterfly steps: which half of the pair this lane is, the bits it keeps, and the
+  // rotation that brings the partner's bits into place
+  uint32_t keep[5], rot[5];
+#pragma unroll
+  for (int st = 0; st < 5; ++st) {
+    const int jj = 16 >> st;
+    const uint32_t m = jj == 16 ? 0x0000ffffu : jj == 8 ? 0x00ff00ffu : jj == 4 ? 0x0f0f0f0fu : jj == 2 ? 0x33333333u : 0x55555555u;
+    const bool upper = (t & jj) == 0;
+    keep[st] = upper ? m : ~m;
+    rot[st] = upper ? (uint32_t)(32 - jj) : (uint32_t)jj;
+  }
+  uint32_t out[4][4];  // [dword q][k-block c]
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int64_t row = blk * 128 + c * 32 + t;
+    uint32_t cw[4] = {0u, 0u, 0u, 0u};
+    if (row < nv) {
+      const uint32_t* r = bits + row * ld_words;
+      if (VEC == 4 && w0 + 3 < ld_words) {
+        const uint4 u = *reinterpret_cast<const uint4*>(r + w0);
+        cw[0] = u.x; cw[1] = u.y; cw[2] = u.z; cw[3] = u.w;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (w0 + q < ld_words) cw[q] = r[w0 + q];
+      }
+    }
+    // bits of samples >= N (row padding, the tail of the last word) are ignored
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t first = 32 * (w0 + q);
+      if (first >= n) cw[q] = 0u;
+      else if (first + 32 > n) cw[q] &= (1u << (n - (int)first)) - 1u;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint32_t v = cw[q];
+#pragma unroll
+      for (int st = 0; st < 5; ++st) {
+        const int jj = 16 >> st;
+        const uint32_t y = (uint32_t)__shfl_xor((int)v, jj, 64);
+        const uint32_t ysh = __builtin_amdgcn_alignbit(y, y, rot[st]);  // rotate right
+        v = (v & keep[st]) | (ysh & ~keep[st]);
+      }
+      out[q][c] = v;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)  // sample 256 G + 128 j + 32 q + t
+    *reinterpret_cast<uint4*>(p + ((size_t)blk * npad + (size_t)256 * G + 128 * j + 32 * q + t) * 4) =
+        make_uint4(out[q][0], out[q][1], out[q][2], out[q][3]);
+}
+
+// CSR carrier lists WITHOUT repeats (the host checks) -> k-bits: one wave per variant row, bit (row % 32) of word
+// (row % 128) / 32 in sample c's 16-byte slot of block row / 128, through a 32-bit atomic OR.  Zero-filled beforehand.
+__global__ __launch_bounds__(256) void densify_csr_kbits_kernel(const int32_t* __restrict__ idx,
+                                                                const int64_t* __restrict__ offs, int64_t nv,
+                                                                int64_t offs_base, uint32_t* __restrict__ p, int npad,
+                                                                int32_t n, int32_t* __restrict__ flag) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nv) return;
+  const int64_t b = offs[row] - offs_base, e = offs[row + 1] - offs_base;
+  const int64_t blk = row >> 7;
+  const int r = (int)(row & 127);
+  for (int64_t q = b + lane; q < e; q += 64) {
+    const int32_t c = idx[q];
+    if (c < 0 || c >= n) {
+      atomicOr(flag, 1);
+      continue;
+    }
+    atomicOr(p + ((size_t)blk * npad + c) * 4 + (r >> 5), 1u << (r & 31));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- contraction
+struct StageBits {
+  uint32_t pi[256][4];  // panel I: [sample][word]; word 2 * hi + k2 is what lane half `hi` feeds to k-step k2
+  uint32_t pj[TJ][4];   // panel J
+};
+
+// 8 DMA instructions of 1 KiB per stage, one per wave (waves 0-3: the quarters of panel I, 4-7: of panel J); a diagonal
+// tile brings in its single panel with waves 0-3 only.
+template <bool DIAG>
+__device__ __forceinline__ void issue_stage_bits(StageBits* st, const int8_t* __restrict__ p, int npad, int64_t blk,
+                                                 int col_i, int col_j, int wave, int lane) {
+  if (DIAG && wave >= 4) return;  // wave-uniform
+  const bool is_i = wave < 4;
+  const int q = wave & 3;
+  const int c0 = (is_i ? col_i : col_j) + q * 64;
+  const int8_t* src = p + ((size_t)blk * npad + c0 + lane) * 16;
+  uint32_t* dst = is_i ? &st->pi[q * 64][0] : &st->pj[q * 64][0];
+  __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+}
+
+// the two words (k-steps 0 and 1) of each of the wave's 4 A rows and 2 B rows: 6 ds_read_b64, conflict-free (a half-wave
+// reads 32 consecutive 16-byte slots at the same 8-byte offset, the other half the other 8 bytes)
+template <bool DIAG>
+__device__ __forceinline__ void read_words(const StageBits* st, int wm, int wn, int lane, uint2 (&raw)[6]) {
+  const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+    raw[mi] = *reinterpret_cast<const uint2*>(&st->pi[wm * 128 + mi * 32 + l31][2 * hi]);
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    if constexpr (DIAG) raw[4 + ni] = *reinterpret_cast<const uint2*>(&st->pi[wn * 64 + ni * 32 + l31][2 * hi]);
+    else raw[4 + ni] = *reinterpret_cast<const uint2*>(&st->pj[wn * 64 + ni * 32 + l31][2 * hi]);
+  }
+}
+
+__device__ __forceinline__ i32x4 expand_word_fp4(uint32_t w) {
+  constexpr uint32_t M = 0x22222222u;  // E2M1 1.0 in every nibble
+  i32x4 r;
+  r[0] = (int)((w << 1) & M);
+  r[1] = (int)(w & M);
+  r[2] = (int)((w >> 1) & M);
+  r[3] = (int)((w >> 2) & M);
+  return r;
+}
+
+__device__ __forceinline__ void expand_frags(const uint2 (&raw)[6], FragsI8<2> (&f)[2]) {
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    f[0].a[mi] = expand_word_fp4(raw[mi].x);
+    f[1].a[mi] = expand_word_fp4(raw[mi].y);
+  }
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    f[0].b[ni] = expand_word_fp4(raw[4 + ni].x);
+    f[1].b[ni] = expand_word_fp4(raw[4 + ni].y);
+  }
+  // The expansion is pure arithmetic: left alone, the optimiser sinks it below the phase barrier to just in front of the
+  // MFMAs that consume it -- into the phase where the wave should do nothing but feed the matrix pipe.  An empty asm
+  // that "modifies" every fragment pins the arithmetic here, in the wave's read phase.
+#pragma unroll
+  for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) asm volatile("" : "+v"(f[k2].a[mi]));
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) asm volatile("" : "+v"(f[k2].b[ni]));
+  }
+}
+
+// One stage of the ping-pong schedule (pp_stage of gram_packed.hip with the operand expanded in registers).  The phases,
+// the barriers and the vmcnt book-keeping are the same; PER_WAVE = 1 DMA instruction per wave and stage.
+template <int NST, int BUF, int GRP, bool IDLE, int LEFT, bool DIAG>
+__device__ __forceinline__ void ppb_stage(StageBits* lds, const int8_t* __restrict__ p, int npad, int64_t blk_begin, int s,
+                                          int ns, int col_i, int col_j, int wave, int lane, int wm, int wn,
+                                          f32x16 (&acc)[4][2], FragsI8<2> (&f)[2]) {
+  constexpr int PER_WAVE = 1;
+  constexpr int D = NST - 1;
+  constexpr int TOT = 16;  // MFMAs per wave and stage
+  const bool more = s + D < ns;
+  uint2 raw[6];
+  if constexpr (GRP == 0) {
+    // ---- phase 2s: read + expand stage s, issue the DMA of stage s+D
+    if constexpr (!IDLE) read_words<DIAG>(&lds[BUF], wm, wn, lane, raw);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) issue_stage_bits<DIAG>(&lds[(BUF + D) % NST], p, npad, blk_begin + s + D, col_i, col_j, wave, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!IDLE) expand_frags(raw, f);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    raw_barrier();
+    // ---- phase 2s+1: the MFMAs of stage s
+    if constexpr (!IDLE) {
+      asm volatile("s_nop 1");  // VALU-written operands -> MFMA (the barrier covers it; this makes it unconditional)
+      __builtin_amdgcn_s_setprio(1);
+      mfma_range<1, 2, 4, 0, TOT - LEFT>(f, acc);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  } else {
+    // ---- phase 2s: issue the DMA of stage s+D, then the MFMAs of stage s-1
+    if (more) issue_stage_bits<DIAG>(&lds[(BUF + D) % NST], p, npad, blk_begin + s + D, col_i, col_j, wave, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!IDLE) {
+      if (s > 0) {
+        asm volatile("s_nop 1");
+        __builtin_amdgcn_s_setprio(1);
+        mfma_range<1, 2, 4, 0, TOT - LEFT>(f, acc);
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+    raw_barrier();
+    // ---- phase 2s+1: (the leftover MFMAs of stage s-1, then) read + expand stage s
+    if constexpr (!IDLE) {
+      if constexpr (LEFT > 0) {
+        if (s > 0) {
+          __builtin_amdgcn_s_setprio(2);
+          mfma_range<1, 2, 4, TOT - LEFT, TOT>(f, acc);
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      read_words<DIAG>(&lds[BUF], wm, wn, lane, raw);
+      expand_frags(raw, f);
+    }
+  }
+  // end of phase 2s+1: stage s+1 must have landed (own share), only the DMA of stage s+2.. may stay in flight
+  if (s + 1 < ns) {
+    const int rem = ns - 2 - s;
+    const int keep = rem < D - 1 ? rem : D - 1;
+    if (keep >= 2) wait_vmcnt<(D >= 3 ? 2 * PER_WAVE : 0)>();
+    else if (keep == 1) wait_vmcnt<(D >= 2 ? PER_WAVE : 0)>();
+    else wait_vmcnt<0>();
+  }
+  if constexpr (GRP == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  raw_barrier();
+  if constexpr (GRP == 0 && !IDLE && LEFT > 0) {  // group 0's leftover MFMAs of stage s, into phase 2(s+1)
+    __builtin_amdgcn_s_setprio(2);
+    mfma_range<1, 2, 4, TOT - LEFT, TOT>(f, acc);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int NST, int GRP, bool IDLE, int LEFT, bool DIAG, int... Is>
+__device__ __forceinline__ void ppb_round(StageBits* lds, const int8_t* __restrict__ p, int npad, int64_t blk_begin, int s,
+                                          int ns, int count, int col_i, int col_j, int wave, int lane, int wm, int wn,
+                                          f32x16 (&acc)[4][2], FragsI8<2> (&f)[2], std::integer_sequence<int, Is...>) {
+  ((Is < count ? ppb_stage<NST, Is, GRP, IDLE, LEFT, DIAG>(lds, p, npad, blk_begin, s + Is, ns, col_i, col_j, wave, lane, wm,
+                                                           wn, acc, f)
+               : (void)0),
+   ...);
+}
+
+template <int NST, int GRP, bool IDLE, int LEFT, bool DIAG>
+__device__ __forceinline__ void ppb_loop(StageBits* lds, const int8_t* __restrict__ p, int npad, int64_t blk_begin, int ns,
+                                         int col_i, int col_j, int wave, int lane, int wm, int wn,
+                                         f32x16 (&acc)[4][2]) {
+  FragsI8<2> f[2];
+  // prologue: stages 0 .. NST-2 go in flight; stage 0 must have landed before group 0 reads it in phase 0
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i)
+    if (i < ns) issue_stage_bits<DIAG>(&lds[i], p, npad, blk_begin + i, col_i, col_j, wave, lane);
+  if (ns > 1 && NST > 2) wait_vmcnt<(NST > 2 ? 1 : 0)>();
+  else wait_vmcnt<0>();
+  raw_barrier();
+  int s = 0;
+  for (; s + NST - 1 < ns; s += NST)
+    ppb_round<NST, GRP, IDLE, LEFT, DIAG>(lds, p, npad, blk_begin, s, ns, NST, col_i, col_j, wave, lane, wm, wn, acc, f,
+                                          std::make_integer_sequence<int, NST>{});
+  if (s < ns)
+    ppb_round<NST, GRP, IDLE, LEFT, DIAG>(lds, p, npad, blk_begin, s, ns, ns - s, col_i, col_j, wave, lane, wm, wn, acc, f,
+                                          std::make_integer_sequence<int, NST - 1>{});
+  if constexpr (GRP == 1 && !IDLE) {  // phase 2*ns: group 1's MFMAs of the last stage, nobody to wait for
+    asm volatile("s_nop 1");
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) mfma_step_i8<1, 2>(f[k2], acc);
+  }
+}
+
+// Work decomposition: xcd_map 0 / 1 / 2 as gram_packed_kernel (legacy split-K, split-K with one k-slice per XCD,
+// lock-step); xcd_map 4 = even split: `nwork` = ntri * nstages (tile, stage) units in tile-major order are cut into
+// gridDim.x equal runs, a workgroup walks its run and pays one epilogue per tile it touches (at most
+// ceil(run / nstages) + 1).  Every CU gets the same number of MFMAs whatever ntri is (55 tiles x split-K 4 leaves 36 of
+// 256 CUs idle in the lock-step launch).
+template <int NST, int LEFT>
+__global__ __launch_bounds__(512, 2) void gram_kbits_kernel(const int8_t* __restrict__ p, int npad, int64_t nstages, int n,
+                                                            int ntile, int ntri, int splitk, int64_t stages_per,
+                                                            int32_t* __restrict__ s32, int xcd_map,
+                                                            const int32_t* __restrict__ skip, GramStrip strip) {
+  __shared__ __attribute__((aligned(16))) StageBits lds[NST];
+  if (skip != nullptr && *skip != 0) return;  // auto mode's device-side predicate (gram_packed_kernel)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int b = blockIdx.x;
+
+  // the run of (tile, stage) units of this workgroup: [u, u_end) in tile-major order
+  int64_t u, u_end;
+  if (xcd_map == 4) {
+    const int64_t nwork = (int64_t)ntri * nstages;
+    const int64_t nwg = gridDim.x;
+    // consecutive runs go to consecutive workgroups of ONE XCD (block b runs on XCD b % 8), so that the workgroups
+    // which share a tile's operand panels at about the same k also share an L2
+    const int64_t slot = (nwg % kNumXcd == 0) ? (int64_t)(b & 7) * (nwg / kNumXcd) + (b >> 3) : (int64_t)b;
+    u = nwork * slot / nwg;
+    u_end = nwork * (slot + 1) / nwg;
+  } else {
+    int tile, ks;
+    if (xcd_map == 2) {
+      const int g = kNumXcd / splitk;
+      const int per = (ntri + g - 1) / g;
+      const int xcd = b & 7, slot = b >> 3;
+      tile = (xcd % g) * per + slot;
+      ks = xcd / g;
+      if (slot >= per || tile >= ntri) return;
+    } else if (xcd_map) {
+      const int q = b >> 3;
+      ks = (b & 7) + kNumXcd * (q / ntri);
+      tile = q % ntri;
+    } else {
+      tile = b % ntri;
+      ks = b / ntri;
+    }
+    const int64_t st_begin = (int64_t)ks * stages_per;
+    const int64_t st_end = (st_begin + stages_per < nstages) ? (st_begin + stages_per) : nstages;
+    if (st_begin >= st_end) return;
+    u = (int64_t)tile * nstages + st_begin;
+    u_end = (int64_t)tile * nstages + st_end;
+  }
+
+  while (u < u_end) {  // workgroup-uniform
+    const int tile = (int)(u / nstages);
+    const int64_t st_begin = u - (int64_t)tile * nstages;
+    const int64_t left = u_end - u;
+    const int ns = (int)((nstages - st_begin < left) ? (nstages - st_begin) : left);
+    u += ns;
+
+    int row_blk, col_blk;
+    if (strip.cols > 0) {  // strip owner: all (row block, column block of the strip) tiles, banded (gram_packed_kernel)
+      const int ctiles = ntri / ntile;
+      const int per_band = BAND * ctiles;
+      const int band = tile / per_band;
+      const int r0 = band * BAND;
+      const int h = (ntile - r0 < BAND) ? (ntile - r0) : BAND;
+      const int rem = tile - band * per_band;
+      row_blk = r0 + rem % h;
+      col_blk = strip.cb0 + rem / h;
+    } else {
+      tile_coords<2>(tile, ntile, row_blk, col_blk);
+    }
+    const int col_i = row_blk * 256, col_j = col_blk * TJ;
+    const bool idle = strip.cols == 0 && (col_i + wm * 128) > (col_j + wn * 64 + 63);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0;
+
+    if (row_blk == col_blk && strip.cols == 0) {  // diagonal tile: one panel (workgroup-uniform branch)
+      if (wm == 0) ppb_loop<NST, 0, false, LEFT, true>(lds, p, npad, st_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
+      else if (idle) ppb_loop<NST, 1, true, LEFT, true>(lds, p, npad, st_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
+      else ppb_loop<NST, 1, false, LEFT, true>(lds, p, npad, st_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
+    } else if (wm == 0) {
+      ppb_loop<NST, 0, false, LEFT, false>(lds, p, npad, st_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
+    } else {
+      ppb_loop<NST, 1, false, LEFT, false>(lds, p, npad, st_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
+    }
+
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last asm MFMA -> VALU read of D
+    if (!idle) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int j = col_j + wn * 64 + ni * 32 + (lane & 31);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int i = col_i + wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int v = (int)acc[mi][ni][r];  // exact integers below 2^24
+            if (strip.cols > 0) {
+              if (i < n && j >= strip.col0 && j < strip.col0 + strip.cols && v != 0)
+                atomicAdd(&s32[(int64_t)i * strip.cols + (j - strip.col0)], v);
+            } else if (j >= i && j < n && v != 0) {
+              atomicAdd(&s32[(int64_t)i * n + j], v);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    // the next tile of this run reuses the LDS ring: every wave must be out of this tile's last stage first (the loops
+    // end with a barrier after the last reads; the epilogue touches no LDS)
+  }
+}
+
+#endif  // PCOA_KBITS_KERNELS
+
+#ifdef PCOA_KBITS_LAUNCHERS
+
+// k-bits pre-passes.  nblk_out: blocks of 128 variants to write (the tail beyond nv is zero-filled); p = first block.
+hipError_t launch_pack_kbits(const void* x, int is_u8, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
+                             hipStream_t stream, int64_t nblk_out) {
+  if (nv <= 0) return hipSuccess;
+  const int npad = (int)gram_packed_npad(n);
+  const int64_t nblk = nblk_out > 0 ? nblk_out : (nv + 127) / 128;
+  const int64_t blocks = (nblk * (npad >> 8) + 3) / 4;  // one wave per (block, 256 samples)
+  if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+  uint32_t* pw = reinterpret_cast<uint32_t*>(p);
+  const uintptr_t addr = reinterpret_cast<uintptr_t>(x);
+  const dim3 grid((unsigned)blocks), block(256);
+  if (is_u8) {
+    const uint8_t* xs = static_cast<const uint8_t*>(x);
+    if (((ld & 7) == 0) && ((addr & 7) == 0)) {
+      const int64_t blocks8 = (nblk * (npad >> 3) + 255) / 256;
+      if (blocks8 > 0x7fffffffLL) return hipErrorInvalidValue;
+      hipLaunchKernelGGL(pack_u8x8_kbits_kernel, dim3((unsigned)blocks8), block, 0, stream, xs, ld, nv, n, npad, nblk, pw,
+                         flag);
+      return hipGetLastError();
+    }
+    const bool vec = ((ld & 3) == 0) && ((addr & 3) == 0);
+    if (vec) hipLaunchKernelGGL((pack_kbits_kernel<uint8_t, 4>), grid, block, 0, stream, xs, ld, nv, n, npad, nblk, pw, flag);
+    else hipLaunchKernelGGL((pack_kbits_kernel<uint8_t, 1>), grid, block, 0, stream, xs, ld, nv, n, npad, nblk, pw, flag);
+  } else {
+    const bool vec = ((ld & 3) == 0) && ((addr & 15) == 0);
+    const float* xs = static_cast<const float*>(x);
+    if (vec) hipLaunchKernelGGL((pack_kbits_kernel<float, 4, true>), grid, block, 0, stream, xs, ld, nv, n, npad, nblk, pw, flag);
+    else hipLaunchKernelGGL((pack_kbits_kernel<float, 1>), grid, block, 0, stream, xs, ld, nv, n, npad, nblk, pw, flag);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_transpose_bits_kbits(const uint32_t* bits, int64_t ld_words, int64_t nv, int32_t n, int8_t* p,
+                                       hipStream_t stream, int64_t nblk_out) {
+  if (nv <= 0) return hipSuccess;
+  const int npad = (int)gram_packed_npad(n);
+  const int64_t nblk = nblk_out > 0 ? nblk_out : (nv + 127) / 128;
+  const int64_t blocks = (nblk * (npad >> 8) + 3) / 4;
+  if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+  uint32_t* pw = reinterpret_cast<uint32_t*>(p);
+  const bool vec = ((ld_words & 3) == 0) && ((reinterpret_cast<uintptr_t>(bits) & 15) == 0);
+  if (vec)
+    hipLaunchKernelGGL(transpose_bits_kbits_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, stream, bits, ld_words, nv, n,
+                       npad, nblk, pw);
+  else
+    hipLaunchKernelGGL(transpose_bits_kbits_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, bits, ld_words, nv, n,
+                       npad, nblk, pw);
+  return hipGetLastError();
+}
+
+hipError_t launch_densify_csr_kbits(const int32_t* idx_dev, const int64_t* offs_dev, int64_t nv, int64_t offs_base,
+                                    int8_t* p, int32_t n, int32_t* flag, hipStream_t stream, int64_t nblk_out) {
+  if (nv <= 0) return hipSuccess;
+  const int npad = (int)gram_packed_npad(n);
+  hipError_t e = hipMemsetAsync(p, 0, (size_t)nblk_out * (size_t)npad * 16, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(densify_csr_kbits_kernel, dim3((unsigned)((nv + 3) / 4)), dim3(256), 0, stream, idx_dev, offs_dev, nv,
+                     offs_base, reinterpret_cast<uint32_t*>(p), npad, n, flag);
+  return hipGetLastError();
+}
+
+// Contraction of a k-bits operand.  mode: 0 = legacy split-K launch, 2 = lock-step (splitk k-streams on 8 / splitk XCDs,
+// fails with hipErrorInvalidValue where the shape does not fit `num_cu`), 4 = even split over `num_cu` workgroups.
+hipError_t launch_gram_kbits(const int8_t* p, int64_t nv, int32_t n, int32_t* s32, int num_cu, hipStream_t stream, int mode,
+                             const int32_t* skip, GramStrip strip) {
+  if (nv <= 0) return hipSuccess;
+  const int cus = num_cu > 0 ? num_cu : 256;
+  const int npad = (int)gram_packed_npad(n);
+  const int ntile = npad / TJ;
+  int64_t ntri64 = (int64_t)ntile * (ntile + 1) / 2;
+  if (strip.cols > 0) {
+    strip.cb0 = strip.col0 / TJ;
+    const int cb1 = (strip.col0 + strip.cols + TJ - 1) / TJ;
+    ntri64 = (int64_t)ntile * (cb1 - strip.cb0);
+  }
+  if (ntri64 > (1 << 28)) return hipErrorInvalidValue;
+  const int ntri = (int)ntri64;
+  const int64_t nstages = gram_kb_pad(nv, 2) / 4;  // blocks of 128 variants (the operand is padded to whole blocks)
+  int64_t splitk = 1, stages_per = nstages, nblocks = 0;
+  int xcd_map = 0;
+  if (mode == 2) {
+    if (strip.cols > 0) return hipErrorInvalidValue;
+    splitk = gram_lockstep_splitk(n, cus);
+    if (splitk == 0) return hipErrorInvalidValue;
+    const int g = kNumXcd / (int)splitk;
+    const int per = (ntri + g - 1) / g;
+    stages_per = (nstages + splitk - 1) / splitk;
+    nblocks = (int64_t)per * kNumXcd;
+    xcd_map = 2;
+  } else if (mode == 4) {
+    // one workgroup per CU, but never runs shorter than 8 stages (1,024 variants): an epilogue costs about as much
+    const int64_t nwork = (int64_t)ntri * nstages;
+    nblocks = std::max<int64_t>(1, std::min<int64_t>(cus, nwork / 8));
+    if (nblocks >= kNumXcd) nblocks = nblocks / kNumXcd * kNumXcd;  // the kernel's XCD-aware run order needs a multiple of 8
+    xcd_map = 4;
+  } else {
+    const int64_t target = (int64_t)cus * 7;
+    splitk = (target + ntri - 1) / ntri;
+    if (debug_knobs().gram_splitk > 0) splitk = debug_knobs().gram_splitk;
+    const int64_t max_by_work = nstages * 4 / 64;
+    if (splitk > max_by_work) splitk = max_by_work;
+    if (splitk < 1) splitk = 1;
+    if (splitk >= kNumXcd) {
+      splitk = (splitk / kNumXcd) * kNumXcd;
+      xcd_map = 1;
+    }
+    stages_per = (nstages + splitk - 1) / splitk;
+    nblocks = (int64_t)ntri * splitk;
+  }
+  if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((gram_kbits_kernel<4, 2>), dim3((unsigned)nblocks), dim3(512), 0, stream, p, npad, nstages, n, ntile,
+                     ntri, (int)splitk, stages_per, s32, xcd_map, skip, strip);
+  return hipGetLastError();
+}
+
+#endif  // PCOA_KBITS_LAUNCHERS

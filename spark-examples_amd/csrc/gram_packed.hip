@@ -30,6 +30,7 @@
 //   ping-pong schedule without the two MFMAs issued behind the phase barrier.
 //
 // Measured at N = 2504 per 10^6 variants: FP4 1.13-1.16 ms (6 PFLOP/s issued), int8 2.14 ms; DESIGN.md 4.1 / 4.2.
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -1178,6 +1179,10 @@ __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram
   }
 }
 
+#define PCOA_KBITS_KERNELS
+#include "gram_kbits.inl"
+#undef PCOA_KBITS_KERNELS
+
 }  // namespace
 
 int64_t gram_packed_npad(int32_t n) { return ((int64_t)n + TM - 1) / TM * TM; }
@@ -1373,6 +1378,10 @@ hipError_t launch_gram_packed_lockstep(const int8_t* p, int fmt, int64_t nv, int
                        splitk, stages_per, s32, map, skip, GramStrip{});
   return hipGetLastError();
 }
+
+#define PCOA_KBITS_LAUNCHERS
+#include "gram_kbits.inl"
+#undef PCOA_KBITS_LAUNCHERS
 
 hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, int32_t* s32, int num_cu,
                               hipStream_t stream, int* splitk_out, const int32_t* skip, GramStrip strip) {

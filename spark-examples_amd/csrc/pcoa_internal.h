@@ -31,6 +31,10 @@ struct DebugKnobs {
   int gram_cfg = 0;                // PCOA_GRAM_I8_CFG: contraction schedule (library built with -DPCOA_EXPERIMENTS only)
   int gram_splitk = 0;             // PCOA_GRAM_I8_SPLITK: split-K of the legacy launch
   int lockstep = -1;               // PCOA_GRAM_LOCKSTEP = 0 | 1: lock-step contraction launch off / on where it fits
+  int guard = 0;                   // PCOA_DEBUG_GUARD = 1 | 2: every device buffer ends (1) / starts (2) at an unmapped page
+  int operand = 0;                 // PCOA_OPERAND = fp4 | bits -> 1 | 2: operand of the binary-tile contraction (0 = default)
+  int kbits_mode = -1;             // PCOA_KBITS_MODE = 0 | 2 | 4: launch form of the k-bits contraction (whole chip)
+  int kbits_pipe_wgs = 0;          // PCOA_KBITS_PIPE_WGS: workgroups of the k-bits contraction beside the fp32 pre-pass
 };
 const DebugKnobs& debug_knobs();
 
@@ -69,6 +73,14 @@ hipError_t launch_expand_bits_fp4(const uint32_t* bits, int64_t ld_words, int64_
                                   hipStream_t stream, int64_t nkb_out = 0);
 hipError_t launch_pack_fp4(const void* x, int is_u8, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
                            hipStream_t stream, int64_t nkb_out = 0);
+// k-bits operand (gram_kbits.inl): K1[V/128][Npad][4 words], one BIT per genotype, expanded to FP4 in registers by the
+// contraction.  nblk_out = blocks of 128 variants to write (the tail beyond nv is zero-filled).
+hipError_t launch_pack_kbits(const void* x, int is_u8, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
+                             hipStream_t stream, int64_t nblk_out);
+hipError_t launch_transpose_bits_kbits(const uint32_t* bits, int64_t ld_words, int64_t nv, int32_t n, int8_t* p,
+                                       hipStream_t stream, int64_t nblk_out);
+hipError_t launch_densify_csr_kbits(const int32_t* idx_dev, const int64_t* offs_dev, int64_t nv, int64_t offs_base,
+                                    int8_t* p, int32_t n, int32_t* flag, hipStream_t stream, int64_t nblk_out);
 bool pack_fp4_ring_ok(const void* x, int64_t ld);
 hipError_t launch_pack_fp4_ring(const float* x, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
                                 hipStream_t stream, int64_t nkb_out, int wgs, int nt);
@@ -85,6 +97,9 @@ hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, i
                               GramStrip strip = GramStrip{});
 // Lock-step launch: all tiles of `splitk` k-streams resident at once, one workgroup per CU for the whole launch.
 // gram_lockstep_splitk: the k-stream count that fits `cus` CUs (8 XCDs), 0 if the shape does not fit.
+// k-bits contraction; mode 0 = split-K launch, 2 = lock-step, 4 = even split of the (tile, stage) units over num_cu workgroups
+hipError_t launch_gram_kbits(const int8_t* p, int64_t nv, int32_t n, int32_t* s32, int num_cu, hipStream_t stream, int mode,
+                             const int32_t* skip = nullptr, GramStrip strip = GramStrip{});
 int gram_lockstep_splitk(int32_t n, int cus);
 int gram_lockstep_workgroups(int32_t n, int splitk);
 hipError_t launch_gram_packed_lockstep(const int8_t* p, int fmt, int64_t nv, int32_t n, int32_t* s32, int num_cu,

@@ -1,0 +1,374 @@
+// exp_bits.hip -- correctness + A/B harness of the k-bits operand (spark-examples_amd/csrc/gram_kbits.inl).
+//
+// On one MI355X, with the library's own kernels (gram_packed.hip is included, so the anonymous-namespace kernels are visible):
+//   1. small ragged shapes: every k-bits pre-pass (fp32 / uint8 / carrier bitsets / CSR) against a host-built operand, and the
+//      k-bits contraction (split-K, lock-step, even-split launches) against a host popcount Gram;
+//   2. BASELINE configs[1] size (2,504 samples x 2^20 variants): S of the k-bits path == S of the shipped FP4 path, bit for bit;
+//   3. times per launch: pre-passes (FP4 vs k-bits, per input format), contractions (FP4 lock-step / split-K vs k-bits lock-step /
+//      even split / split-K, whole chip and half chip), and the pipelined step (pre-pass beside the contraction of the other buffer).
+// Not part of the product.  Build: make -C tools exp_bits.  Prints one line per measurement.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../spark-examples_amd/csrc/gram_packed.hip"
+
+namespace pcoa {
+const DebugKnobs& debug_knobs() {
+  static const DebugKnobs k;
+  return k;
+}
+}  // namespace pcoa
+
+using namespace pcoa;
+
+#define CK(expr)                                                                                  \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      std::fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+      std::exit(1);                                                                               \
+    }                                                                                             \
+  } while (0)
+
+__global__ void fill_kernel(float* x, int64_t rows, int64_t n, int64_t ld, uint32_t seed, uint32_t thr) {
+  const int64_t count = rows * ld;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t col = i % ld;
+    uint32_t h = (uint32_t)i * 2654435761u ^ (uint32_t)(i >> 32) * 40503u ^ seed;
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    x[i] = col < n ? ((h < thr) ? 1.0f : 0.0f) : 7.5f;  // padding columns hold garbage on purpose
+  }
+}
+__global__ void to_u8_kernel(const float* x, uint8_t* y, int64_t rows, int64_t n, int64_t ld, int64_t ld8) {
+  const int64_t count = rows * ld8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / ld8, c = i % ld8;
+    y[i] = c < n ? (uint8_t)x[r * ld + c] : (uint8_t)0xff;
+  }
+}
+// natural carrier bitsets: row v, bit (i & 31) of word i >> 5 = sample i; words beyond the row hold garbage
+__global__ void to_bits_kernel(const float* x, uint32_t* bits, int64_t rows, int64_t n, int64_t ld, int64_t ldw) {
+  const int64_t count = rows * ldw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / ldw, w = i % ldw;
+    uint32_t v = 0;
+    for (int b = 0; b < 32; ++b) {
+      const int64_t c = w * 32 + b;
+      if (c < n) v |= (x[r * ld + c] == 1.0f ? 1u : 0u) << b;
+      else v |= (uint32_t)((c * 7 + r) & 1) << b;  // garbage beyond N
+    }
+    bits[i] = v;
+  }
+}
+__global__ void diff_kernel(const uint32_t* a, const uint32_t* b, int64_t words, unsigned long long* out) {
+  unsigned long long d = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (int64_t)gridDim.x * blockDim.x)
+    d += (a[i] != b[i]);
+  if (d) atomicAdd(out, d);
+}
+__global__ void delay_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+static double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static unsigned long long count_diff(const void* a, const void* b, int64_t bytes, unsigned long long* cnt) {
+  CK(hipMemset(cnt, 0, 8));
+  hipLaunchKernelGGL(diff_kernel, dim3(2048), dim3(256), 0, 0, (const uint32_t*)a, (const uint32_t*)b, bytes / 4, cnt);
+  unsigned long long h = 0;
+  CK(hipMemcpy(&h, cnt, 8, hipMemcpyDeviceToHost));
+  return h;
+}
+
+static float time_ms(hipStream_t s, int reps, const std::function<void()>& body) {
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b));
+  body();  // warm-up
+  CK(hipStreamSynchronize(s));
+  CK(hipEventRecord(a, s));
+  for (int r = 0; r < reps; ++r) body();
+  CK(hipEventRecord(b, s));
+  CK(hipEventSynchronize(b));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, a, b));
+  CK(hipEventDestroy(a));
+  CK(hipEventDestroy(b));
+  return ms / reps;
+}
+
+// ---- part 1: small ragged shapes against the host ------------------------------------------------------------------------
+static int small_case(int n, int64_t v, int64_t ld, uint32_t thr, int num_cu, unsigned long long* cnt) {
+  const int npad = (int)gram_packed_npad(n);
+  const int64_t nblk = gram_kb_pad(v, 2) / 4;
+  const int64_t kbytes = nblk * npad * 16;
+  float* x;
+  CK(hipMalloc(&x, (size_t)(v * ld * 4 + 64)));
+  hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, x, v, (int64_t)n, ld, 12345u + (uint32_t)n, thr);
+  std::vector<float> hx((size_t)(v * ld));
+  CK(hipMemcpy(hx.data(), x, (size_t)(v * ld * 4), hipMemcpyDeviceToHost));
+  // host operand + host Gram (column bitsets, popcount)
+  std::vector<uint32_t> hk((size_t)(kbytes / 4), 0u);
+  const int64_t cw = (v + 63) / 64;
+  std::vector<uint64_t> colbits((size_t)(n * cw), 0ull);
+  for (int64_t r = 0; r < v; ++r)
+    for (int i = 0; i < n; ++i)
+      if (hx[(size_t)(r * ld + i)] == 1.0f) {
+        hk[(size_t)(((r >> 7) * npad + i) * 4 + ((r & 127) >> 5))] |= 1u << (r & 31);
+        colbits[(size_t)(i * cw + (r >> 6))] |= 1ull << (r & 63);
+      }
+  std::vector<int32_t> href((size_t)n * n, 0);
+  for (int i = 0; i < n; ++i)
+    for (int j = i; j < n; ++j) {
+      int32_t c = 0;
+      for (int64_t w = 0; w < cw; ++w) c += __builtin_popcountll(colbits[(size_t)(i * cw + w)] & colbits[(size_t)(j * cw + w)]);
+      href[(size_t)i * n + j] = c;
+    }
+  int8_t *k1, *k2, *kref;
+  int32_t *s32, *flag, *sref;
+  CK(hipMalloc(&k1, (size_t)kbytes));
+  CK(hipMalloc(&k2, (size_t)kbytes));
+  CK(hipMalloc(&kref, (size_t)kbytes));
+  CK(hipMalloc(&s32, (size_t)n * n * 4));
+  CK(hipMalloc(&sref, (size_t)n * n * 4));
+  CK(hipMalloc(&flag, 64));
+  CK(hipMemset(flag, 0, 64));
+  CK(hipMemcpy(kref, hk.data(), (size_t)kbytes, hipMemcpyHostToDevice));
+  CK(hipMemcpy(sref, href.data(), (size_t)n * n * 4, hipMemcpyHostToDevice));
+  int bad = 0;
+  auto check_k = [&](const char* what, int8_t* k) {
+    const unsigned long long d = count_diff(k, kref, kbytes, cnt);
+    std::printf("small n=%d v=%lld ld=%lld  operand %-28s %s (%llu words differ)\n", n, (long long)v, (long long)ld, what,
+                d ? "MISMATCH" : "ok", d);
+    bad += d != 0;
+  };
+  // fp32 pre-pass
+  CK(hipMemset(k1, 0xee, (size_t)kbytes));
+  CK(launch_pack_kbits(x, 0, ld, v, n, k1, flag, 0, nblk));
+  check_k("pack_kbits<float>", k1);
+  // uint8 pre-pass, two strides: ld (generic or 4-byte path) and a multiple of 8 (8-byte path)
+  for (int64_t ld8 : {ld, (ld + 7) / 8 * 8}) {
+    uint8_t* x8;
+    CK(hipMalloc(&x8, (size_t)(v * ld8 + 64)));
+    hipLaunchKernelGGL(to_u8_kernel, dim3(1024), dim3(256), 0, 0, x, x8, v, (int64_t)n, ld, ld8);
+    CK(hipMemset(k2, 0xee, (size_t)kbytes));
+    CK(launch_pack_kbits(x8, 1, ld8, v, n, k2, flag, 0, nblk));
+    check_k(ld8 % 8 ? "pack_kbits<uint8>" : "pack_u8x8_kbits", k2);
+    CK(hipFree(x8));
+  }
+  // carrier bitsets: padded stride (generic path) and a 4-word-aligned stride (vector path)
+  for (int64_t ldw : {(int64_t)(n + 31) / 32 + 1, ((int64_t)(n + 31) / 32 + 3) / 4 * 4}) {
+    uint32_t* bits;
+    CK(hipMalloc(&bits, (size_t)(v * ldw * 4 + 64)));
+    hipLaunchKernelGGL(to_bits_kernel, dim3(1024), dim3(256), 0, 0, x, bits, v, (int64_t)n, ld, ldw);
+    CK(hipMemset(k2, 0xee, (size_t)kbytes));
+    CK(launch_transpose_bits_kbits(bits, ldw, v, n, k2, 0, nblk));
+    check_k(ldw % 4 ? "transpose_bits_kbits<1>" : "transpose_bits_kbits<4>", k2);
+    CK(hipFree(bits));
+  }
+  {  // CSR carrier lists
+    std::vector<int32_t> idx;
+    std::vector<int64_t> offs((size_t)v + 1, 0);
+    for (int64_t r = 0; r < v; ++r) {
+      for (int i = 0; i < n; ++i)
+        if (hx[(size_t)(r * ld + i)] == 1.0f) idx.push_back(i);
+      offs[(size_t)r + 1] = (int64_t)idx.size();
+    }
+    if (idx.empty()) idx.push_back(0);
+    int32_t* didx;
+    int64_t* doffs;
+    CK(hipMalloc(&didx, idx.size() * 4));
+    CK(hipMalloc(&doffs, offs.size() * 8));
+    CK(hipMemcpy(didx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(doffs, offs.data(), offs.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMemset(k2, 0xee, (size_t)kbytes));
+    CK(launch_densify_csr_kbits(didx, doffs, v, 0, k2, n, flag, 0, nblk));
+    check_k("densify_csr_kbits", k2);
+    CK(hipFree(didx));
+    CK(hipFree(doffs));
+  }
+  int32_t hflag = 0;
+  CK(hipMemcpy(&hflag, flag, 4, hipMemcpyDeviceToHost));
+  if (hflag) { std::printf("small n=%d: flag word %d (expected 0)\n", n, hflag); ++bad; }
+  // contraction, three launch modes
+  for (int mode : {0, 2, 4}) {
+    CK(hipMemset(s32, 0, (size_t)n * n * 4));
+    hipError_t e = launch_gram_kbits(k1, v, n, s32, num_cu, 0, mode);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      std::printf("small n=%d v=%lld  contraction mode %d: does not fit (%s)\n", n, (long long)v, mode, hipGetErrorString(e));
+      continue;
+    }
+    CK(hipDeviceSynchronize());
+    const unsigned long long d = count_diff(s32, sref, (int64_t)n * n * 4, cnt);
+    std::printf("small n=%d v=%lld  contraction mode %d vs host popcount Gram: %s (%llu entries differ)\n", n, (long long)v, mode,
+                d ? "MISMATCH" : "ok", d);
+    bad += d != 0;
+  }
+  CK(hipFree(x)); CK(hipFree(k1)); CK(hipFree(k2)); CK(hipFree(kref)); CK(hipFree(s32)); CK(hipFree(sref)); CK(hipFree(flag));
+  return bad;
+}
+
+int main(int argc, char** argv) {
+  int n = 2504, reps = 5;
+  int64_t v = (int64_t)1 << 20;
+  for (int i = 1; i < argc; ++i) {
+    if (!std::strcmp(argv[i], "--n") && i + 1 < argc) n = std::atoi(argv[++i]);
+    if (!std::strcmp(argv[i], "--v") && i + 1 < argc) v = std::atoll(argv[++i]);
+    if (!std::strcmp(argv[i], "--reps") && i + 1 < argc) reps = std::atoi(argv[++i]);
+  }
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  const int num_cu = prop.multiProcessorCount;
+  std::printf("device %s, %d CUs\n", prop.name, num_cu);
+  unsigned long long* cnt;
+  CK(hipMalloc(&cnt, 8));
+
+  int bad = 0;
+  bad += small_case(1000, 777, 1003, 0x30000000u, num_cu, cnt);   // odd stride: generic paths
+  bad += small_case(1000, 4100, 1000, 0x08000000u, num_cu, cnt);  // vector paths, several blocks
+  bad += small_case(257, 129, 260, 0xc0000000u, num_cu, cnt);     // tile edge + dense
+  bad += small_case(2504, 3000, 2504, 0x20000000u, num_cu, cnt);  // BASELINE sample count, lock-step fits
+  std::printf("part 1: %s\n", bad ? "FAILED" : "all ok");
+
+  // ---- part 2 / 3: BASELINE configs[1] size ----------------------------------------------------------------------------
+  const int npad = (int)gram_packed_npad(n);
+  const int64_t ld = n;
+  const int64_t nkb = gram_kb_pad(v, 1);
+  const int64_t nblk = gram_kb_pad(v, 2) / 4;
+  float* x;
+  int8_t *p4[2], *k1[2];
+  int32_t *sa, *sb, *flag;
+  CK(hipMalloc(&x, (size_t)(v * ld * 4)));
+  for (int b = 0; b < 2; ++b) {
+    CK(hipMalloc(&p4[b], (size_t)(nkb * npad * 16)));
+    CK(hipMalloc(&k1[b], (size_t)(nblk * npad * 16)));
+  }
+  CK(hipMalloc(&sa, (size_t)n * n * 4));
+  CK(hipMalloc(&sb, (size_t)n * n * 4));
+  CK(hipMalloc(&flag, 64));
+  CK(hipMemset(flag, 0, 64));
+  hipLaunchKernelGGL(fill_kernel, dim3(8192), dim3(256), 0, 0, x, v, (int64_t)n, ld, 777u, 0x18000000u);
+  CK(hipDeviceSynchronize());
+
+  // S of the shipped path
+  CK(launch_pack_fp4(x, 0, ld, v, n, p4[0], flag, 0, nkb));
+  CK(hipMemset(sa, 0, (size_t)n * n * 4));
+  if (launch_gram_packed_lockstep(p4[0], 1, nkb * 32, n, sa, num_cu, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    CK(launch_gram_packed(p4[0], 1, nkb * 32, n, sa, num_cu, 0, nullptr));
+  }
+  CK(launch_pack_kbits(x, 0, ld, v, n, k1[0], flag, 0, nblk));
+  for (int mode : {0, 2, 4}) {
+    CK(hipMemset(sb, 0, (size_t)n * n * 4));
+    hipError_t e = launch_gram_kbits(k1[0], v, n, sb, num_cu, 0, mode);
+    if (e != hipSuccess) { (void)hipGetLastError(); std::printf("full size: k-bits mode %d does not fit\n", mode); continue; }
+    CK(hipDeviceSynchronize());
+    const unsigned long long d = count_diff(sa, sb, (int64_t)n * n * 4, cnt);
+    std::printf("full size n=%d v=%lld: S(k-bits, mode %d) vs S(FP4 path): %s (%llu entries differ)\n", n, (long long)v, mode,
+                d ? "MISMATCH" : "bit-identical", d);
+    bad += d != 0;
+  }
+  int32_t hflag = 0;
+  CK(hipMemcpy(&hflag, flag, 4, hipMemcpyDeviceToHost));
+  std::printf("flag word after the pre-passes: %d\n", hflag);
+
+  const double mv = (double)v / 1e6;
+  auto line = [&](const char* what, float ms) { std::printf("time  %-58s %8.3f ms  (%.3f ms per 10^6 variants)\n", what, ms, ms / mv); };
+  // pre-passes
+  line("pack_fp4<float> (shipped)", time_ms(0, reps, [&] { CK(launch_pack_fp4(x, 0, ld, v, n, p4[0], flag, 0, nkb)); }));
+  line("pack_kbits<float>", time_ms(0, reps, [&] { CK(launch_pack_kbits(x, 0, ld, v, n, k1[0], flag, 0, nblk)); }));
+  {
+    const int64_t ld8 = (n + 7) / 8 * 8;
+    uint8_t* x8;
+    CK(hipMalloc(&x8, (size_t)(v * ld8)));
+    hipLaunchKernelGGL(to_u8_kernel, dim3(8192), dim3(256), 0, 0, x, x8, v, (int64_t)n, ld, ld8);
+    line("pack_u8x8_fp4 (shipped)", time_ms(0, reps, [&] { CK(launch_pack_fp4(x8, 1, ld8, v, n, p4[1], flag, 0, nkb)); }));
+    line("pack_u8x8_kbits", time_ms(0, reps, [&] { CK(launch_pack_kbits(x8, 1, ld8, v, n, k1[1], flag, 0, nblk)); }));
+    std::printf("       u8 operand == fp32 operand: %s\n", count_diff(k1[0], k1[1], nblk * npad * 16, cnt) ? "MISMATCH" : "ok");
+    CK(hipFree(x8));
+    const int64_t ldw = ((n + 31) / 32 + 3) / 4 * 4;
+    uint32_t* bits;
+    CK(hipMalloc(&bits, (size_t)(v * ldw * 4)));
+    hipLaunchKernelGGL(to_bits_kernel, dim3(8192), dim3(256), 0, 0, x, bits, v, (int64_t)n, ld, ldw);
+    line("expand_bits_fp4 (shipped)", time_ms(0, reps, [&] { CK(launch_expand_bits_fp4(bits, ldw, v, n, p4[1], 0, nkb)); }));
+    line("transpose_bits_kbits", time_ms(0, reps, [&] { CK(launch_transpose_bits_kbits(bits, ldw, v, n, k1[1], 0, nblk)); }));
+    std::printf("       bitset operand == fp32 operand: %s\n", count_diff(k1[0], k1[1], nblk * npad * 16, cnt) ? "MISMATCH" : "ok");
+    CK(hipFree(bits));
+  }
+  // contractions, whole chip and half chip
+  CK(launch_pack_fp4(x, 0, ld, v, n, p4[1], flag, 0, nkb));
+  CK(launch_pack_kbits(x, 0, ld, v, n, k1[1], flag, 0, nblk));
+  for (int cus : {num_cu, num_cu / 2}) {
+    std::string tag = cus == num_cu ? " [whole chip]" : " [sized for half the chip]";
+    line(("FP4 lock-step" + tag).c_str(), time_ms(0, reps, [&] { CK(launch_gram_packed_lockstep(p4[0], 1, nkb * 32, n, sa, cus, 0)); }));
+    line(("k-bits lock-step (mode 2)" + tag).c_str(), time_ms(0, reps, [&] { CK(launch_gram_kbits(k1[0], v, n, sb, cus, 0, 2)); }));
+    line(("k-bits even split (mode 4)" + tag).c_str(), time_ms(0, reps, [&] { CK(launch_gram_kbits(k1[0], v, n, sb, cus, 0, 4)); }));
+  }
+  for (int cus : {192, 160, 144}) {
+    std::string tag = " [" + std::to_string(cus) + " workgroups]";
+    line(("k-bits even split (mode 4)" + tag).c_str(), time_ms(0, reps, [&] { CK(launch_gram_kbits(k1[0], v, n, sb, cus, 0, 4)); }));
+  }
+  line("FP4 split-K launch (legacy)", time_ms(0, reps, [&] { CK(launch_gram_packed(p4[0], 1, nkb * 32, n, sa, num_cu, 0, nullptr)); }));
+  line("k-bits split-K launch (mode 0)", time_ms(0, reps, [&] { CK(launch_gram_kbits(k1[0], v, n, sb, num_cu, 0, 0)); }));
+
+  // the pipelined step: pre-pass of buffer k+1 (pre-pass stream, behind a 10-us one-wave spin) beside the contraction of buffer k
+  hipStream_t ps, gs;
+  CK(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+  CK(hipStreamCreateWithFlags(&gs, hipStreamNonBlocking));
+  hipEvent_t packed[2], consumed[2];
+  for (int b = 0; b < 2; ++b) {
+    CK(hipEventCreateWithFlags(&packed[b], hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&consumed[b], hipEventDisableTiming));
+  }
+  auto pipeline = [&](const char* what, int fmt, int gram_mode, int gram_cus, int delay_us) {
+    const int K = 12;
+    double best = 1e30;
+    for (int round = 0; round < 3; ++round) {
+      CK(hipDeviceSynchronize());
+      const double t0 = now_ms();
+      for (int k = 0; k < K; ++k) {
+        const int b = k & 1;
+        if (k >= 2) CK(hipStreamWaitEvent(ps, consumed[b], 0));
+        if (k >= 1 && delay_us > 0) hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, ps, (long long)delay_us * 100);
+        if (fmt == 1) CK(launch_pack_fp4(x, 0, ld, v, n, p4[b], flag, ps, nkb));
+        else CK(launch_pack_kbits(x, 0, ld, v, n, k1[b], flag, ps, nblk));
+        CK(hipEventRecord(packed[b], ps));
+        CK(hipStreamWaitEvent(gs, packed[b], 0));
+        if (fmt == 1) CK(launch_gram_packed_lockstep(p4[b], 1, nkb * 32, n, sa, gram_cus, gs));
+        else CK(launch_gram_kbits(k1[b], v, n, sb, gram_cus, gs, gram_mode));
+        CK(hipEventRecord(consumed[b], gs));
+      }
+      CK(hipDeviceSynchronize());
+      best = std::min(best, (now_ms() - t0) / K);
+    }
+    std::printf("pipe  %-58s %8.3f ms per step (%.3f per 10^6 variants, %.0f M variants/s)\n", what, best, best / mv, v / best / 1e3);
+  };
+  pipeline("FP4: pack_fp4 || lock-step on half the chip (shipped)", 1, 2, num_cu / 2, 10);
+  pipeline("k-bits: pack_kbits || lock-step on half the chip", 2, 2, num_cu / 2, 10);
+  pipeline("k-bits: pack_kbits || even split, 128 workgroups", 2, 4, 128, 10);
+  pipeline("k-bits: pack_kbits || even split, 96 workgroups", 2, 4, 96, 10);
+  pipeline("k-bits: pack_kbits || even split, 160 workgroups", 2, 4, 160, 10);
+  pipeline("k-bits: pack_kbits || even split, 256 workgroups", 2, 4, num_cu, 10);
+  pipeline("k-bits: pack_kbits || lock-step whole chip", 2, 2, num_cu, 10);
+  pipeline("k-bits: no head start, lock-step on half the chip", 2, 2, num_cu / 2, 0);
+  // serial reference on one stream
+  line("serial step FP4 (pack + lock-step, one stream)", time_ms(0, reps, [&] {
+         CK(launch_pack_fp4(x, 0, ld, v, n, p4[0], flag, 0, nkb));
+         CK(launch_gram_packed_lockstep(p4[0], 1, nkb * 32, n, sa, num_cu, 0));
+       }));
+  line("serial step k-bits (pack + even split, one stream)", time_ms(0, reps, [&] {
+         CK(launch_pack_kbits(x, 0, ld, v, n, k1[0], flag, 0, nblk));
+         CK(launch_gram_kbits(k1[0], v, n, sb, num_cu, 0, 4));
+       }));
+  std::printf("%s\n", bad ? "RESULT: FAILED" : "RESULT: ok");
+  return bad ? 1 : 0;
+}
