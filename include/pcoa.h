@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define PCOA_VERSION_MAJOR 0
-#define PCOA_VERSION_MINOR 2
+#define PCOA_VERSION_MINOR 3
 
 typedef struct pcoa_ctx pcoa_ctx;
 
@@ -65,6 +65,9 @@ typedef enum pcoa_status {
 #define PCOA_FLAG_EIG_LANCZOS    0x40u /* Lanczos only: PCOA_ERR_NOT_CONVERGED instead of falling back      */
 #define PCOA_FLAG_NO_PIPELINE    0x80u /* fp32 tiles: pre-pass and contraction strictly one after the other on the ctx
                                            stream (the default overlaps them on two side streams where the shape fits) */
+#define PCOA_FLAG_OPERAND_FP4    0x100u /* binary tiles: keep the re-laid-out operand in HBM as MX-FP4 (4 bits per genotype,
+                                           the r01 / r02 form) instead of the default k-bits form (1 bit per genotype,
+                                           expanded to MX-FP4 in registers by the contraction).  Same MFMA, same S. */
 
 /* Per-stage timings, filled by pcoa_get_timings(); times in seconds, measured with HIP events on
  * the ctx stream.  Counters are cumulative since pcoa_create / pcoa_reset_timings. */
@@ -83,7 +86,8 @@ typedef struct pcoa_timings {
   double backtransform_seconds; /* reflector back-transform + normalisation                           */
   double compute_total_seconds; /* wall of the last pcoa_compute (centring..D2H)                      */
   int32_t gram_kernel_kind;     /* of the last launch: 1 = fp32 MFMA, 2 = int8 MFMA, 3 = MX-FP4 MFMA */
-  int32_t reserved;
+  int32_t operand_bits;         /* bits per genotype of that launch's operand in HBM: 32 (fp32 tile read in place), 8 (int8),
+                                   4 (MX-FP4 operand), 1 (k-bits operand: expanded to MX-FP4 inside the contraction) */
   double pack_seconds;          /* fp32 -> k-blocked int8 pre-pass of the i8 path (sum of launches)   */
   int64_t pack_launches;
   double pack_bytes;            /* algorithmic bytes of the pre-pass: 4*V*N read + V*Npad written     */
@@ -96,6 +100,8 @@ typedef struct pcoa_timings {
                                    (fp32 pipeline)                                                  */
   int32_t pipeline_pre_pass_cus;    /* CUs left to the pre-pass while such a contraction runs (0 = pipeline unavailable) */
   int32_t pipeline_contraction_cus; /* CUs that contraction occupies (one workgroup each)                        */
+  int64_t evensplit_launches;   /* contraction launches in the even-split form (k-bits operand: every workgroup an equal
+                                   run of (tile, stage) units, one workgroup per CU)                                */
 } pcoa_timings;
 
 /* Synthetic genotype model (bench / tests only; not part of the reference).  Sample i belongs to

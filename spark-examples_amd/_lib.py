@@ -27,6 +27,7 @@ PCOA_FLAG_NO_SIGN_NORM = 0x10
 PCOA_FLAG_EIG_HOUSEHOLDER = 0x20
 PCOA_FLAG_EIG_LANCZOS = 0x40
 PCOA_FLAG_NO_PIPELINE = 0x80
+PCOA_FLAG_OPERAND_FP4 = 0x100
 
 
 class PcoaTimings(ctypes.Structure):
@@ -45,7 +46,7 @@ class PcoaTimings(ctypes.Structure):
         ("backtransform_seconds", ctypes.c_double),
         ("compute_total_seconds", ctypes.c_double),
         ("gram_kernel_kind", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("operand_bits", ctypes.c_int32),
         ("pack_seconds", ctypes.c_double),
         ("pack_launches", ctypes.c_int64),
         ("pack_bytes", ctypes.c_double),
@@ -57,6 +58,7 @@ class PcoaTimings(ctypes.Structure):
         ("pipeline_launches", ctypes.c_int64),
         ("pipeline_pre_pass_cus", ctypes.c_int32),
         ("pipeline_contraction_cus", ctypes.c_int32),
+        ("evensplit_launches", ctypes.c_int64),
     ]
 
 

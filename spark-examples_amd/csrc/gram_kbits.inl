@@ -299,64 +299,141 @@ __device__ __forceinline__ void read_words(const StageBits* st, int wm, int wn, 
   }
 }
 
+// ENC 0: both operands as E2M1 1.0 (nibble 0x2): d_q = ((w << 1) >> q) & 0x22222222 -- 7 VALU operations per word.
+// ENC 1: conjugate weights.  E2M1 also has 0.5 (nibble 0x1) and 2.0 (nibble 0x4), and 0.5 x 2.0 = 1.0 x 1.0 = 1, both
+// exact; so bit class q = b % 4 may sit at different heights in the A and the B nibble as long as the heights add up:
+//   class   A (rows: 4 fragments per k-step)        B (columns: 2 fragments)
+//     0     w & 0x1111..        0.5                 (w << 2) & 0x4444..   2.0
+//     1     w & 0x2222..        1.0                 w & 0x2222..          1.0
+//     2     w & 0x4444..        2.0                 (w >> 2) & 0x1111..   0.5
+//     3     (w >> 1) & 0x4444.. 2.0                 (w >> 3) & 0x1111..   0.5
+// 5 operations for an A word, 7 for a B word: 34 instead of 42 per k-step.  (The sign bit of a nibble is the one height
+// that cannot be used, which is why class 3 always pays a shift.)
+template <int ENC, bool IS_B>
 __device__ __forceinline__ i32x4 expand_word_fp4(uint32_t w) {
-  constexpr uint32_t M = 0x22222222u;  // E2M1 1.0 in every nibble
   i32x4 r;
-  r[0] = (int)((w << 1) & M);
-  r[1] = (int)(w & M);
-  r[2] = (int)((w >> 1) & M);
-  r[3] = (int)((w >> 2) & M);
+  if constexpr (ENC == 0) {
+    constexpr uint32_t M = 0x22222222u;  // E2M1 1.0 in every nibble
+    r[0] = (int)((w << 1) & M);
+    r[1] = (int)(w & M);
+    r[2] = (int)((w >> 1) & M);
+    r[3] = (int)((w >> 2) & M);
+  } else if constexpr (!IS_B) {
+    r[0] = (int)(w & 0x11111111u);
+    r[1] = (int)(w & 0x22222222u);
+    r[2] = (int)(w & 0x44444444u);
+    r[3] = (int)((w >> 1) & 0x44444444u);
+  } else {
+    r[0] = (int)((w << 2) & 0x44444444u);
+    r[1] = (int)(w & 0x22222222u);
+    r[2] = (int)((w >> 2) & 0x11111111u);
+    r[3] = (int)((w >> 3) & 0x11111111u);
+  }
   return r;
 }
 
-__device__ __forceinline__ void expand_frags(const uint2 (&raw)[6], FragsI8<2> (&f)[2]) {
+// ENC 2 = ENC 1 with the expansion split over the two phases: the read phase only expands the fragments of k-step 0;
+// those of k-step 1 are expanded one per MFMA gap while the wave issues its first six MFMAs (which only need k-step 0).
+// The read phase (LDS latency + expansion) is then shorter than the partner's MFMA phase instead of longer.
+template <int ENC, int K2>
+__device__ __forceinline__ void expand_half(const uint2 (&raw)[6], FragsI8<2> (&f)[2]) {
+  constexpr int E = ENC == 0 ? 0 : 1;
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    f[0].a[mi] = expand_word_fp4(raw[mi].x);
-    f[1].a[mi] = expand_word_fp4(raw[mi].y);
-  }
+  for (int mi = 0; mi < 4; ++mi) f[K2].a[mi] = expand_word_fp4<E, false>(K2 == 0 ? raw[mi].x : raw[mi].y);
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    f[0].b[ni] = expand_word_fp4(raw[4 + ni].x);
-    f[1].b[ni] = expand_word_fp4(raw[4 + ni].y);
-  }
+  for (int ni = 0; ni < 2; ++ni) f[K2].b[ni] = expand_word_fp4<E, true>(K2 == 0 ? raw[4 + ni].x : raw[4 + ni].y);
   // The expansion is pure arithmetic: left alone, the optimiser sinks it below the phase barrier to just in front of the
   // MFMAs that consume it -- into the phase where the wave should do nothing but feed the matrix pipe.  An empty asm
   // that "modifies" every fragment pins the arithmetic here, in the wave's read phase.
 #pragma unroll
-  for (int k2 = 0; k2 < 2; ++k2) {
+  for (int mi = 0; mi < 4; ++mi) asm volatile("" : "+v"(f[K2].a[mi]));
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) asm volatile("" : "+v"(f[k2].a[mi]));
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) asm volatile("" : "+v"(f[k2].b[ni]));
+  for (int ni = 0; ni < 2; ++ni) asm volatile("" : "+v"(f[K2].b[ni]));
+}
+
+template <int ENC>
+__device__ __forceinline__ void expand_frags(uint2 (&raw)[6], FragsI8<2> (&f)[2]) {
+  expand_half<ENC, 0>(raw, f);
+  if constexpr (ENC != 2) expand_half<ENC, 1>(raw, f);
+}
+
+// fragment IDX (in the order the k-step-1 MFMAs need them: a0, b0, b1, a1, a2, a3) of k-step 1, pinned at this point of
+// the instruction stream from both sides (its input is "redefined" here, its output "used" here)
+template <int IDX>
+__device__ __forceinline__ void expand_late(uint2 (&raw)[6], FragsI8<2> (&f)[2]) {
+  constexpr int R = IDX == 0 ? 0 : IDX == 1 ? 4 : IDX == 2 ? 5 : IDX - 2;  // row of `raw`
+  asm volatile("" : "+v"(raw[R].y));
+  if constexpr (R < 4) {
+    f[1].a[R] = expand_word_fp4<1, false>(raw[R].y);
+    asm volatile("" : "+v"(f[1].a[R]));
+  } else {
+    f[1].b[R - 4] = expand_word_fp4<1, true>(raw[R].y);
+    asm volatile("" : "+v"(f[1].b[R - 4]));
+  }
+}
+
+// MFMA number T of a stage (order (k-step, mi, ni) as mfma_range), optionally with wait states in front of it INSIDE the
+// asm statement, where nothing can be scheduled between them and the instruction.
+template <int T, bool PAD>
+__device__ __forceinline__ void mfma_one(const FragsI8<2> (&f)[2], f32x16 (&acc)[4][2]) {
+  constexpr int k2 = T / 8, mi = (T % 8) / 2, ni = T % 2;
+  if constexpr (PAD)
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, %0 cbsz:4 blgp:4"
+                 : "+v"(acc[mi][ni])
+                 : "v"(f[k2].a[mi]), "v"(f[k2].b[ni]));
+  else
+    asm volatile("v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, %0 cbsz:4 blgp:4" : "+v"(acc[mi][ni]) : "v"(f[k2].a[mi]), "v"(f[k2].b[ni]));
+}
+
+// MFMAs LO .. HI-1 of a stage; ENC 2: with the six late expansions behind MFMAs 0 .. 5.
+// Two hazards of mixing VALU work into an asm MFMA run, both measured (profiles/r03g_kbits_hazards.txt), neither padded by
+// the compiler because it cannot see an MFMA inside an asm statement:
+//  * an MFMA that issues in the cycle after a VALU instruction comes back with the first two registers of its
+//    accumulator wrong (rows 0, 1, 4, 5 of its 32 x 32 tile): MFMA 6 directly behind the last late expansion (~7,000 of
+//    6.3 M entries of S at configs[1] size, group-1 waves only), and, once that one was padded, MFMA 0 / 8 behind
+//    compiler-placed moves at small shapes.  One wait state is enough (measured); every MFMA of this schedule carries two,
+//    inside its own asm statement where nothing can be scheduled between them and the instruction (free behind another
+//    MFMA: the pipe is busy for 32 cycles anyway);
+//  * an MFMA reads its A / B registers for several cycles after it has issued: a late expansion must never be allocated
+//    to the registers of a k-step-0 fragment that died an instruction ago, so all of k-step 0 is kept alive until its last
+//    MFMA has issued.
+template <int ENC, int LO, int HI, int T = LO>
+__device__ __forceinline__ void mfma_run(uint2 (&raw)[6], FragsI8<2> (&f)[2], f32x16 (&acc)[4][2]) {
+  if constexpr (ENC != 2) {
+    mfma_range<1, 2, 4, LO, HI>(f, acc);
+  } else if constexpr (T < HI) {
+    mfma_one<T, true>(f, acc);
+    if constexpr (T < 6) expand_late<T>(raw, f);
+    if constexpr (T == 7)
+      asm volatile("" ::"v"(f[0].a[0]), "v"(f[0].a[1]), "v"(f[0].a[2]), "v"(f[0].a[3]), "v"(f[0].b[0]), "v"(f[0].b[1]));
+    mfma_run<ENC, LO, HI, T + 1>(raw, f, acc);
   }
 }
 
 // One stage of the ping-pong schedule (pp_stage of gram_packed.hip with the operand expanded in registers).  The phases,
 // the barriers and the vmcnt book-keeping are the same; PER_WAVE = 1 DMA instruction per wave and stage.
-template <int NST, int BUF, int GRP, bool IDLE, int LEFT, bool DIAG>
+template <int NST, int BUF, int GRP, bool IDLE, int LEFT, bool DIAG, int ENC>
 __device__ __forceinline__ void ppb_stage(StageBits* lds, const int8_t* __restrict__ p, int npad, int64_t blk_begin, int s,
                                           int ns, int col_i, int col_j, int wave, int lane, int wm, int wn,
-                                          f32x16 (&acc)[4][2], FragsI8<2> (&f)[2]) {
+                                          f32x16 (&acc)[4][2], FragsI8<2> (&f)[2], uint2 (&raw)[6]) {
   constexpr int PER_WAVE = 1;
   constexpr int D = NST - 1;
   constexpr int TOT = 16;  // MFMAs per wave and stage
   const bool more = s + D < ns;
-  uint2 raw[6];
   if constexpr (GRP == 0) {
     // ---- phase 2s: read + expand stage s, issue the DMA of stage s+D
     if constexpr (!IDLE) read_words<DIAG>(&lds[BUF], wm, wn, lane, raw);
     __builtin_amdgcn_sched_barrier(0);
     if (more) issue_stage_bits<DIAG>(&lds[(BUF + D) % NST], p, npad, blk_begin + s + D, col_i, col_j, wave, lane);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!IDLE) expand_frags(raw, f);
+    if constexpr (!IDLE) expand_frags<ENC>(raw, f);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     raw_barrier();
     // ---- phase 2s+1: the MFMAs of stage s
     if constexpr (!IDLE) {
       asm volatile("s_nop 1");  // VALU-written operands -> MFMA (the barrier covers it; this makes it unconditional)
       __builtin_amdgcn_s_setprio(1);
-      mfma_range<1, 2, 4, 0, TOT - LEFT>(f, acc);
+      mfma_run<ENC, 0, TOT - LEFT>(raw, f, acc);
       __builtin_amdgcn_s_setprio(0);
     }
   } else {
@@ -367,7 +444,7 @@ __device__ __forceinline__ void ppb_stage(StageBits* lds, const int8_t* __restri
       if (s > 0) {
         asm volatile("s_nop 1");
         __builtin_amdgcn_s_setprio(1);
-        mfma_range<1, 2, 4, 0, TOT - LEFT>(f, acc);
+        mfma_run<ENC, 0, TOT - LEFT>(raw, f, acc);
         __builtin_amdgcn_s_setprio(0);
       }
     }
@@ -377,13 +454,13 @@ __device__ __forceinline__ void ppb_stage(StageBits* lds, const int8_t* __restri
       if constexpr (LEFT > 0) {
         if (s > 0) {
           __builtin_amdgcn_s_setprio(2);
-          mfma_range<1, 2, 4, TOT - LEFT, TOT>(f, acc);
+          mfma_run<ENC, TOT - LEFT, TOT>(raw, f, acc);
           __builtin_amdgcn_s_setprio(0);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
       read_words<DIAG>(&lds[BUF], wm, wn, lane, raw);
-      expand_frags(raw, f);
+      expand_frags<ENC>(raw, f);
     }
   }
   // end of phase 2s+1: stage s+1 must have landed (own share), only the DMA of stage s+2.. may stay in flight
@@ -398,27 +475,29 @@ __device__ __forceinline__ void ppb_stage(StageBits* lds, const int8_t* __restri
   raw_barrier();
   if constexpr (GRP == 0 && !IDLE && LEFT > 0) {  // group 0's leftover MFMAs of stage s, into phase 2(s+1)
     __builtin_amdgcn_s_setprio(2);
-    mfma_range<1, 2, 4, TOT - LEFT, TOT>(f, acc);
+    mfma_run<ENC, TOT - LEFT, TOT>(raw, f, acc);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-template <int NST, int GRP, bool IDLE, int LEFT, bool DIAG, int... Is>
+template <int NST, int GRP, bool IDLE, int LEFT, bool DIAG, int ENC, int... Is>
 __device__ __forceinline__ void ppb_round(StageBits* lds, const int8_t* __restrict__ p, int npad, int64_t blk_begin, int s,
                                           int ns, int count, int col_i, int col_j, int wave, int lane, int wm, int wn,
-                                          f32x16 (&acc)[4][2], FragsI8<2> (&f)[2], std::integer_sequence<int, Is...>) {
-  ((Is < count ? ppb_stage<NST, Is, GRP, IDLE, LEFT, DIAG>(lds, p, npad, blk_begin, s + Is, ns, col_i, col_j, wave, lane, wm,
-                                                           wn, acc, f)
+                                          f32x16 (&acc)[4][2], FragsI8<2> (&f)[2], uint2 (&raw)[6],
+                                          std::integer_sequence<int, Is...>) {
+  ((Is < count ? ppb_stage<NST, Is, GRP, IDLE, LEFT, DIAG, ENC>(lds, p, npad, blk_begin, s + Is, ns, col_i, col_j, wave, lane, wm,
+                                                           wn, acc, f, raw)
                : (void)0),
    ...);
 }
 
-template <int NST, int GRP, bool IDLE, int LEFT, bool DIAG>
+template <int NST, int GRP, bool IDLE, int LEFT, bool DIAG, int ENC>
 __device__ __forceinline__ void ppb_loop(StageBits* lds, const int8_t* __restrict__ p, int npad, int64_t blk_begin, int ns,
                                          int col_i, int col_j, int wave, int lane, int wm, int wn,
                                          f32x16 (&acc)[4][2]) {
   FragsI8<2> f[2];
+  uint2 raw[6];
   // prologue: stages 0 .. NST-2 go in flight; stage 0 must have landed before group 0 reads it in phase 0
 #pragma unroll
   for (int i = 0; i < NST - 1; ++i)
@@ -428,15 +507,14 @@ __device__ __forceinline__ void ppb_loop(StageBits* lds, const int8_t* __restric
   raw_barrier();
   int s = 0;
   for (; s + NST - 1 < ns; s += NST)
-    ppb_round<NST, GRP, IDLE, LEFT, DIAG>(lds, p, npad, blk_begin, s, ns, NST, col_i, col_j, wave, lane, wm, wn, acc, f,
-                                          std::make_integer_sequence<int, NST>{});
+    ppb_round<NST, GRP, IDLE, LEFT, DIAG, ENC>(lds, p, npad, blk_begin, s, ns, NST, col_i, col_j, wave, lane, wm, wn, acc, f,
+                                          raw, std::make_integer_sequence<int, NST>{});
   if (s < ns)
-    ppb_round<NST, GRP, IDLE, LEFT, DIAG>(lds, p, npad, blk_begin, s, ns, ns - s, col_i, col_j, wave, lane, wm, wn, acc, f,
-                                          std::make_integer_sequence<int, NST - 1>{});
+    ppb_round<NST, GRP, IDLE, LEFT, DIAG, ENC>(lds, p, npad, blk_begin, s, ns, ns - s, col_i, col_j, wave, lane, wm, wn, acc, f,
+                                          raw, std::make_integer_sequence<int, NST - 1>{});
   if constexpr (GRP == 1 && !IDLE) {  // phase 2*ns: group 1's MFMAs of the last stage, nobody to wait for
     asm volatile("s_nop 1");
-#pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2) mfma_step_i8<1, 2>(f[k2], acc);
+    mfma_run<ENC, 0, 16>(raw, f, acc);
   }
 }
 
@@ -445,7 +523,7 @@ __device__ __forceinline__ void ppb_loop(StageBits* lds, const int8_t* __restric
 // gridDim.x equal runs, a workgroup walks its run and pays one epilogue per tile it touches (at most
 // ceil(run / nstages) + 1).  Every CU gets the same number of MFMAs whatever ntri is (55 tiles x split-K 4 leaves 36 of
 // 256 CUs idle in the lock-step launch).
-template <int NST, int LEFT>
+template <int NST, int LEFT, int ENC>
 __global__ __launch_bounds__(512, 2) void gram_kbits_kernel(const int8_t* __restrict__ p, int npad, int64_t nstages, int n,
                                                             int ntile, int ntri, int splitk, int64_t stages_per,
                                                             int32_t* __restrict__ s32, int xcd_map,
@@ -523,13 +601,13 @@ __global__ __launch_bounds__(512, 2) void gram_kbits_kernel(const int8_t* __rest
         for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0;
 
     if (row_blk == col_blk && strip.cols == 0) {  // diagonal tile: one panel (workgroup-uniform branch)
-      if (wm == 0) ppb_loop<NST, 0, false, LEFT, true>(lds, p, npad, st_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
-      else if (idle) ppb_loop<NST, 1, true, LEFT, true>(lds, p, npad, st_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
-      else ppb_loop<NST, 1, false, LEFT, true>(lds, p, npad, st_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
+      if (wm == 0) ppb_loop<NST, 0, false, LEFT, true, ENC>(lds, p, npad, st_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
+      else if (idle) ppb_loop<NST, 1, true, LEFT, true, ENC>(lds, p, npad, st_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
+      else ppb_loop<NST, 1, false, LEFT, true, ENC>(lds, p, npad, st_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
     } else if (wm == 0) {
-      ppb_loop<NST, 0, false, LEFT, false>(lds, p, npad, st_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
+      ppb_loop<NST, 0, false, LEFT, false, ENC>(lds, p, npad, st_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
     } else {
-      ppb_loop<NST, 1, false, LEFT, false>(lds, p, npad, st_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
+      ppb_loop<NST, 1, false, LEFT, false, ENC>(lds, p, npad, st_begin, ns, col_i, col_j, wave, lane, wm, wn, acc);
     }
 
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last asm MFMA -> VALU read of D
@@ -562,6 +640,10 @@ __global__ __launch_bounds__(512, 2) void gram_kbits_kernel(const int8_t* __rest
 #endif  // PCOA_KBITS_KERNELS
 
 #ifdef PCOA_KBITS_LAUNCHERS
+
+#ifdef PCOA_EXPERIMENTS
+int g_kbits_variant = 0;  // harness knob: which instantiation launch_gram_kbits uses
+#endif
 
 // k-bits pre-passes.  nblk_out: blocks of 128 variants to write (the tail beyond nv is zero-filled); p = first block.
 hipError_t launch_pack_kbits(const void* x, int is_u8, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
@@ -673,8 +755,22 @@ hipError_t launch_gram_kbits(const int8_t* p, int64_t nv, int32_t n, int32_t* s3
     nblocks = (int64_t)ntri * splitk;
   }
   if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL((gram_kbits_kernel<4, 2>), dim3((unsigned)nblocks), dim3(512), 0, stream, p, npad, nstages, n, ntile,
-                     ntri, (int)splitk, stages_per, s32, xcd_map, skip, strip);
+  const dim3 grid((unsigned)nblocks), block(512);
+#define PCOA_LAUNCH_KBITS(NST_, LEFT_, ENC_)                                                                              \
+  hipLaunchKernelGGL((gram_kbits_kernel<NST_, LEFT_, ENC_>), grid, block, 0, stream, p, npad, nstages, n, ntile, ntri,      \
+                     (int)splitk, stages_per, s32, xcd_map, skip, strip)
+#ifdef PCOA_EXPERIMENTS
+  switch (g_kbits_variant) {  // harness knob (tools/exp_bits.hip)
+    case 1: PCOA_LAUNCH_KBITS(4, 2, 0); break;   // plain encoding (7 + 7 operations per word pair), whole expansion in the read phase
+    case 2: PCOA_LAUNCH_KBITS(3, 2, 1); break;   // conjugate weights, whole expansion in the read phase
+    case 3: PCOA_LAUNCH_KBITS(4, 2, 2); break;   // shipped schedule on a 4-stage ring
+    case 4: PCOA_LAUNCH_KBITS(3, 0, 2); break;   // no MFMAs behind the phase barrier
+    default: PCOA_LAUNCH_KBITS(3, 2, 2); break;
+  }
+#else
+  PCOA_LAUNCH_KBITS(3, 2, 2);  // conjugate weights, expansion split over the phases, 3-stage ring, two MFMAs behind the barrier
+#endif
+#undef PCOA_LAUNCH_KBITS
   return hipGetLastError();
 }
 

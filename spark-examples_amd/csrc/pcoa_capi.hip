@@ -238,6 +238,10 @@ struct pcoa_ctx {
   int64_t pack_cap = 0;            // bytes
   bool use_i8 = true;              // packed-operand Gram (FP4 / int8) or fp32-MFMA Gram
   int packed_mode = 0;             // 0 auto (FP4 for binary tiles, int8 otherwise), 2 int8 only, 3 FP4 only
+  // Form of the binary-tile operand in HBM: 2 = k-bits (1 bit per genotype, expanded to MX-FP4 in registers by the
+  // contraction: gram_kbits.inl; default), 1 = MX-FP4 (4 bits per genotype, PCOA_FLAG_OPERAND_FP4).  The buffer logic
+  // below counts in k-blocks of 32 variants either way; a k-bits chunk is padded to whole blocks of 128 variants.
+  int op_fmt = 2;
   int64_t fp4_fallbacks = 0;
   int i8_streak = 0;               // auto mode: chunks still to be sent straight to the int8 kernel after a fallback
   // FP4 operand buffers.  Binary chunks are only PACKED when they arrive (behind what the active buffer already
@@ -270,7 +274,8 @@ struct pcoa_ctx {
   hipStream_t pack_stream = nullptr, gram_stream = nullptr;
   hipEvent_t ev_fork = nullptr;
   bool lockstep_ok = false;          // the lock-step contraction launch fits this N on the whole chip
-  int64_t lockstep_launches = 0, pipeline_launches = 0;
+  int kbits_mode = 4;                // whole-chip launch form of the k-bits contraction: 4 even split, 2 lock-step, 0 split-K
+  int64_t lockstep_launches = 0, pipeline_launches = 0, evensplit_launches = 0;
   int64_t pack_chunk = (int64_t)1 << 20;  // variants packed + contracted per launch pair
   int64_t pack_launches = 0;
   double pack_bytes = 0;
@@ -470,7 +475,28 @@ constexpr int64_t kBatchVariants = (int64_t)1 << 22;   // variants per FP4 contr
 constexpr int64_t kBatchBytes = (int64_t)6 << 30;      // cap of an FP4 operand buffer
 constexpr int64_t kPipeVariants = (int64_t)1 << 20;    // buffer size where two buffers alternate (pipeline / lock-step)
 
-int64_t fp4_kb_bytes(const pcoa_ctx* c) { return gram_packed_npad(c->n) * 16; }
+int64_t fp4_kb_bytes(const pcoa_ctx* c) { return gram_packed_npad(c->n) * (c->op_fmt == 2 ? 4 : 16); }
+// k-blocks (of 32 variants) a chunk of nv variants takes in the operand buffer
+int64_t kb_of(const pcoa_ctx* c, int64_t nv) {
+  const int64_t kb = (nv + 31) / 32;
+  return c->op_fmt == 2 ? round_up(kb, 4) : kb;
+}
+// the three pre-passes onto the binary-tile operand, in the ctx's operand format
+hipError_t launch_pack_operand(const pcoa_ctx* c, const void* x, int is_u8, int64_t ld, int64_t nv, int8_t* dst, int32_t* flag,
+                               hipStream_t s, int64_t kb) {
+  return c->op_fmt == 2 ? launch_pack_kbits(x, is_u8, ld, nv, c->n, dst, flag, s, kb / 4)
+                        : launch_pack_fp4(x, is_u8, ld, nv, c->n, dst, flag, s, kb);
+}
+hipError_t launch_bits_operand(const pcoa_ctx* c, const uint32_t* bits, int64_t ld_words, int64_t nv, int8_t* dst, hipStream_t s,
+                               int64_t kb) {
+  return c->op_fmt == 2 ? launch_transpose_bits_kbits(bits, ld_words, nv, c->n, dst, s, kb / 4)
+                        : launch_expand_bits_fp4(bits, ld_words, nv, c->n, dst, s, kb);
+}
+hipError_t launch_csr_operand(const pcoa_ctx* c, const int32_t* idx, const int64_t* offs, int64_t nv, int64_t offs_base,
+                              int8_t* dst, hipStream_t s, int64_t kb) {
+  return c->op_fmt == 2 ? launch_densify_csr_kbits(idx, offs, nv, offs_base, dst, c->n, c->err_flag, s, kb / 4)
+                        : launch_densify_csr_fp4(idx, offs, nv, offs_base, dst, c->n, c->err_flag, s, kb);
+}
 int32_t* fb_flag(pcoa_ctx* c, int b) { return c->fb_flags + 16 * b; }
 
 // k-blocks a buffer is meant to hold
@@ -509,13 +535,26 @@ int fp4_setup(pcoa_ctx* c) {
   c->lockstep_ok = !c->is_strip && ls > 0 && gram_lockstep_workgroups(c->n, ls) * 5 >= c->num_cu * 4;
   if (k.lockstep == 0) c->lockstep_ok = false;
   if (k.lockstep == 1) c->lockstep_ok = !c->is_strip && ls > 0;
-  // fp32 pipeline: a lock-step contraction sized for HALF the chip (split-K 2 at N = 2504: 110 workgroups, one per CU)
-  // that fills >= 80 % of that half, beside the pre-pass on every CU it leaves.  No CU masks: a contraction workgroup
-  // takes 2 x 224 of a SIMD's 512 VGPRs, a pre-pass wave needs 96, so the two never share a CU (sharing one is
-  // negative-sum: the CU's vector-memory path returns in order) -- provided the contraction's workgroups are placed
-  // FIRST, which a 10-us one-wave spin in front of a generation's first pre-pass ensures (fp4_reserve).  Against
-  // static 16 + 16 CU masks (hipExtStreamCreateWithCUMask) this is 5 % faster: the pre-pass gets the 18 CUs the
-  // contraction does not use, and the whole chip once the contraction is done (profiles/r02n_overlap_harness.txt).
+  // k-bits operand: the EVEN-SPLIT launch (one workgroup per CU, each an equal run of (tile, 128-variant stage) units)
+  // wherever the output has few tiles -- it fills all CUs whatever the tile count is (the lock-step launch leaves 36 of
+  // 256 idle at N = 2504), and the 4x smaller operand stream affords the loss of operand sharing.  Large N (many more
+  // tiles than CUs) keeps the banded split-K order that shares panels between concurrent workgroups.
+  {
+    const int64_t ntile = gram_packed_npad(c->n) / 256;
+    const int64_t ntri = c->is_strip ? ntile * ((c->s_cols + 255) / 256 + 1) : ntile * (ntile + 1) / 2;
+    c->kbits_mode = (ntri <= 4 * (int64_t)c->num_cu) ? 4 : 0;
+    if (k.kbits_mode == 0 || k.kbits_mode == 4) c->kbits_mode = k.kbits_mode;
+    if (k.kbits_mode == 2 && !c->is_strip && ls > 0) c->kbits_mode = 2;
+  }
+  // fp32 pipeline: the contraction of one operand buffer beside the pre-pass of the next, on two side streams.
+  //  FP4 operand: a lock-step contraction sized for HALF the chip (split-K 2 at N = 2504: 110 workgroups, one per CU)
+  //  that fills >= 80 % of that half; k-bits operand: an even-split contraction of `pipe_gram_cus` workgroups.
+  // No CU masks: a contraction workgroup takes 2 x 224..256 of a SIMD's 512 VGPRs, a pre-pass wave needs 96..136, so the
+  // two never share a CU (sharing one is negative-sum: the CU's vector-memory path returns in order) -- provided the
+  // contraction's workgroups are placed FIRST, which a 10-us one-wave spin in front of a generation's first pre-pass
+  // ensures (fp4_reserve).  Against static 16 + 16 CU masks (hipExtStreamCreateWithCUMask) this is 5 % faster: the
+  // pre-pass gets the CUs the contraction does not use, and the whole chip once the contraction is done
+  // (profiles/r02n_overlap_harness.txt; k-bits: profiles/r03*_kbits_harness.txt).
   const int half = c->num_cu / 2;
   const int lsh = gram_lockstep_splitk(c->n, half);
   // (worth it whenever the contraction is a real share of the step: from ~5 tile columns, N > 1024)
@@ -529,6 +568,7 @@ int fp4_setup(pcoa_ctx* c) {
     if (e1 == hipSuccess && e2 == hipSuccess) {
       c->pipe_ok = true;
       c->pipe_gram_cus = half;
+      if (c->op_fmt == 2 && k.kbits_pipe_wgs >= 8 && k.kbits_pipe_wgs <= c->num_cu) c->pipe_gram_cus = k.kbits_pipe_wgs / 8 * 8;
       c->fb_count = 2;
     } else {
       (void)hipGetLastError();
@@ -536,6 +576,7 @@ int fp4_setup(pcoa_ctx* c) {
       c->pack_stream = c->gram_stream = nullptr;
     }
   }
+  if (c->op_fmt == 2 && c->kbits_mode != 0) c->fb_count = 2;  // cheap epilogue (<= 2 tiles per workgroup)
   if (!c->pipe_ok && c->lockstep_ok) c->fb_count = 2;  // cheap epilogue: 2^20-variant launches from alternating buffers
   return PCOA_OK;
 }
@@ -563,14 +604,28 @@ int fp4_launch(pcoa_ctx* c, int bi, bool overlapped) {
   {
     ScopedTimer t(c, T_GRAM, gs);
     hipError_t e = hipErrorInvalidValue;
-    if (side || c->lockstep_ok) e = launch_gram_packed_lockstep(b.p, 1, b.kb * 32, c->n, c->s32, cus, gs, skip);
-    if (e == hipSuccess) {
-      c->lockstep_launches += 1;
-      if (side) c->pipeline_launches += 1;
-    }
-    if (e != hipSuccess) {
-      (void)hipGetLastError();
-      e = launch_gram_packed(b.p, 1, b.kb * 32, c->n, c->s32, cus, gs, nullptr, skip, strip_of(c));
+    if (c->op_fmt == 2) {
+      // k-bits: beside the pre-pass an even split over `pipe_gram_cus` workgroups, else the whole-chip form chosen in fp4_setup
+      const int mode = side ? 4 : c->kbits_mode;
+      e = launch_gram_kbits(b.p, b.kb * 32, c->n, c->s32, cus, gs, mode, skip, strip_of(c));
+      if (e != hipSuccess && mode != 0) {
+        (void)hipGetLastError();
+        e = launch_gram_kbits(b.p, b.kb * 32, c->n, c->s32, cus, gs, 0, skip, strip_of(c));
+      } else if (e == hipSuccess) {
+        if (mode == 2) c->lockstep_launches += 1;
+        if (mode == 4) c->evensplit_launches += 1;
+        if (side) c->pipeline_launches += 1;
+      }
+    } else {
+      if (side || c->lockstep_ok) e = launch_gram_packed_lockstep(b.p, 1, b.kb * 32, c->n, c->s32, cus, gs, skip);
+      if (e == hipSuccess) {
+        c->lockstep_launches += 1;
+        if (side) c->pipeline_launches += 1;
+      }
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        e = launch_gram_packed(b.p, 1, b.kb * 32, c->n, c->s32, cus, gs, nullptr, skip, strip_of(c));
+      }
     }
     if (e != hipSuccess) return hip_fail(c, e, "packed gram kernel launch");
   }
@@ -799,7 +854,7 @@ int packed_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64
   }
   if (fp4) {
     const bool autom = c->packed_mode == 0;
-    const int64_t kb = (cur + 31) / 32;
+    const int64_t kb = kb_of(c, cur);
     int8_t* dst = nullptr;
     hipStream_t ps = nullptr;
     int32_t* bflag = nullptr;
@@ -812,8 +867,8 @@ int packed_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64
     if (autom && !can_defer) HIP_TRY(c, hipMemsetAsync(flag, 0, sizeof(int32_t), ps));
     {
       ScopedTimer t(c, T_PACK, ps);
-      hipError_t e = launch_pack_fp4(x_chunk, is_u8, ld, cur, c->n, dst, flag, ps, kb);
-      if (e != hipSuccess) return hip_fail(c, e, "pack(fp4) kernel launch");
+      hipError_t e = launch_pack_operand(c, x_chunk, is_u8, ld, cur, dst, flag, ps, kb);
+      if (e != hipSuccess) return hip_fail(c, e, "operand pre-pass launch");
     }
     c->pack_launches += 1;
     c->pack_bytes += in_bytes + (double)(kb * fp4_kb_bytes(c));
@@ -1035,7 +1090,7 @@ const DebugKnobs& debug_knobs() {
 // ================================================================================================
 extern "C" {
 
-const char* pcoa_version(void) { return "pcoa_hip 0.2 (gfx950)"; }
+const char* pcoa_version(void) { return "pcoa_hip 0.3 (gfx950)"; }
 
 static int create_impl(pcoa_ctx** out, int32_t n_samples, int32_t device_ordinal, uint32_t flags, int32_t col0, int32_t cols) {
   if (!out) return fail(nullptr, PCOA_ERR_INVALID_ARG, "out is NULL");
@@ -1065,7 +1120,9 @@ static int create_impl(pcoa_ctx** out, int32_t n_samples, int32_t device_ordinal
   c->flags = flags;
   c->use_i8 = !(flags & PCOA_FLAG_GRAM_F32_MFMA);
   c->packed_mode = (flags & PCOA_FLAG_GRAM_I8_MFMA) ? 2 : (flags & PCOA_FLAG_GRAM_FP4_MFMA) ? 3 : 0;
+  c->op_fmt = (flags & PCOA_FLAG_OPERAND_FP4) ? 1 : 2;
   const DebugKnobs& knobs = debug_knobs();
+  if (knobs.operand == 1 || knobs.operand == 2) c->op_fmt = knobs.operand;
   if (knobs.gram_kernel == 1) c->use_i8 = false;
   if (knobs.gram_kernel == 2) { c->use_i8 = true; c->packed_mode = 2; }
   if (knobs.gram_kernel == 3) { c->use_i8 = true; c->packed_mode = 3; }
@@ -1241,15 +1298,15 @@ int gram_device_bits(pcoa_ctx* c, const uint32_t* bits_dev, int64_t nv, int64_t 
   const int64_t max_cur = std::min(c->max_launch, c->pack_chunk);
   while (done < nv) {
     const int64_t cur = std::min(nv - done, max_cur);
-    const int64_t kb = (cur + 31) / 32;
+    const int64_t kb = kb_of(c, cur);
     int8_t* dst = nullptr;
     hipStream_t ps = nullptr;
     int rc = fp4_reserve(c, kb, cur, false, false, &dst, &ps, nullptr);  // bitsets are binary by construction
     if (rc != PCOA_OK) return rc;
     {
       ScopedTimer t(c, T_PACK, ps);
-      hipError_t e = launch_expand_bits_fp4(bits_dev + done * ld_words, ld_words, cur, c->n, dst, ps, kb);
-      if (e != hipSuccess) return hip_fail(c, e, "expand(bits) kernel launch");
+      hipError_t e = launch_bits_operand(c, bits_dev + done * ld_words, ld_words, cur, dst, ps, kb);
+      if (e != hipSuccess) return hip_fail(c, e, "bitset pre-pass launch");
     }
     c->pack_launches += 1;
     c->pack_bytes += 4.0 * (double)((c->n + 31) / 32) * (double)cur + (double)(kb * fp4_kb_bytes(c));
@@ -1355,13 +1412,13 @@ int pcoa_accumulate_calls(pcoa_ctx* c, const int32_t* sample_idx, const int64_t*
                               hipMemcpyHostToDevice, c->stream));
     if (csr_fp4) {
       // carrier SETS -> FP4 operand, appended to the operand buffer; the contraction is deferred (fp4_flush)
-      const int64_t kb = (rows + 31) / 32;
+      const int64_t kb = kb_of(c, rows);
       int8_t* dst = nullptr;
       hipStream_t ps = nullptr;
       if ((rc = fp4_reserve(c, kb, rows, false, false, &dst, &ps, nullptr)) != PCOA_OK) return rc;
       {
         ScopedTimer t(c, T_DENSIFY, ps);
-        HIP_TRY(c, launch_densify_csr_fp4(c->csr_idx, c->csr_offs, rows, b, dst, c->n, c->err_flag, ps, kb));
+        HIP_TRY(c, launch_csr_operand(c, c->csr_idx, c->csr_offs, rows, b, dst, ps, kb));
       }
       fp4_commit(c, kb, rows);
       continue;
@@ -1857,9 +1914,12 @@ int pcoa_get_timings(pcoa_ctx* c, pcoa_timings* out) {
   out->fp4_fallbacks = c->fp4_fallbacks;
   out->lockstep_launches = c->lockstep_launches;
   out->pipeline_launches = c->pipeline_launches;
+  out->evensplit_launches = c->evensplit_launches;
+  out->operand_bits = !c->use_i8 ? 32 : c->gram_kind == 2 ? 8 : c->op_fmt == 2 ? 1 : 4;
   {
     const int ls = c->pipe_ok ? gram_lockstep_splitk(c->n, c->pipe_gram_cus) : 0;
-    const int wgs = ls > 0 ? gram_lockstep_workgroups(c->n, ls) : 0;   // one workgroup per CU
+    int wgs = ls > 0 ? gram_lockstep_workgroups(c->n, ls) : 0;   // one workgroup per CU
+    if (c->pipe_ok && c->op_fmt == 2) wgs = c->pipe_gram_cus;         // even split: exactly that many workgroups
     out->pipeline_pre_pass_cus = c->pipe_ok ? c->num_cu - wgs : 0;
     out->pipeline_contraction_cus = wgs;
   }
@@ -1883,6 +1943,7 @@ int pcoa_reset_timings(pcoa_ctx* c) {
   c->pack_bytes = 0;
   c->lockstep_launches = 0;
   c->pipeline_launches = 0;
+  c->evensplit_launches = 0;
   return PCOA_OK;
 }
 

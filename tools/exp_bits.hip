@@ -212,6 +212,30 @@ static int small_case(int n, int64_t v, int64_t ld, uint32_t thr, int num_cu, un
     std::printf("small n=%d v=%lld  contraction mode %d vs host popcount Gram: %s (%llu entries differ)\n", n, (long long)v, mode,
                 d ? "MISMATCH" : "ok", d);
     bad += d != 0;
+    if (d) {
+      std::vector<int32_t> hb((size_t)n * n);
+      CK(hipMemcpy(hb.data(), s32, (size_t)n * n * 4, hipMemcpyDeviceToHost));
+      int by_wave[2][4] = {}, by_mi[4] = {}, by_ni[2] = {}, by_r[8] = {}, by_hi[2] = {}, shown = 0, diag = 0, offd = 0;
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+          const int32_t a = href[(size_t)i * n + j], b = hb[(size_t)i * n + j];
+          if (a == b) continue;
+          (i / 256 == j / 256 ? diag : offd)++;
+          by_wave[(i % 256) / 128][(j % 256) / 64]++;
+          by_mi[(i % 128) / 32]++;
+          by_ni[(j % 64) / 32]++;
+          const int ri = i % 32;
+          by_hi[(ri >> 2) & 1]++;
+          by_r[(ri & 3) + 4 * ((ri >> 3) & 1)]++;
+          if (shown++ < 6) std::printf("   S[%d][%d]: host %d, device %d\n", i, j, a, b);
+        }
+      std::printf("   diag tiles %d, off-diag %d; by wave (wm, wn):", diag, offd);
+      for (int a = 0; a < 2; ++a) for (int b = 0; b < 4; ++b) std::printf(" %d", by_wave[a][b]);
+      std::printf("; by mi: %d %d %d %d; by ni: %d %d; by hi: %d %d; by r&3 (+4 for odd 8-row groups):", by_mi[0], by_mi[1], by_mi[2], by_mi[3],
+                  by_ni[0], by_ni[1], by_hi[0], by_hi[1]);
+      for (int a = 0; a < 8; ++a) std::printf(" %d", by_r[a]);
+      std::printf("\n");
+    }
   }
   CK(hipFree(x)); CK(hipFree(k1)); CK(hipFree(k2)); CK(hipFree(kref)); CK(hipFree(s32)); CK(hipFree(sref)); CK(hipFree(flag));
   return bad;
@@ -267,16 +291,52 @@ int main(int argc, char** argv) {
     CK(launch_gram_packed(p4[0], 1, nkb * 32, n, sa, num_cu, 0, nullptr));
   }
   CK(launch_pack_kbits(x, 0, ld, v, n, k1[0], flag, 0, nblk));
+  const char* vname[5] = {"enc1-split ring3 (shipped)", "enc0 ring4", "enc1 ring3", "enc1-split ring4", "enc1-split ring3 left0"};
+  const int nvar = 5;
+  for (int var = 0; var < nvar; ++var)
   for (int mode : {0, 2, 4}) {
+    g_kbits_variant = var;
+    if (var > 0 && mode == 0) continue;
     CK(hipMemset(sb, 0, (size_t)n * n * 4));
     hipError_t e = launch_gram_kbits(k1[0], v, n, sb, num_cu, 0, mode);
     if (e != hipSuccess) { (void)hipGetLastError(); std::printf("full size: k-bits mode %d does not fit\n", mode); continue; }
     CK(hipDeviceSynchronize());
     const unsigned long long d = count_diff(sa, sb, (int64_t)n * n * 4, cnt);
-    std::printf("full size n=%d v=%lld: S(k-bits, mode %d) vs S(FP4 path): %s (%llu entries differ)\n", n, (long long)v, mode,
-                d ? "MISMATCH" : "bit-identical", d);
+    std::printf("full size n=%d v=%lld: S(k-bits %s, mode %d) vs S(FP4 path): %s (%llu entries differ)\n", n, (long long)v,
+                vname[var], mode, d ? "MISMATCH" : "bit-identical", d);
     bad += d != 0;
+    if (d) {  // where: by tile, by wave sub-tile (128 x 64), by MFMA tile, first few entries
+      std::vector<int32_t> ha((size_t)n * n), hb((size_t)n * n);
+      CK(hipMemcpy(ha.data(), sa, (size_t)n * n * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(hb.data(), sb, (size_t)n * n * 4, hipMemcpyDeviceToHost));
+      int by_tile[10][10] = {}, by_wave[2][4] = {}, by_mi[4] = {}, by_ni[2] = {}, shown = 0, by_r[16] = {}, by_hi[2] = {};
+      long long sum_delta = 0;
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+          const int32_t a = ha[(size_t)i * n + j], b = hb[(size_t)i * n + j];
+          if (a == b) continue;
+          by_tile[i / 256][j / 256]++;
+          by_wave[(i % 256) / 128][(j % 256) / 64]++;
+          by_mi[(i % 128) / 32]++;
+          by_ni[(j % 64) / 32]++;
+          const int ri = i % 32;  // row inside the MFMA tile: ri = (r & 3) + 8 * (r >> 2) + 4 * hi
+          by_hi[(ri >> 2) & 1]++;
+          by_r[(ri & 3) + 4 * (ri >> 3)]++;
+          sum_delta += (long long)b - a;
+          if (shown++ < 12) std::printf("   S[%d][%d]: FP4 %d, k-bits %d (delta %d)\n", i, j, a, b, b - a);
+        }
+      std::printf("   sum of deltas %lld; by wave (wm, wn):", sum_delta);
+      for (int a = 0; a < 2; ++a) for (int b = 0; b < 4; ++b) std::printf(" %d", by_wave[a][b]);
+      std::printf("; by mi:");
+      for (int a = 0; a < 4; ++a) std::printf(" %d", by_mi[a]);
+      std::printf("; by ni: %d %d; by hi: %d %d; by r:", by_ni[0], by_ni[1], by_hi[0], by_hi[1]);
+      for (int a = 0; a < 16; ++a) std::printf(" %d", by_r[a]);
+      std::printf("\n   by tile (row block, col block):");
+      for (int a = 0; a < 10; ++a) for (int b = a; b < 10; ++b) if (by_tile[a][b]) std::printf(" (%d,%d):%d", a, b, by_tile[a][b]);
+      std::printf("\n");
+    }
   }
+  g_kbits_variant = 0;
   int32_t hflag = 0;
   CK(hipMemcpy(&hflag, flag, 4, hipMemcpyDeviceToHost));
   std::printf("flag word after the pre-passes: %d\n", hflag);
@@ -310,8 +370,12 @@ int main(int argc, char** argv) {
   for (int cus : {num_cu, num_cu / 2}) {
     std::string tag = cus == num_cu ? " [whole chip]" : " [sized for half the chip]";
     line(("FP4 lock-step" + tag).c_str(), time_ms(0, reps, [&] { CK(launch_gram_packed_lockstep(p4[0], 1, nkb * 32, n, sa, cus, 0)); }));
-    line(("k-bits lock-step (mode 2)" + tag).c_str(), time_ms(0, reps, [&] { CK(launch_gram_kbits(k1[0], v, n, sb, cus, 0, 2)); }));
-    line(("k-bits even split (mode 4)" + tag).c_str(), time_ms(0, reps, [&] { CK(launch_gram_kbits(k1[0], v, n, sb, cus, 0, 4)); }));
+    for (int var = 0; var < nvar; ++var) {
+      g_kbits_variant = var;
+      line((std::string("k-bits ") + vname[var] + " lock-step (mode 2)" + tag).c_str(), time_ms(0, reps, [&] { CK(launch_gram_kbits(k1[0], v, n, sb, cus, 0, 2)); }));
+      line((std::string("k-bits ") + vname[var] + " even split (mode 4)" + tag).c_str(), time_ms(0, reps, [&] { CK(launch_gram_kbits(k1[0], v, n, sb, cus, 0, 4)); }));
+    }
+    g_kbits_variant = 0;
   }
   for (int cus : {192, 160, 144}) {
     std::string tag = " [" + std::to_string(cus) + " workgroups]";
