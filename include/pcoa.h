@@ -27,6 +27,7 @@
 #ifndef PCOA_H_
 #define PCOA_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -167,6 +168,13 @@ int pcoa_set_stream(pcoa_ctx* ctx, void* hip_stream);
 /* Blocks until all queued work of the ctx has finished. */
 int pcoa_sync(pcoa_ctx* ctx);
 
+/* Optional.  Allocates NOW what the first calls would otherwise allocate lazily: the operand buffers for accumulate calls
+ * of up to `variants_per_call` variants (0 = skip) and the computePca workspace for `num_pc` components (0 = skip), so that
+ * no device allocation happens inside a streaming or timed region (a first pcoa_compute is ~4x slower than a later one
+ * without it).  Replaces: nothing in the reference -- the JVM allocates its per-partition matrix inside the task
+ * (VariantsPca.scala:185); this is the executor warm-up a Spark host would run once per GPU. */
+int pcoa_reserve(pcoa_ctx* ctx, int64_t variants_per_call, int32_t num_pc);
+
 /* ---- Gram accumulation: getSimilarityMatrix -------------------------------------------------- */
 
 /* The faithful boundary: exactly what RDD[Seq[Int]] carries (getCallsRdd, VariantsPca.scala:153-168).
@@ -191,9 +199,10 @@ int pcoa_accumulate_calls(pcoa_ctx* ctx, const int32_t* sample_idx, const int64_
 int pcoa_accumulate_dense_f32(pcoa_ctx* ctx, const float* x, int64_t n_variants, int64_t ld,
                               int is_device_ptr);
 
-/* Same boundary with one byte per genotype (values 0..127): the production format -- the int8 matrix
- * cores take it after a 4x cheaper re-layout pass than the fp32 tile (SURVEY.md 8f "bit-packed / int8
- * Gram path").  Always runs the i8-MFMA kernel.  Host or device pointer as above. */
+/* Same boundary with one byte per genotype (values 0..127): the production format -- a 4x cheaper re-layout pass than the
+ * fp32 tile (SURVEY.md 8f "bit-packed / int8 Gram path").  Kernel choice as for the fp32 tile: in the default (auto) mode a
+ * tile of 0 / 1 bytes goes to the MX-FP4 matrix cores (pcoa_timings.gram_kernel_kind == 3), a tile with carrier
+ * multiplicities 2..127 to the int8 ones (== 2); the create flags force either.  Host or device pointer as above. */
 int pcoa_accumulate_dense_u8(pcoa_ctx* ctx, const uint8_t* x, int64_t n_variants, int64_t ld, int is_device_ptr);
 
 /* Bit-packed variants x samples tile: row v is the carrier BITSET of variant v, 1 bit per genotype; sample i is
@@ -235,6 +244,12 @@ int pcoa_gram_allreduce_rccl(pcoa_ctx* ctx, void* nccl_comm);
  * 128-byte unique id, ships it to the other ranks by its own means (Spark broadcast), then every
  * rank calls pcoa_comm_init.  *comm_out is an ncclComm_t. */
 int pcoa_comm_unique_id(uint8_t out_id[128]);
+/* Which RCCL the three calls above and pcoa_gram_allreduce_rccl are bound to.  libpcoa_hip.so does not link librccl: at
+ * the first communicator call it binds the RCCL image the process has already mapped (a PyTorch process carries its own,
+ * torch/lib/librccl.so -- one collective runtime per process, not two), else librccl.so.1 from the library's RUNPATH
+ * (/opt/rocm/lib: the Scala / JNI host's case).  path_out receives the image's path, *version_out ncclGetVersion's code;
+ * either may be NULL.  PCOA_ERR_RCCL if no RCCL can be found. */
+int pcoa_comm_runtime(char* path_out, int32_t path_cap, int32_t* version_out);
 int pcoa_comm_init(pcoa_ctx* ctx, const uint8_t id[128], int32_t rank, int32_t n_ranks,
                    void** comm_out);
 int pcoa_comm_destroy(void* nccl_comm);
@@ -284,6 +299,16 @@ int pcoa_compute(pcoa_ctx* ctx, int32_t num_pc, double* out_components, double* 
  * (VariantsPca.scala:48,281). */
 int pcoa_get_timings(pcoa_ctx* ctx, pcoa_timings* out);
 int pcoa_reset_timings(pcoa_ctx* ctx);
+
+/* ---- test hooks (not part of the reference-facing boundary) ---------------------------------------------------------------
+ * Device memory from the library's own allocator.  With the environment variable PCOA_DEBUG_GUARD=1 (=2) every device
+ * buffer of the library -- and these -- is a virtual range of its own whose END (START) lies against a page that is
+ * never mapped: a kernel that reads or writes one element too far faults at once ("Memory access fault by GPU") instead
+ * of touching a neighbouring allocation.  The GPU test suite runs its fuzz and parity sweeps in that mode with the
+ * input tiles allocated here (tests/test_gpu_guard.py).  pcoa_debug_guard_mode returns the mode in effect (0 = off). */
+int pcoa_debug_alloc(int32_t device_ordinal, size_t bytes, void** out);
+int pcoa_debug_free(void* p);
+int pcoa_debug_guard_mode(void);
 
 /* Name of the GPU the ctx runs on, its CU count and the library version string. */
 int pcoa_device_info(pcoa_ctx* ctx, char* name_out, int32_t name_cap, int32_t* cu_count_out);

@@ -89,6 +89,11 @@ _SIGNATURES = [
     ("pcoa_n_samples", ctypes.c_int, [_vp]),
     ("pcoa_set_stream", ctypes.c_int, [_vp, _vp]),
     ("pcoa_sync", ctypes.c_int, [_vp]),
+    ("pcoa_reserve", ctypes.c_int, [_vp, _i64, _i32]),
+    ("pcoa_comm_runtime", ctypes.c_int, [ctypes.c_char_p, _i32, ctypes.POINTER(_i32)]),
+    ("pcoa_debug_alloc", ctypes.c_int, [_i32, ctypes.c_size_t, ctypes.POINTER(_vp)]),
+    ("pcoa_debug_free", ctypes.c_int, [_vp]),
+    ("pcoa_debug_guard_mode", ctypes.c_int, []),
     ("pcoa_accumulate_calls", ctypes.c_int, [_vp, _vp, _vp, _i64]),
     ("pcoa_accumulate_dense_f32", ctypes.c_int, [_vp, _vp, _i64, _i64, ctypes.c_int]),
     ("pcoa_accumulate_dense_u8", ctypes.c_int, [_vp, _vp, _i64, _i64, ctypes.c_int]),

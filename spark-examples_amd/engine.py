@@ -27,14 +27,20 @@ def _ptr(a):
 
 class PcoaEngine(object):
     def __init__(self, n_samples, device=0, flags=L.PCOA_FLAG_DEFAULT, gram_kernel=None, eig=None, strip=None,
-                 pipeline=True):
+                 pipeline=True, operand=None):
         """gram_kernel: None/"auto" (MX-FP4 MFMA for binary tiles, int8 MFMA for multiplicities; both exact),
         "fp4", "i8" (force one of them) or "f32" (fp32-MFMA path).
         eig: None/"auto" (Lanczos with verified residual, Householder fallback), "householder", "lanczos".
         strip: None, or (col0, cols): a strip owner holding S[:, col0:col0+cols] (pcoa_create_strip; see strips.py).
-        pipeline=False: PCOA_FLAG_NO_PIPELINE (fp32 pre-pass and contraction strictly serial; measurements)."""
+        pipeline=False: PCOA_FLAG_NO_PIPELINE (fp32 pre-pass and contraction strictly serial; measurements).
+        operand: None/"bits" (binary tiles are re-laid out to 1 bit per genotype and expanded to MX-FP4 inside the
+        contraction) or "fp4" (PCOA_FLAG_OPERAND_FP4: the operand is stored as MX-FP4, 4 bits per genotype)."""
         if not pipeline:
             flags |= L.PCOA_FLAG_NO_PIPELINE
+        if operand == "fp4":
+            flags |= L.PCOA_FLAG_OPERAND_FP4
+        elif operand not in (None, "bits"):
+            raise ValueError("operand must be 'bits' or 'fp4'")
         if eig == "householder":
             flags |= L.PCOA_FLAG_EIG_HOUSEHOLDER
         elif eig == "lanczos":
@@ -98,6 +104,10 @@ class PcoaEngine(object):
 
     def reset(self):
         self._check(self._lib.pcoa_reset(self._ctx))
+
+    def reserve(self, variants_per_call=0, num_pc=0):
+        """Allocate now what the first accumulate / compute calls would allocate lazily (pcoa_reserve)."""
+        self._check(self._lib.pcoa_reserve(self._ctx, int(variants_per_call), int(num_pc)))
 
     def set_stream(self, hip_stream_ptr):
         self._check(self._lib.pcoa_set_stream(self._ctx, ctypes.c_void_p(hip_stream_ptr or 0)))
@@ -259,6 +269,13 @@ class PcoaEngine(object):
         self._check(self._lib.pcoa_comm_init(self._ctx, ctypes.cast(buf, ctypes.c_void_p), int(rank), int(n_ranks),
                                              ctypes.byref(comm)))
         return comm
+
+    def comm_runtime(self):
+        """(path, version code) of the RCCL image the library's communicator calls are bound to."""
+        buf = ctypes.create_string_buffer(1024)
+        ver = ctypes.c_int32(0)
+        self._check(self._lib.pcoa_comm_runtime(buf, 1024, ctypes.byref(ver)))
+        return buf.value.decode(), int(ver.value)
 
     def comm_destroy(self, comm):
         self._check(self._lib.pcoa_comm_destroy(comm))

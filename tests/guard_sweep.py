@@ -1,0 +1,145 @@
+"""Guard-page sweep (run as a child process by tests/test_gpu_guard.py with PCOA_DEBUG_GUARD=1 or 2 in the environment).
+
+Every device buffer of libpcoa_hip.so -- and, through pcoa_debug_alloc, every INPUT tile handed to it here -- is then a
+virtual range of its own whose end (mode 1) or start (mode 2) lies against a page that is never mapped.  A kernel that
+reads or writes one element too far dies with "Memory access fault by GPU" on the spot; the last "case ..." line printed
+says which boundary of which shape it was (AMD_SERIALIZE_KERNEL=3 / HIP_LAUNCH_BLOCKING=1 keep the kernels one at a time).
+Results are still compared with an integer matmul, so an out-of-bounds read that happened to land in mapped memory and
+changed S is caught as well.
+
+usage: guard_sweep.py <n_cases> <first_seed> [loops]
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+from conftest import int_gram, load_pkg  # noqa: E402
+
+P = load_pkg()
+L = load_pkg("_lib")
+ingest = load_pkg("ingest")
+lib = L.load()
+hip = ctypes.CDLL("libamdhip64.so")  # the runtime torch / libpcoa_hip already mapped
+hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+hip.hipMemcpy.restype = ctypes.c_int
+hip.hipDeviceSynchronize.restype = ctypes.c_int
+
+
+class DevBuf(object):
+    """Host array -> exactly-sized device allocation from the library's (guarded) allocator."""
+
+    def __init__(self, a):
+        a = np.ascontiguousarray(a)
+        self.ptr = ctypes.c_void_p()
+        rc = lib.pcoa_debug_alloc(0, a.nbytes, ctypes.byref(self.ptr))
+        assert rc == 0, lib.pcoa_last_error(None)
+        assert hip.hipMemcpy(self.ptr, a.ctypes.data, a.nbytes, 1) == 0
+
+    def free(self):
+        lib.pcoa_debug_free(self.ptr)
+
+
+def case(seed):
+    rng = np.random.default_rng(seed)
+    edges_n = [1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 513, 1025]
+    edges_v = [1, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 1023, 1025]
+    n = int(rng.choice(edges_n)) if rng.random() < 0.5 else int(rng.integers(1, 1300))
+    v = int(rng.choice(edges_v)) if rng.random() < 0.5 else int(rng.integers(1, 4000))
+    dens = float(rng.choice([0.01, 0.1, 0.3, 0.6, 0.97]))
+    x = (rng.random((v, n)) < dens).astype(np.uint8)
+    return rng, n, v, x
+
+
+def check(eng, want, what):
+    got = eng.gram()
+    if not np.array_equal(got, want):
+        bad = np.argwhere(got != want)
+        raise SystemExit("MISMATCH %s: %d entries, first %s got %d want %d" % (
+            what, len(bad), bad[0], got[tuple(bad[0])], want[tuple(bad[0])]))
+
+
+def one_case(seed, idx):
+    rng, n, v, x = case(seed)
+    want = int_gram(x)
+    pad = int(rng.integers(0, 9))
+    kernel = ["auto", "auto", "fp4", "i8", "f32"][idx % 5]
+    operand = "fp4" if idx % 3 == 2 else "bits"
+    mult = (idx % 7 == 3) and kernel in ("auto", "i8")   # carrier multiplicities: the int8 path / the auto fallback
+    print("case seed=%d n=%d v=%d pad=%d kernel=%s operand=%s mult=%s" % (seed, n, v, pad, kernel, operand, mult), flush=True)
+    xm = x.astype(np.int64)
+    if mult:
+        xm = xm * rng.integers(1, 6, size=x.shape)
+        want = int_gram(xm)
+    with P.PcoaEngine(n, gram_kernel=kernel, operand=operand) as eng:
+        ctx = eng._ctx
+        # fp32 device tile, padded stride, NaN in the padding -- the allocation ends with the last row
+        a = np.full((v, n + pad), np.nan, dtype=np.float32)
+        a[:, :n] = xm
+        d = DevBuf(a)
+        eng._check(lib.pcoa_accumulate_dense_f32(ctx, d.ptr, v, n + pad, 1))
+        check(eng, want, "f32 device")
+        d.free()
+        eng.reset()
+        # uint8 device tile
+        a8 = np.full((v, n + pad), 255, dtype=np.uint8)
+        a8[:, :n] = xm
+        d = DevBuf(a8)
+        eng._check(lib.pcoa_accumulate_dense_u8(ctx, d.ptr, v, n + pad, 1))
+        check(eng, want, "u8 device")
+        d.free()
+        eng.reset()
+        # host tiles (staging buffers of the library)
+        eng.accumulate_dense(xm.astype(np.float32))
+        eng.accumulate_dense_u8(xm.astype(np.uint8))
+        check(eng, 2 * want, "host tiles")
+        eng.reset()
+        if kernel != "f32" and not mult:
+            # carrier bitsets: device (padded stride with garbage) and host
+            bits = ingest.pack_bits(x, pad_words=pad % 3)
+            if pad % 3:
+                bits[:, (n + 31) // 32:] = 0xa5a5a5a5
+            d = DevBuf(bits)
+            eng._check(lib.pcoa_accumulate_bits(ctx, d.ptr, v, bits.shape[1], 1))
+            eng.accumulate_bits(bits)
+            check(eng, 2 * want, "bits")
+            d.free()
+            eng.reset()
+        # CSR carrier lists (repeats = multiplicities when mult)
+        eng.accumulate_callsets([list(np.repeat(np.arange(n), r)) for r in xm])
+        check(eng, want, "csr")
+        if n >= 2 and idx % 4 == 0:
+            comps, lam, nz = eng.compute(min(2, n))   # centring + Lanczos (dense solver below N = 32) under the guard
+            assert np.all(np.isfinite(comps)) and np.all(np.isfinite(lam))
+    if idx % 6 == 1 and n >= 64 and kernel != "f32" and not mult:
+        # a strip owner (rectangular tile list, strip reductions) and the dense eigensolver
+        c0, cols = n // 3, n - n // 3 - 1
+        with P.PcoaEngine(n, gram_kernel=kernel, operand=operand, strip=(c0, cols)) as st:
+            st.accumulate_dense_u8(x)
+            check(st, want[:, c0:c0 + cols], "strip")
+            st.strip_col_sums()
+            st.strip_matvec(np.ones(n), np.zeros(n), 0.0)
+        with P.PcoaEngine(n, eig="householder") as hh:
+            hh.load_gram(want)
+            hh.compute(2)
+
+
+def main():
+    n_cases, first = int(sys.argv[1]), int(sys.argv[2])
+    loops = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    mode = lib.pcoa_debug_guard_mode()
+    print("guard mode %d" % mode, flush=True)
+    assert mode == int(os.environ.get("PCOA_DEBUG_GUARD", "0"))
+    for lp in range(loops):
+        for i in range(n_cases):
+            one_case(first + i, i)
+    assert hip.hipDeviceSynchronize() == 0
+    print("guard sweep ok: %d cases x %d loops, mode %d" % (n_cases, loops, mode), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -71,6 +71,93 @@ def test_config1_full_size_every_entry_and_eigenpairs_against_the_oracle(P, O):
         assert np.linalg.norm(got[:, c] - ref["components"][:, c]) < EIG_TOL
 
 
+def device_bitsets_of_synthetic_cohort(P, torch, n, v, seed, chunk=1 << 18):
+    """Carrier bitsets [v][ceil(n/32)] (int32 words, the pcoa_accumulate_bits layout) of the synthetic cohort, generated on
+    the device chunk by chunk: synth_fill into an fp32 scratch tile, packed to words by torch (plumbing)."""
+    synth = load_pkg("synth")
+    offs = synth.pop_offsets(n)
+    words = (n + 31) // 32
+    bits = torch.empty((v, words), dtype=torch.int32, device="cuda")
+    tile = torch.empty((chunk, n), dtype=torch.float32, device="cuda")
+    shifts = torch.arange(32, device="cuda", dtype=torch.int32)
+    with P.PcoaEngine(n) as gen:
+        for v0 in range(0, v, chunk):
+            c = min(chunk, v - v0)
+            gen.synth_fill(seed, offs, synth.thresholds(seed, v0, c), v0, tile.data_ptr(), n)
+            for r0 in range(0, c, 1 << 16):
+                r1 = min(c, r0 + (1 << 16))
+                xb = torch.nn.functional.pad(tile[r0:r1] > 0, (0, words * 32 - n)).view(r1 - r0, words, 32)
+                # int32 arithmetic wraps: bit 31 contributes -2^31, which is the two's-complement word wanted
+                bits[v0 + r0:v0 + r1] = (xb.to(torch.int32) << shifts).sum(dim=2, dtype=torch.int32)
+    del tile
+    torch.cuda.synchronize()
+    return bits
+
+
+def test_config2_full_size_one_cohort_on_one_gpu_bitset_boundary(P, O):
+    """BASELINE configs[2]: 2,504 samples x 40,000,000 variants (whole-genome scale).  As carrier bitsets the cohort is
+    12.6 GB and stays resident on ONE MI355X; it is accumulated as one cohort through pcoa_accumulate_bits.  Entries of S
+    pass 2^24 (the fp32-exact range of one launch) several times over and the int32 partial holds counts up to ~1.2 * 10^7
+    x ... well inside int32; the int64 fold threshold (2^30 variants) is NOT reached by 4 * 10^7 variants -- the fold and
+    the int64 all-reduce branch are forced with small thresholds elsewhere (test_multi_launch_and_int64_fold_paths).
+      (i)   partition invariance (VariantsPca.scala:184-190): S == sum of 8 shard engines over dist.shard_range(r, 8, V);
+      (ii)  blocks of S against the oracle's faithful pair loop on those sample columns of ALL 40 M variants;
+      (iii) eigenpairs against oracle.compute_pca(S) at the north_star tolerance."""
+    import torch
+    dist = load_pkg("dist")
+    synth = load_pkg("synth")
+    n, v, seed = 2504, 40000000, 1003
+    bits = device_bitsets_of_synthetic_cohort(P, torch, n, v, seed)
+    # the device generator against its host twin on a few rows of the packed cohort
+    offs = synth.pop_offsets(n)
+    ingest = load_pkg("ingest")
+    for v0 in (0, 23456789, v - 32):
+        rows = synth.genotypes(seed, v0, synth.thresholds(seed, v0, 32), offs, dtype=np.uint8)
+        assert np.array_equal(bits[v0:v0 + 32].cpu().numpy().view(np.uint32), ingest.pack_bits(rows))
+    with P.PcoaEngine(n) as eng:
+        eng.reserve(1 << 20, 2)
+        eng.accumulate_bits(bits)
+        s = eng.gram()
+        tim = eng.timings()
+        comps, lam, nz = eng.compute(2)
+    assert tim["gram_kernel_kind"] == 3 and tim["gram_variants"] == v
+    assert int(s.max()) > (1 << 24) and int(s.max()) < (1 << 31)          # beyond one launch's exact range, for real
+    assert np.array_equal(s, s.T)
+    # (i) eight shards, as the reference's partitions / the 8 ranks of configs[2] would hold them
+    total = np.zeros_like(s)
+    for r in range(8):
+        a, b = dist.shard_range(r, 8, v)
+        with P.PcoaEngine(n) as shard:
+            shard.accumulate_bits(bits[a:b])
+            total += shard.gram()
+    assert np.array_equal(total, s)
+    # (ii) blocks against the CPU oracle: 32-sample groups are word columns of the bitsets
+    def columns(word):  # [v][32] uint8 of samples 32 * word .. 32 * word + 31
+        w = bits[:, word].contiguous().cpu().numpy().view(np.uint32)
+        return np.unpackbits(w.view(np.uint8).reshape(-1, 4), axis=1, bitorder="little")
+    groups = {}
+    for (ga, gb) in ((0, 0), (7, 8), (20, 77), (41, 3), (78, 78)):   # incl. the last, partly filled word (samples 2496 .. 2503)
+        for g in (ga, gb):
+            if g not in groups:
+                groups[g] = columns(g)
+        want = np.zeros((64, 64), dtype=np.int64)
+        for v0 in range(0, v, 1 << 21):                                 # the oracle in partitions, summed (:190)
+            xa, xb = groups[ga][v0:v0 + (1 << 21)], groups[gb][v0:v0 + (1 << 21)]
+            want += O.similarity_from_dense(np.concatenate([xa, xb], axis=1).astype(np.float32), 64)
+        r0, c0 = 32 * ga, 32 * gb
+        rows, cols = min(32, n - r0), min(32, n - c0)
+        assert np.array_equal(s[r0:r0 + rows, c0:c0 + cols], want[:32, 32:][:rows, :cols]), (ga, gb)
+        assert np.array_equal(s[r0:r0 + rows, r0:r0 + rows], want[:32, :32][:rows, :rows]), (ga, ga)
+    del groups, bits
+    # (iii) eigenpairs
+    ref = O.compute_pca(s, 2)
+    assert nz == ref["nonzero_rows"]
+    assert np.max(np.abs(lam - ref["eigenvalues"]) / np.abs(ref["eigenvalues"])) < EIG_TOL
+    got = align_sign(comps, ref["components"])
+    for c in range(2):
+        assert np.linalg.norm(got[:, c] - ref["components"][:, c]) < EIG_TOL
+
+
 def test_config3_biobank_sample_count_blocks_against_the_cpu_oracle(P, O):
     """BASELINE configs[3] sample count (N = 100,000; S = 40 GB int32 in one HBM) x 65,536 variants generated on the
     device.  A block S[r0:r0+b, c0:c0+b] depends only on those 2b sample columns of X: the host twin of the generator

@@ -38,7 +38,8 @@ def test_every_boundary_agrees_with_integer_matmul(P, seed):
     want = int_gram(x)
     pad = int(rng.integers(0, 9))
     kernel = ["auto", "auto", "fp4", "i8"][seed % 4]
-    with P.PcoaEngine(n, gram_kernel=kernel) as eng:
+    operand = "fp4" if seed % 3 == 2 else "bits"   # form of the binary-tile operand in HBM (PCOA_FLAG_OPERAND_FP4 / default)
+    with P.PcoaEngine(n, gram_kernel=kernel, operand=operand) as eng:
         # fp32, device pointer, padded stride, NaN in the padding
         buf = torch.full((v, n + pad), float("nan"), dtype=torch.float32, device="cuda")
         buf[:, :n] = torch.from_numpy(x.astype(np.float32)).cuda()
@@ -63,6 +64,8 @@ def test_every_boundary_agrees_with_integer_matmul(P, seed):
         eng.accumulate_bits(torch.from_numpy(bits.view(np.int32)).cuda())
         eng.accumulate_callsets([list(np.nonzero(r)[0]) for r in x])
         assert np.array_equal(eng.gram(), 2 * want), ("bits + csr", n, v, kernel)
+        if kernel != "i8":
+            assert eng.timings()["operand_bits"] == (4 if operand == "fp4" else 1)
 
 
 @pytest.mark.parametrize("seed", range(8))

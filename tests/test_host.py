@@ -4,6 +4,7 @@ import io
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -580,3 +581,52 @@ def test_hot_kernels_do_not_spill_to_scratch():
             for nm, sc in zip(names, scratch):
                 if "gram_" in nm:
                     assert sc == 0, "%s spills %d bytes/lane" % (nm, sc)
+
+
+# ---- the same ingest tests through the AddressSanitizer + UBSan build of the compiled host ------------------
+def _sanitizer_exe():
+    import subprocess
+    hdir = os.path.join(ROOT, "spark-examples_amd", "host")
+    if not os.path.exists(os.path.join(ROOT, "spark-examples_amd", "libpcoa_hip.so")):
+        pytest.skip("libpcoa_hip.so not built")
+    res = subprocess.run(["make", "-s", "-C", hdir, "sanitize"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         universal_newlines=True)
+    exe = os.path.join(ROOT, "spark-examples_amd", "variants_pca_driver_san")
+    if res.returncode != 0 or not os.path.exists(exe):
+        pytest.skip("no sanitizer build on this machine: " + res.stdout[-300:])
+    return exe
+
+
+@pytest.mark.parametrize("which", ["ingest", "goldens_vcf", "goldens_plink", "plink_refusals", "same_stem", "gzip_path"])
+def test_compiled_host_again_under_asan_and_ubsan(which, tmp_path, monkeypatch):
+    """Every --parse-only test of this file once more with the sanitizer build in place of the release binary: a heap
+    overrun, use-after-free, leak or undefined operation in the VCF / PLINK readers, the joins or the option parsing makes
+    the child exit non-zero (abort_on_error / halt_on_error), which those tests assert against."""
+    san = _sanitizer_exe()
+    me = sys.modules[__name__]
+    monkeypatch.setattr(me, "_driver_exe", lambda: san)
+    # libpcoa_hip.so pulls in the HIP runtime, whose start-up allocations are not ours to judge: leaks are reported for
+    # the host's own frames only through the suppression of everything below the runtime libraries
+    supp = tmp_path / "lsan.supp"
+    supp.write_text("leak:libamdhip64\nleak:libhsa-runtime64\nleak:librocprofiler\nleak:libamd_comgr\nleak:libdrm\n")
+    monkeypatch.setenv("ASAN_OPTIONS", "abort_on_error=1:detect_leaks=1:strict_string_checks=1")
+    monkeypatch.setenv("LSAN_OPTIONS", "suppressions=%s:print_suppressions=0" % supp)
+    monkeypatch.setenv("UBSAN_OPTIONS", "halt_on_error=1:print_stacktrace=1")
+    if which == "ingest":
+        test_compiled_host_ingest_matches_python_ingest(tmp_path)
+    elif which == "goldens_vcf":
+        for name in golden_cases():
+            d = tmp_path / ("v_" + name)
+            d.mkdir()
+            test_vcf_ingest_of_both_hosts_reproduces_the_reference_carrier_rows(name, d)
+    elif which == "goldens_plink":
+        for name in golden_cases():
+            d = tmp_path / ("p_" + name)
+            d.mkdir()
+            test_plink_fileset_ingest_reproduces_the_reference_carrier_rows(name, d)
+    elif which == "plink_refusals":
+        test_plink_reader_refuses_what_it_cannot_read(tmp_path)
+    elif which == "same_stem":
+        test_variant_sets_with_the_same_file_stem_keep_distinct_callsets(tmp_path)
+    else:
+        test_gzip_path_with_shell_metacharacters_is_just_a_path(tmp_path)
