@@ -93,6 +93,13 @@ def main():
     ap.add_argument("--gram-kernel", choices=["auto", "fp4", "i8", "f32"], default="auto",
                     help="auto (default): binary tiles -> pack to MX-FP4 + v_mfma_f32_32x32x64_f8f6f4, tiles with "
                          "multiplicities -> int8; fp4 / i8: force one; f32: v_mfma_f32_32x32x2_f32")
+    ap.add_argument("--operand", choices=["bits", "fp4"], default="bits",
+                    help="form of the binary-tile operand in HBM: bits (default; 1 bit per genotype, expanded to MX-FP4 inside "
+                         "the contraction) or fp4 (PCOA_FLAG_OPERAND_FP4, the r01 / r02 form)")
+    ap.add_argument("--config2-variants", type=int, default=40000000,
+                    help="extras: variants of the configs[2] cohort accumulated on this one GPU as bitsets (0 = skip)")
+    ap.add_argument("--sustained-seconds", type=float, default=2.0,
+                    help="extras: length of the additional sustained run (same step, >= this many seconds of timed region)")
     args = ap.parse_args()
 
     import torch
@@ -114,8 +121,9 @@ def main():
     dist = pkg("dist")
     synth = pkg("synth")
     n, v = args.samples, args.variants
-    eng = P.PcoaEngine(n, device=local_rank, gram_kernel=args.gram_kernel)
+    eng = P.PcoaEngine(n, device=local_rank, gram_kernel=args.gram_kernel, operand=args.operand)
     dev_name, cus = eng.device_info()
+    eng.reserve(v, 2)   # operand buffers + computePca workspace now, not inside the first calls (pcoa_reserve)
 
     # ---- resident input: this rank's shard of the cohort, generated on device --------------------------
     offs = synth.pop_offsets(n)
@@ -225,11 +233,14 @@ def main():
         ms_per_step = 1e3 * elapsed / steps
         value = variants_per_job / elapsed
         launches = max(int(tim["gram_kernel_launches"]), 1)
+        kbits = int(tim["operand_bits"]) == 1
         info = {"pipeline": bool(tim["pipeline_launches"] > 0), "lockstep": bool(tim["lockstep_launches"] > 0),
+                "even_split": bool(tim["evensplit_launches"] > 0), "operand_bits_per_genotype": int(tim["operand_bits"]),
                 "pipeline_launches": int(tim["pipeline_launches"]), "lockstep_launches": int(tim["lockstep_launches"]),
+                "evensplit_launches": int(tim["evensplit_launches"]),
                 "pipeline_pre_pass_cus": int(tim["pipeline_pre_pass_cus"]),
                 "pipeline_contraction_cus": int(tim["pipeline_contraction_cus"]),
-                "what": "fp32 tiles at this N: the pre-pass of operand buffer k+1 runs beside the lock-step contraction of buffer k "
+                "what": "fp32 tiles at this N: the pre-pass of operand buffer k+1 runs beside the contraction of buffer k "
                         "(one workgroup per CU on pipeline_contraction_cus CUs, placed first; the pre-pass cannot share a CU "
                         "with it and takes the rest) -- DESIGN.md 4.1; PCOA_PIPELINE=0 disables it"}
         kern_s = tim["gram_kernel_seconds"] / launches           # average Gram-kernel launch duration (HIP events)
@@ -240,7 +251,8 @@ def main():
         pmc_path = os.path.join(ROOT, "profiles", "gram_pmc_latest.json")
         if os.path.exists(pmc_path):
             try:
-                pmc = json.load(open(pmc_path)).get({1: "f32", 2: "i8", 3: "fp4"}[tim["gram_kernel_kind"]], {})
+                pmc = json.load(open(pmc_path)).get(
+                    "kbits" if int(tim["operand_bits"]) == 1 else {1: "f32", 2: "i8", 3: "fp4"}[tim["gram_kernel_kind"]], {})
                 pmc_src = "profiles/gram_pmc_latest.json (static: rocprofv3 --pmc passes of an earlier run of this command, " \
                           "scaled to this run's launch size; NOT measured in this run)"
             except Exception:
@@ -248,7 +260,15 @@ def main():
         kind = tim["gram_kernel_kind"]          # what actually ran: 1 fp32, 2 int8, 3 MX-FP4
         pipe = bool(info.get("pipeline"))
         gram_cus = info.get("pipeline_contraction_cus", cus) if pipe else cus
-        if kind == 3:
+        if kind == 3 and kbits:
+            tile, peak = 256, PEAK_FP4_MFMA_TFLOPS
+            kname = "gram_kbits_kernel<3, 2, 2> (k-bits operand expanded to MX-FP4 in registers, ping-pong; %s launch)" % (
+                "even-split" if info.get("even_split") else "lock-step" if info.get("lockstep") else "split-K")
+            kdesc = ("pack fp32->k-bits (1 bit per genotype, HBM-bound, verifies values are 0/1) + MX-FP4 MFMA "
+                     "v_mfma_f32_32x32x64_f8f6f4 (unscaled form, exact) fed from bit words expanded in registers (0.5 x 2.0 "
+                     "conjugate E2M1 weights), upper-triangular 256x256 tiles, fp32 accumulators (< 2^24 per launch) -> "
+                     "int32 atomics")
+        elif kind == 3:
             tile, peak = 256, PEAK_FP4_MFMA_TFLOPS
             kname = "gram_packed_kernel<1, 2, 2, 4, 3, true, 2> (FMT 1 = MX-FP4, ping-pong; %s launch)" % (
                 "lock-step" if info.get("lockstep") or pipe else "split-K")
@@ -286,18 +306,20 @@ def main():
                          "frac": read_gbs / PEAK_HBM_GBS,
                          "bytes_convention": "SURVEY 8(d): 4*V*N bytes of X read once per launch",
                          "achieved_incl_operand_writes": all_gbs, "frac_incl_operand_writes": all_gbs / PEAK_HBM_GBS,
-                         "incl_note": "also credits the V*Npad%s bytes of packed operand the pre-pass writes" % ("/2" if kind == 3 else ""),
+                         "incl_note": "also credits the V*Npad%s bytes of packed operand the pre-pass writes" % (
+                             "/8" if kbits else "/2" if kind == 3 else ""),
                          "cus_used": pack_cus,
                          "traffic": (pmc["pack_hbm_bytes_per_mvariants"] * (tim["gram_variants"] / pl) / 1e6
                                      if "pack_hbm_bytes_per_mvariants" in pmc else pmc.get("pack_hbm_bytes_per_launch")),
                          "traffic_source": pmc_src,
-                         "kernel": "pack_fp4_kernel<float, 4, true>" if kind == 3 else "pack_f32_i8_kernel<4>",
+                         "kernel": ("pack_kbits_kernel<float, 4, true>" if kbits else "pack_fp4_kernel<float, 4, true>")
+                         if kind == 3 else "pack_f32_i8_kernel<4>",
                          "avg_launch_ms": 1e3 * pack_s, "launches": pl}
             if pipe:
-                roof_pack["note"] = ("fp32 pipeline: this kernel runs BESIDE the lock-step contraction of the previous buffer -- on the "
+                roof_pack["note"] = ("fp32 pipeline: this kernel runs BESIDE the contraction of the previous buffer -- on the "
                                      "%d of %d CUs the contraction's %d workgroups leave, and on all of them once it is done -- "
                                      "so its launch duration ~ the step; alone on the whole chip it takes ~2.0 ms per 10^6 "
-                                     "variants (profiles/r02*_overlap_harness.txt)" % (pack_cus, cus, gram_cus))
+                                     "variants (roofline_standalone; profiles/r03*_kbits_harness.txt)" % (pack_cus, cus, gram_cus))
         # the dominant kernel (larger share of the step) goes into `roofline`, the other into `roofline_other`
         if roof_pack is not None and tim["pack_seconds"] > tim["gram_kernel_seconds"]:
             roofline, roofline_other = roof_pack, roof_gram
@@ -339,7 +361,7 @@ def main():
                        "resident_variants_per_gpu": resident, "seed": SEED,
                        "parallelism": "variant-sharded x%d" % world,
                        "allreduce": allreduce_mode,
-                       "gram_kernel": kdesc, "gram_kernel_mode": args.gram_kernel,
+                       "gram_kernel": kdesc, "gram_kernel_mode": args.gram_kernel, "operand": args.operand,
                        "fp4_fallback_chunks": int(tim["fp4_fallbacks"])},
             "roofline": roofline, "roofline_other": roofline_other,
             "step_hbm_frac": step_hbm_frac,
@@ -365,8 +387,9 @@ def main():
         if not args.no_extras and info["pipeline"]:
             # the two kernels STANDALONE (each alone on the whole chip, strictly serial on one stream): what their own
             # rooflines look like without the other kernel beside them -- three steps on a PCOA_FLAG_NO_PIPELINE engine
-            with P.PcoaEngine(n, device=local_rank, gram_kernel=args.gram_kernel, pipeline=False) as es:
+            with P.PcoaEngine(n, device=local_rank, gram_kernel=args.gram_kernel, pipeline=False, operand=args.operand) as es:
                 a0, b0 = batch_of(0)
+                es.reserve(b0 - a0, 0)
                 es.accumulate_dense(x[a0:b0]); es.finalize(); es.sync()
                 es.reset(); es.reset_timings(); es.sync()
                 t1 = time.perf_counter()
@@ -398,6 +421,26 @@ def main():
                 alone = out["roofline_standalone"]["pre_pass" if obj.get("bound") == "hbm" else "contraction"]
                 obj["alone_on_the_chip"] = {"avg_launch_ms": alone["avg_launch_ms"], "achieved": alone["achieved"],
                                             "frac": alone["frac"], "source": "roofline_standalone (same run, same box)"}
+        if not args.no_extras and world == 1:
+            # the same step, sustained: a timed region of >= --sustained-seconds (boost clocks, thermal state and a 53-ms
+            # burst are different things); S would pass int32 on the way, so the int64 fold is part of it, as in a real
+            # whole-genome stream
+            reps_s = max(int(args.sustained_seconds / max(ms_per_step * 1e-3, 1e-6)) + 1, steps)
+            eng.reset(); eng.reset_timings(); fence()
+            t1 = time.perf_counter()
+            for i in range(reps_s):
+                one_step(i)
+            finish_job()
+            fence()
+            dts = time.perf_counter() - t1
+            out["sustained"] = {"steps": reps_s, "seconds": dts, "ms_per_step": 1e3 * dts / reps_s,
+                                "value": reps_s * (variants_per_job / steps) / dts, "unit": "variants/s",
+                                "vs_timed_region": (reps_s * (variants_per_job / steps) / dts) / value,
+                                "note": "the timed region of `value` repeated for >= %.1f s (same batches, same finalize)" % args.sustained_seconds}
+            eng.reset()
+            one_step(steps - 1)
+            finish_job()
+            fence()
         if not args.no_extras:
             # north_star's literal kernel: the fp32-MFMA Gram (v_mfma_f32_32x32x2_f32) on a slice of the same batch, so that
             # the record carries its roofline fraction too ("at >= 40 % fp32-MFMA roofline")
@@ -469,6 +512,10 @@ def main():
                                      "note": "same cohort as carrier bitsets [V][ceil(N/32)] uint32 "
                                              "(pcoa_accumulate_bits, SURVEY 8d '1-bit-packed twin'); reported separately"}
             del bits
+        if world == 1 and not args.no_extras and args.config2_variants > 0:
+            # BASELINE configs[2] on ONE GPU: the whole 40 M-variant cohort as carrier bitsets (12.6 GB, resident), one job
+            out["config2_one_gpu_bits"] = config2_one_gpu_bits(P, synth, torch, dev, local_rank, n, args.config2_variants,
+                                                               args.operand)
         if world == 1 and not args.no_extras:
             # BASELINE configs[0] stand-in: BRCA1-sized region (2,500 variants) through the faithful CSR boundary
             # (pcoa_accumulate_calls, host arrays), end to end: H2D + densify + Gram + finalize + PCoA + D2H
@@ -544,6 +591,53 @@ def main():
         td.destroy_process_group()
     eng.close()
     return 0
+
+
+def config2_one_gpu_bits(P, synth, torch, dev, local_rank, n, v, operand):
+    """BASELINE configs[2] (2,504 samples x 40 M variants, seed 1003) as ONE job on one GPU through the bit-packed boundary:
+    the cohort is generated on the device chunk by chunk and kept resident as bitsets (313 B per variant), then
+    accumulate + finalize + computePca are timed.  Reported beside the headline, never as `value`."""
+    seed, chunk = 1003, 1 << 18
+    offs = synth.pop_offsets(n)
+    words = (n + 31) // 32
+    t0 = time.perf_counter()
+    bits = torch.empty((v, words), dtype=torch.int32, device=dev)
+    tile = torch.empty((chunk, n), dtype=torch.float32, device=dev)
+    shifts = torch.arange(32, device=dev, dtype=torch.int32)
+    with P.PcoaEngine(n, device=local_rank) as gen:
+        for v0 in range(0, v, chunk):
+            c = min(chunk, v - v0)
+            gen.synth_fill(1003, offs, synth.thresholds(seed, v0, c), v0, tile.data_ptr(), n)
+            for r0 in range(0, c, 1 << 16):
+                r1 = min(c, r0 + (1 << 16))
+                xb = torch.nn.functional.pad(tile[r0:r1] > 0, (0, words * 32 - n)).view(r1 - r0, words, 32)
+                bits[v0 + r0:v0 + r1] = (xb.to(torch.int32) << shifts).sum(dim=2, dtype=torch.int32)
+    del tile
+    torch.cuda.synchronize(dev)
+    t_gen = time.perf_counter() - t0
+    with P.PcoaEngine(n, device=local_rank, operand=operand) as e2:
+        e2.reserve(1 << 20, 2)
+        e2.accumulate_bits(bits[:1 << 20]); e2.finalize(); e2.compute(2)       # warm-up
+        e2.reset(); e2.reset_timings(); e2.sync()
+        t1 = time.perf_counter()
+        e2.accumulate_bits(bits)
+        e2.finalize()
+        e2.sync()
+        t_gram = time.perf_counter() - t1
+        comps, lam, nz = e2.compute(2)
+        t_all = time.perf_counter() - t1
+        tt = e2.timings()
+        smax = int(e2.gram().max())
+    del bits
+    return {"workload": "configs[2]: %d samples x %d variants (seed %d) as carrier bitsets, resident on one GPU (%.1f GB), one job"
+                        % (n, v, seed, 4.0 * words * v / 1e9),
+            "gram_wall_s": t_gram, "gram_variants_per_s": v / t_gram, "gram_plus_pcoa_wall_s": t_all,
+            "pre_pass_s": tt["pack_seconds"], "contraction_s": tt["gram_kernel_seconds"],
+            "contraction_launches": int(tt["gram_kernel_launches"]), "largest_entry_of_S": smax,
+"eigenvalues": [float(t) for t in lam],
+            "generation_s_outside_the_timed_region": t_gen,
+            "note": "parity of this job (shard sum, oracle blocks, eigenpairs): tests/test_gpu_baseline_sizes.py::"
+                    "test_config2_full_size_one_cohort_on_one_gpu_bitset_boundary"}
 
 
 def issued_fraction(n, bm, idle_diag=True):

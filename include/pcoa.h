@@ -149,6 +149,14 @@ int pcoa_strip_col_sums(pcoa_ctx* ctx, double* out_cols);
  * Lanczos step; the owners' results concatenate (all-gather) to B v. */
 int pcoa_strip_matvec(pcoa_ctx* ctx, const double* v, const double* means, double matrix_mean, double* y_out);
 
+/* The same mat-vec for a host whose vectors already live on the GPU (e.g. torch tensors exchanged with an RCCL all-gather):
+ * pcoa_strip_set_centering uploads means (host, N doubles) and matrix_mean ONCE per computePca -- they stay resident until
+ * S changes -- and pcoa_strip_matvec_device takes v (N doubles) and y (cols doubles) as DEVICE pointers on the ctx's GPU.
+ * It returns when y is complete; v must be complete when it is called (synchronise the producing stream first).
+ * Nothing crosses PCIe per Lanczos step. */
+int pcoa_strip_set_centering(pcoa_ctx* ctx, const double* means, double matrix_mean);
+int pcoa_strip_matvec_device(pcoa_ctx* ctx, const double* v_dev, double* y_dev);
+
 /* Replaces: VariantsPcaDriver.stop (VariantsPca.scala:283-285). */
 void pcoa_destroy(pcoa_ctx* ctx);
 

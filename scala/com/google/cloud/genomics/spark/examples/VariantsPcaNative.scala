@@ -27,15 +27,22 @@ object VariantsPcaNative {
   val BatchRecords = 65536
 
   /**
-   * getSimilarityMatrix.  The RDD[Seq[Int]] of getCallsRdd (VariantsPca.scala:153-168) is coalesced to one partition
-   * per GPU; each task streams its records to its GPU as CSR batches, then the partial N x N matrices are summed over
-   * xGMI (== reduceByKey(_ + _), :190).  Returns one engine handle per GPU; every one of them holds the full S in HBM.
+   * getSimilarityMatrix.  The RDD[Seq[Int]] of getCallsRdd (VariantsPca.scala:153-168) is REpartitioned to exactly one
+   * partition per GPU (coalesce cannot raise a partition count: with fewer partitions than GPUs fewer than nGpus tasks
+   * would enter the collective commInit and the job would hang); each task streams its records to its GPU as CSR
+   * batches, then the partial N x N matrices are summed over xGMI (== reduceByKey(_ + _), :190).  All nGpus tasks must
+   * run at the same time (they meet in an RCCL collective): the executor needs >= nGpus task slots, which is checked
+   * up front.  Returns one engine handle per GPU; every one of them holds the full S in HBM.  A task that fails releases
+   * its engine before the exception leaves it.
    */
   def getSimilarityMatrix(sc: SparkContext, callsets: RDD[Seq[Int]], size: Int, nGpus: Int): Array[Long] = {
     val uid = sc.broadcast(NativePcoa.commUniqueId()) // rank 0's RCCL id, shipped by Spark
     require(uid.value != null, "pcoa_comm_unique_id failed")
-    callsets.coalesce(nGpus).mapPartitionsWithIndex { (rank, callsInPartition) =>
+    require(nGpus == 1 || sc.defaultParallelism >= nGpus,
+      s"$nGpus GPU tasks meet in one RCCL collective but only ${sc.defaultParallelism} task slots exist: they would wait for each other forever")
+    callsets.repartition(nGpus).mapPartitionsWithIndex { (rank, callsInPartition) =>
       val ctx = NativePcoa.create(size, rank, NativePcoa.FlagDefault)
+      try {
       callsInPartition.grouped(BatchRecords).foreach { batch =>
         val nnz = batch.iterator.map(_.size.toLong).sum
         val offs = NativePcoa.direct(8L * (batch.size + 1))
@@ -54,8 +61,13 @@ object VariantsPcaNative {
       if (nGpus > 1) {
         val comm = NativePcoa.commInit(ctx, uid.value, rank, nGpus)
         if (comm == 0L) throw new IllegalStateException(NativePcoa.lastError(ctx))
-        NativePcoa.check(ctx, NativePcoa.gramAllreduce(ctx, comm))
-        NativePcoa.commDestroy(comm)
+        try NativePcoa.check(ctx, NativePcoa.gramAllreduce(ctx, comm))
+        finally NativePcoa.commDestroy(comm)
+      }
+      } catch {
+        case e: Throwable =>
+          NativePcoa.destroy(ctx) // the handle never reaches the driver: release the GPU memory here
+          throw e
       }
       Iterator((rank, ctx))
     }.collect().sortBy(_._1).map(_._2)

@@ -83,6 +83,8 @@ _SIGNATURES = [
     ("pcoa_strip_info", ctypes.c_int, [_vp, ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
     ("pcoa_strip_col_sums", ctypes.c_int, [_vp, _vp]),
     ("pcoa_strip_matvec", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, _vp]),
+    ("pcoa_strip_set_centering", ctypes.c_int, [_vp, _vp, ctypes.c_double]),
+    ("pcoa_strip_matvec_device", ctypes.c_int, [_vp, _vp, _vp]),
     ("pcoa_destroy", None, [_vp]),
     ("pcoa_last_error", ctypes.c_char_p, [_vp]),
     ("pcoa_reset", ctypes.c_int, [_vp]),

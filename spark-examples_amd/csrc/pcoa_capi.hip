@@ -107,7 +107,10 @@ bool guard_free(void* p) {
   }
   (void)hipMemUnmap(r.map, r.map_size);
   (void)hipMemRelease(r.handle);
-  (void)hipMemAddressFree(r.va, r.va_size);
+  // The virtual range is deliberately NOT given back (hipMemAddressFree): a later reservation could get the same
+  // addresses with other physical pages behind them, and kernels were then seen to read through stale translations of
+  // the old mapping (wrong counts that changed from run to run, profiles/r03n_guard_va_reuse.txt).  A debug process can
+  // afford the address space, and a freed buffer's range stays unmapped for good: a use after free faults as well.
   return true;
 }
 
@@ -197,6 +200,9 @@ struct pcoa_ctx {
   bool is_strip = false;
   double* strip_ws = nullptr;      // partial sums of the strip reductions (lazy)
   int64_t strip_ws_cap = 0;
+  double* strip_means = nullptr;   // [n] rowSums / N, resident between the mat-vecs of one computePca (pcoa_strip_set_centering)
+  double strip_matrix_mean = 0.0;
+  bool strip_centering_set = false;
   int device = 0;
   uint32_t flags = 0;
   int num_cu = 256;
@@ -457,6 +463,7 @@ void account_gram(pcoa_ctx* c, int64_t cur, int64_t weight = 1) {
   c->gram_bytes += 4.0 * (double)cur * (double)c->n + 4.0 * (double)c->n * (double)c->n;
   c->variants_in_s32 += cur * weight;
   c->dirty = true;
+  c->strip_centering_set = false;  // S changes: the row means of an earlier computePca no longer belong to it
 }
 
 int fp4_quiesce(pcoa_ctx* c);
@@ -809,6 +816,7 @@ void fp4_commit(pcoa_ctx* c, int64_t kb, int64_t vars) {
   b.vars += vars;
   c->gram_kind = 3;
   c->dirty = true;
+  c->strip_centering_set = false;
 }
 
 // int8 path of one chunk: pre-pass into the workspace and contraction at once, on the ctx stream.  The pre-pass
@@ -1218,7 +1226,7 @@ void pcoa_destroy(pcoa_ctx* c) {
   if (c->hw) (void)hipHostFree(c->hw);
   if (c->ws.host_rec) (void)hipHostFree(c->ws.host_rec);
   void* bufs[] = {c->s32, c->s64, c->zeros, c->err_flag, c->tile, c->csr_idx, c->csr_offs, c->thr_dev,
-                  c->sample_pop, c->xfer, c->coll, c->fb_flags, c->strip_ws, c->pack_buf, c->lanczos_ws, c->ws.a, c->ws.d, c->ws.e, c->ws.tau, c->ws.q, c->ws.w, c->ws.lam,
+                  c->sample_pop, c->xfer, c->coll, c->fb_flags, c->strip_ws, c->strip_means, c->pack_buf, c->lanczos_ws, c->ws.a, c->ws.d, c->ws.e, c->ws.tau, c->ws.q, c->ws.w, c->ws.lam,
                   c->ws.z, c->ws.wy, c->ws.scratch, c->ws.iscratch, c->row_sums, c->colmean, c->stats, c->nz,
                   c->out_dev};
   for (void* b : bufs)
@@ -1955,6 +1963,38 @@ int pcoa_strip_matvec(pcoa_ctx* c, const double* v, const double* means, double 
   }
   HIP_TRY(c, hipMemcpyAsync(y_out, c->strip_ws, sizeof(double) * (size_t)c->s_cols, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return PCOA_OK;
+}
+
+int pcoa_strip_set_centering(pcoa_ctx* c, const double* means, double matrix_mean) {
+  CHECK_CTX(c);
+  if (!c->is_strip) return fail(c, PCOA_ERR_STATE, "not a strip owner (pcoa_create_strip)");
+  if (!means) return fail(c, PCOA_ERR_INVALID_ARG, "means is NULL");
+  if (!c->strip_means) HIP_TRY(c, dev_alloc((void**)&c->strip_means, sizeof(double) * (size_t)c->n, c->device));
+  HIP_TRY(c, hipMemcpyAsync(c->strip_means, means, sizeof(double) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller's array may go away
+  c->strip_matrix_mean = matrix_mean;
+  c->strip_centering_set = true;
+  return PCOA_OK;
+}
+
+int pcoa_strip_matvec_device(pcoa_ctx* c, const double* v_dev, double* y_dev) {
+  CHECK_CTX(c);
+  if (!c->is_strip) return fail(c, PCOA_ERR_STATE, "not a strip owner (pcoa_create_strip)");
+  if (!v_dev || !y_dev) return fail(c, PCOA_ERR_INVALID_ARG, "v_dev or y_dev is NULL");
+  if (!c->strip_centering_set) return fail(c, PCOA_ERR_STATE, "pcoa_strip_set_centering has not been called");
+  int rc = finalize_impl(c);
+  if (rc != PCOA_OK) return rc;
+  if ((rc = check_device_flags(c)) != PCOA_OK) return rc;
+  const int64_t need = strip_ws_doubles(c->n, c->s_cols) + 2 * (int64_t)c->n;
+  if ((rc = ensure(c, &c->strip_ws, &c->strip_ws_cap, need)) != PCOA_OK) return rc;
+  {
+    ScopedTimer t(c, T_LANCZOS);
+    HIP_TRY(c, launch_strip_matvec(c->s32, c->s64, c->n, c->strip_col0, c->s_cols, v_dev, c->strip_means, c->strip_matrix_mean,
+                                   c->strip_ws, c->stream));
+  }
+  HIP_TRY(c, hipMemcpyAsync(y_dev, c->strip_ws, sizeof(double) * (size_t)c->s_cols, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // y_dev is ready for the caller's own stream / collective
   return PCOA_OK;
 }
 

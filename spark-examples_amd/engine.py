@@ -300,6 +300,23 @@ class PcoaEngine(object):
         self._check(self._lib.pcoa_strip_matvec(self._ctx, _ptr(v), _ptr(means), float(matrix_mean), _ptr(out)))
         return out
 
+    def strip_set_centering(self, means, matrix_mean):
+        """Row means and matrix mean of the current S, resident on the device for strip_matvec_device."""
+        means = np.ascontiguousarray(means, dtype=np.float64)
+        if means.shape != (self.n,):
+            raise ValueError("means must have N = %d entries" % self.n)
+        self._check(self._lib.pcoa_strip_set_centering(self._ctx, _ptr(means), float(matrix_mean)))
+
+    def strip_matvec_device(self, v_dev):
+        """(B v)[col0:col0+cols] for a float64 torch tensor v on this engine's GPU; returns a device tensor (no PCIe traffic)."""
+        import torch  # plumbing only: device memory handles
+        assert v_dev.is_cuda and v_dev.dtype == torch.float64 and v_dev.dim() == 1 and v_dev.shape[0] == self.n
+        v_dev = v_dev.contiguous()
+        y = torch.empty(self.cols, dtype=torch.float64, device=v_dev.device)
+        torch.cuda.current_stream(v_dev.device).synchronize()   # the engine runs on its own stream
+        self._check(self._lib.pcoa_strip_matvec_device(self._ctx, ctypes.c_void_p(v_dev.data_ptr()), ctypes.c_void_p(y.data_ptr())))
+        return y
+
     # ------------------------------------------------------------------ computePca
     def center(self, want_matrix=True):
         """Row sums + double-centring (VariantsPca.scala:206-223).  Returns (B, row_sums, nonzero_rows, mean)."""

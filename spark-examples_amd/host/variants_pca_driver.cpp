@@ -54,6 +54,7 @@ struct Conf {  // PcaConf / GenomicsConf (GenomicsConf.scala:31-101), same flag 
   bool parse_only = false;  // not a reference flag: ingest + getCallsRdd only, prints the carrier statistics (no GPU)
   std::string dump_similarity;  // not a reference flag: writes S (N x N int64, little-endian, row-major) for parity tests
   int ingest_threads = 0;   // not a reference flag: 0 = hardware concurrency (local[*]), cf. --spark-master local[k]
+  std::string plink_ref_allele = "a2";  // not a reference flag: which .bim allele column is REF (a2 = --keep-allele-order)
   float min_allele_frequency = 0.f;
   int num_pc = 2, num_reduce_partitions = 10, gpu = 0;
   long bases_per_partition = 1000000;
@@ -93,6 +94,10 @@ Conf parse(int argc, char** argv) {
     else if (a == "--parse-only") c.parse_only = true;
     else if (a == "--dump-similarity") c.dump_similarity = one(i);
     else if (a == "--ingest-threads") c.ingest_threads = std::atoi(one(i).c_str());
+    else if (a == "--plink-ref-allele") {
+      c.plink_ref_allele = one(i);
+      if (c.plink_ref_allele != "a1" && c.plink_ref_allele != "a2") die("--plink-ref-allele takes a1 or a2");
+    }
     else die("unknown flag " + a);
   }
   return c;
@@ -434,8 +439,22 @@ bool is_plink_path(const std::string& p) {
 // .bed, two bits per genotype, four samples to a byte (sample s in bits 2 (s % 4) of byte s / 4): 00 homozygous A1,
 // 01 missing, 10 heterozygous, 11 homozygous A2.  A2 is the reference allele (plink --keep-allele-order / plink2
 // --make-bed), so hasVariation (:56-60) = code 00 or 10; a missing call has none.  Callset index = row of the .fam,
-// name = its IID.  Contig rule and --references filter as for a VCF (0-based start = bp - 1).
-Dataset load_plink(const std::string& path, const std::string& stem, const std::vector<Region>& regions, int32_t index_base) {
+// name = its IID.  Contig rule and --references filter as for a VCF (0-based start = bp - 1); a .bim names the sex and
+// mitochondrial chromosomes by NUMBER (23 X, 24 Y, 25 XY, 26 MT, 0 unplaced), which the VCF rule would keep as ordinary
+// contigs although the reference drops X / Y / MT (VariantsRDD.scala:103-110): they are mapped back to their names first,
+// so the same cohort gives the same S through either format.  ref_a1: A1 is the reference allele (a fileset written
+// without --keep-allele-order): the codes 00 and 11 trade places.
+std::string plink_chrom_name(const std::string& chrom) {
+  if (chrom == "23") return "X";
+  if (chrom == "24") return "Y";
+  if (chrom == "25") return "XY";
+  if (chrom == "26") return "MT";
+  if (chrom == "0") return "unplaced";
+  return chrom;
+}
+
+Dataset load_plink(const std::string& path, const std::string& stem, const std::vector<Region>& regions, int32_t index_base,
+                   bool ref_a1) {
   const std::string prefix = path.substr(0, path.size() - 4);
   Dataset d;
   {
@@ -463,7 +482,7 @@ Dataset load_plink(const std::string& path, const std::string& stem, const std::
       long bp = 0;
       if (!(is >> chrom >> id >> cm >> bp)) continue;
       std::string contig;
-      bool ok = normalize_contig(chrom, contig);
+      bool ok = normalize_contig(plink_chrom_name(chrom), contig);
       if (ok && !regions.empty()) {
         ok = false;
         for (const auto& r : regions)
@@ -487,7 +506,7 @@ Dataset load_plink(const std::string& path, const std::string& stem, const std::
     Variant var;
     for (size_t s = 0; s < n; ++s) {
       const unsigned code = (row[s >> 2] >> (2 * (s & 3))) & 3u;
-      if (code == 0u || code == 2u) var.carriers.push_back(index_base + (int32_t)s);
+      if (code == 2u || code == (ref_a1 ? 3u : 0u)) var.carriers.push_back(index_base + (int32_t)s);
     }
     d.variants.push_back(std::move(var));
   }
@@ -514,7 +533,8 @@ int main(int argc, char** argv) {
       if (conf.input_path.size() > 1 || conf.has_maf)
         die("joining variant sets or filtering by allele frequency needs VCF inputs: a PLINK fileset is read as carriers "
             "only (no ref/alt keys, no INFO/AF)");
-      data.push_back(load_plink(conf.input_path[k], set_id_of(conf.input_path[k], k, used_stems), regions, (int32_t)ids.size()));
+      data.push_back(load_plink(conf.input_path[k], set_id_of(conf.input_path[k], k, used_stems), regions, (int32_t)ids.size(),
+                                conf.plink_ref_allele == "a1"));
     } else {
       data.push_back(load_vcf(conf.input_path[k], set_id_of(conf.input_path[k], k, used_stems), regions, (int32_t)ids.size(),
                               conf.debug_datasets, conf.ingest_threads));

@@ -25,6 +25,16 @@ def normalize_contig(name):
     return m.group(2) if m else None
 
 
+# A .bim names the sex and mitochondrial chromosomes by number; the reference's contig rule drops X / Y / MT
+# (VariantsRDD.scala:103-110), so the numeric codes are mapped back to their names before that rule is applied and the same
+# cohort gives the same S as a VCF and as a PLINK fileset.
+_PLINK_CHROM = {"23": "X", "24": "Y", "25": "XY", "26": "MT", "0": "unplaced"}
+
+
+def plink_contig(chrom):
+    return normalize_contig(_PLINK_CHROM.get(chrom, chrom))
+
+
 def parse_references(refs):
     """'chr17:41196311:41277499' (optionally comma separated) -> [(contig, start, end)]"""
     out = []
@@ -149,7 +159,7 @@ def load_plink(path, references=None, ref_allele="a2", chunk_variants=4096, as_b
             if not ln.strip():
                 continue
             t = ln.split()
-            contig = normalize_contig(t[0])
+            contig = plink_contig(t[0])
             ok = contig is not None
             if ok and regions:
                 start = int(t[3]) - 1

@@ -10,7 +10,10 @@ and nothing N x N ever moves.  computePca (VariantsPca.scala:198-231) becomes
                                    reference's operation order
   principal components (:224-227)  Lanczos with full re-orthogonalisation on B: one mat-vec per step = one
                                    pcoa_strip_matvec per owner + an all-gather of the N-vector; the Krylov basis
-                                   (N x m doubles) and the m x m tridiagonal live on the host, replicated on every rank;
+                                   (N x m doubles), replicated on every rank, lives ON THE DEVICE when the owners are
+                                   engines (the row means are uploaded once, the vector and the basis never cross PCIe,
+                                   the exchange is an all-gather of device tensors: RCCL) and on the host for the numpy
+                                   stand-ins of the CPU tests; the m x m tridiagonal is host-side either way;
                                    a Ritz pair is accepted on its TRUE residual ||B u - theta u||, as in the single-GPU
                                    engine (csrc/eig_lanczos.hip)
 
@@ -86,12 +89,21 @@ def feed_owners_from_variant_shards(owners, local_bits, group=None, chunk_varian
     except Exception:  # pragma: no cover
         dist, world = None, 1
 
+    fed = [0]
+
     def give(tile):
         if tile.shape[0] == 0:
             return
         arg = tile if tile.is_cuda else tile.numpy().view(np.uint32)
         for o in owners:
             o.accumulate_bits(arg)
+        # an engine keeps every device tile alive until its next sync() (the pre-pass reads it asynchronously): without a
+        # sync now and then the all-gathered chunks of a whole cohort -- GBs per round at N = 250,000 -- stay pinned
+        fed[0] += 1
+        if tile.is_cuda and fed[0] % 4 == 0:
+            for o in owners:
+                if hasattr(o, "sync"):
+                    o.sync()
 
     if world == 1:
         for v0 in range(0, t.shape[0], chunk):
@@ -117,6 +129,25 @@ def feed_owners_from_variant_shards(owners, local_bits, group=None, chunk_varian
             give(got[r][:k])
             total += k
     return total
+
+
+def gather_concat_device(pieces, widths, group=None):
+    """gather_concat for 1-D float64 DEVICE tensors: torch.distributed.all_gather (RCCL over xGMI) of the rank's
+    concatenated pieces, padded to the widest rank (`widths`: columns per rank, known from the strip ranges)."""
+    import torch
+    local = torch.cat(pieces) if len(pieces) > 1 else pieces[0]
+    try:
+        import torch.distributed as dist
+    except Exception:  # pragma: no cover
+        return local
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    wmax = max(widths)
+    mine = torch.zeros(wmax, dtype=torch.float64, device=local.device)
+    mine[:local.shape[0]] = local
+    got = [torch.empty_like(mine) for _ in widths]
+    dist.all_gather(got, mine, group=group)
+    return torch.cat([g[:w] for g, w in zip(got, widths)])
 
 
 def _sign_normalize(u):
@@ -148,8 +179,28 @@ def compute_pca_over_strips(owners, num_pc=2, group=None, max_steps=512, tol=1e-
     matrix_mean = float(rs.sum()) / rc / rc                                  # :210-211 (integers < 2^53: any order)
     means = rs / rc                                                          # rowSums(i) / N, reused as column means
 
-    def matvec(v):
-        return gather_concat([o.strip_matvec(v, means, matrix_mean) for o in owners], group)
+    # Engines keep everything of the iteration on the device (row means uploaded once; vector, Krylov basis and
+    # re-orthogonalisation on the GPU; all-gather of device tensors).  xp = torch on that path, numpy for the stand-ins.
+    on_device = all(hasattr(o, "strip_matvec_device") for o in owners)
+    if on_device:
+        import torch
+        dev = torch.device("cuda", int(getattr(owners[0], "device", 0)))
+        for o in owners:
+            o.strip_set_centering(means, matrix_mean)
+        my_cols = int(sum(o.strip[1] for o in owners))
+        widths = [int(wd) for wd in gather_concat([np.array([my_cols], dtype=np.float64)], group)]
+
+        def matvec(v):
+            return gather_concat_device([o.strip_matvec_device(v) for o in owners], widths, group)
+
+        def to_host(t):
+            return t.cpu().numpy()
+    else:
+        def matvec(v):
+            return gather_concat([o.strip_matvec(v, means, matrix_mean) for o in owners], group)
+
+        def to_host(t):
+            return t
 
     # deterministic start vector (the same LCG stream on every rank)
     idx = np.arange(1, n + 1, dtype=np.uint64)
@@ -161,8 +212,14 @@ def compute_pca_over_strips(owners, num_pc=2, group=None, max_steps=512, tol=1e-
     v /= np.linalg.norm(v)
 
     mmax = int(min(max_steps, n))
-    basis = np.zeros((mmax + 1, n), dtype=np.float64)
-    basis[0] = v
+    if on_device:
+        basis = torch.zeros((mmax + 1, n), dtype=torch.float64, device=dev)
+        basis[0] = torch.from_numpy(v).to(dev)
+        norm = lambda t: float(torch.linalg.vector_norm(t))            # noqa: E731
+    else:
+        basis = np.zeros((mmax + 1, n), dtype=np.float64)
+        basis[0] = v
+        norm = lambda t: float(np.linalg.norm(t))                      # noqa: E731
     alpha, beta = [], []
     next_check = max(k + 1, min(first_check, mmax))
     for j in range(mmax):
@@ -172,7 +229,7 @@ def compute_pca_over_strips(owners, num_pc=2, group=None, max_steps=512, tol=1e-
         # full re-orthogonalisation, twice (classical Gram-Schmidt x 2)
         for _ in range(2):
             w -= basis[:j + 1].T @ (basis[:j + 1] @ w)
-        b = float(np.linalg.norm(w))
+        b = norm(w)
         m = j + 1
         breakdown = b <= 1e-14 * max(1.0, max(abs(x) for x in alpha))
         if m >= next_check or breakdown or m == mmax:
@@ -187,16 +244,17 @@ def compute_pca_over_strips(owners, num_pc=2, group=None, max_steps=512, tol=1e-
             if trace is not None:
                 trace.append((m, theta.copy(), est.copy()))
             if ok or breakdown:
-                u = basis[:m].T @ y[:, order]
-                u /= np.linalg.norm(u, axis=0)
+                yk = np.ascontiguousarray(y[:, order])
+                u = basis[:m].T @ (torch.from_numpy(yk).to(dev) if on_device else yk)
+                u = u / (torch.linalg.vector_norm(u, dim=0) if on_device else np.linalg.norm(u, axis=0))
                 # accept only on the TRUE residual (one more mat-vec per vector)
                 good = len(order) == k
                 for c in range(len(order)):
-                    r = matvec(u[:, c]) - theta[c] * u[:, c]
-                    res = float(np.linalg.norm(r))
+                    uc = u[:, c].contiguous() if on_device else u[:, c]
+                    res = norm(matvec(uc) - theta[c] * uc)
                     good = good and res <= max(tol * scale * 10.0, 1e-9 * abs(theta[c])) and res <= 1e-6 * max(gaps[c], 1e-300)
                 if good:
-                    return _sign_normalize(u), theta.copy(), nonzero
+                    return _sign_normalize(to_host(u)), theta.copy(), nonzero
             next_check = m + (4 if m < 24 else 8)
         if breakdown or m == mmax:
             break

@@ -222,6 +222,9 @@ class PcaConf(object):
         # additions of this engine
         p.add_argument("--synthetic", type=str, default=None, help="V,N,seed: synthetic Balding-Nichols input")
         p.add_argument("--gpu", type=int, default=0)
+        p.add_argument("--plink-ref-allele", choices=["a1", "a2"], default="a2",
+                       help="PLINK filesets: which .bim allele column is the reference allele (a2: written with "
+                            "--keep-allele-order / plink2 --make-bed; a1: the other way round)")
         p.add_argument("--dump-similarity", type=str, default=None,
                        help="write S (N x N int64, little-endian, row-major) to this file (parity tests)")
         a = p.parse_args(list(arguments))
@@ -401,7 +404,7 @@ def load_dataset(conf):
         if paths[0].endswith(".npz"):
             return ingest.load_npz(paths[0])
         if paths[0][-4:] in (".bed", ".bim", ".fam"):
-            return ingest.load_plink(paths[0], refs, as_bits=True)
+            return ingest.load_plink(paths[0], refs, ref_allele=conf.plink_ref_allele, as_bits=True)
         return ingest.load_vcf(paths[0], refs)
     # several variant sets (or the AF filter): full variant records are needed for keys and INFO/AF
     if any(p.endswith(".npz") or p[-4:] in (".bed", ".bim", ".fam") for p in paths):

@@ -7,7 +7,7 @@ says which boundary of which shape it was (AMD_SERIALIZE_KERNEL=3 / HIP_LAUNCH_B
 Results are still compared with an integer matmul, so an out-of-bounds read that happened to land in mapped memory and
 changed S is caught as well.
 
-usage: guard_sweep.py <n_cases> <first_seed> [loops]
+usage: guard_sweep.py <n_cases> <first_seed> [loops] [index of the first case]
 """
 import ctypes
 import os
@@ -39,6 +39,10 @@ class DevBuf(object):
         rc = lib.pcoa_debug_alloc(0, a.nbytes, ctypes.byref(self.ptr))
         assert rc == 0, lib.pcoa_last_error(None)
         assert hip.hipMemcpy(self.ptr, a.ctypes.data, a.nbytes, 1) == 0
+        # a "synchronous" copy into a virtual-memory mapping was seen to return before the data is visible to kernels on
+        # the engine's (non-blocking) stream: the first guarded sweeps read partly copied tiles.  (The library's own copies
+        # are stream-ordered with the kernels that consume them.)
+        assert hip.hipDeviceSynchronize() == 0
 
     def free(self):
         lib.pcoa_debug_free(self.ptr)
@@ -131,12 +135,13 @@ def one_case(seed, idx):
 def main():
     n_cases, first = int(sys.argv[1]), int(sys.argv[2])
     loops = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    idx0 = int(sys.argv[4]) if len(sys.argv) > 4 else 0   # reproduce case number idx0 of an earlier sweep on its own
     mode = lib.pcoa_debug_guard_mode()
     print("guard mode %d" % mode, flush=True)
     assert mode == int(os.environ.get("PCOA_DEBUG_GUARD", "0"))
     for lp in range(loops):
         for i in range(n_cases):
-            one_case(first + i, i)
+            one_case(first + i, idx0 + i)
     assert hip.hipDeviceSynchronize() == 0
     print("guard sweep ok: %d cases x %d loops, mode %d" % (n_cases, loops, mode), flush=True)
 

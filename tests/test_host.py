@@ -406,14 +406,49 @@ def test_plink_fileset_ingest_reproduces_the_reference_carrier_rows(name, tmp_pa
                 for r in bparts[0][1]]
         assert [r for r in rows if r] == want
         assert all((np.asarray(r)[-1] >> np.uint32(n % 32)) == 0 for r in bparts[0][1]) if n % 32 else True
-        if not flip:   # the compiled host reads the same fileset (A2 = reference) and returns the same rows
-            stdout, got = _parse_only_rows(_driver_exe(), [prefix + ".bed"], str(tmp_path / "o"),
-                                           extra=["--references", "chr17:41196311:41277499"])
-            assert "Matrix size: %d." % n in stdout and got == want
+        # the compiled host reads the same fileset (--plink-ref-allele a1 for the flipped one) and returns the same rows
+        stdout, got = _parse_only_rows(_driver_exe(), [prefix + ".bed"], str(tmp_path / "o"),
+                                       extra=["--references", "chr17:41196311:41277499"] + (["--plink-ref-allele", "a1"] if flip else []))
+        assert "Matrix size: %d." % n in stdout and got == want
         # the prefix and the .fam name the same fileset; a region that holds nothing gives no rows
         assert np.array_equal(ingest.load_plink(prefix, None, ref_allele="a1" if flip else "a2")[2][0][1], idx)
         empty = ingest.load_plink(prefix + ".fam", ["chr17:1:100"])[2][0]
         assert empty[1].size == 0 and empty[2].tolist() == [0]
+
+
+def test_plink_sex_and_mitochondrial_chromosome_codes_are_dropped_like_x_y_mt_in_a_vcf(tmp_path):
+    """A .bim names X / Y / XY / MT / unplaced as 23 / 24 / 25 / 26 / 0.  The reference's contig rule keeps [a-z]*[0-9]+ only
+    (VariantsRDD.scala:103-110), i.e. drops X, Y, MT of a VCF; the same variants written to a PLINK fileset must be dropped
+    too, by both hosts, or the two formats of one cohort give different S."""
+    from conftest import write_golden_plink
+    g = load_golden("pops40")
+    offs = g["row_offsets"]
+    n = int(g["n_samples"])
+    prefix = str(tmp_path / "sex")
+    write_golden_plink(g, prefix)
+    lines = open(prefix + ".bim").read().splitlines()
+    codes = {1: "23", 2: "24", 4: "25", 5: "26", 7: "0", 8: "X", 9: "MT"}
+    for k, code in codes.items():
+        t = lines[k].split("\t")
+        t[0] = code
+        lines[k] = "\t".join(t)
+    open(prefix + ".bim", "w").write("\n".join(lines) + "\n")
+    variants = json.loads(str(g["variants_json"]))
+    ids = [str(s) for s in g["callset_ids"]]
+    ingest = load_pkg("ingest")
+    kind, idx, o = ingest.load_plink(prefix + ".bed", None)[2][0]
+    got = [idx[o[k]:o[k + 1]].tolist() for k in range(len(o) - 1)]
+    # expected: the carrier rows of the variants that keep an autosomal code, empty rows dropped (VariantsPca.scala:166)
+    want = []
+    for k, var in enumerate(variants):
+        if k in codes:
+            continue
+        row = sorted(ids.index(c["callSetId"]) for c in var.get("calls", []) if any(a > 0 for a in c["genotype"]))
+        if row:
+            want.append(row)
+    assert got == want and len(got) < len(offs) - 1
+    stdout, got_cpp = _parse_only_rows(_driver_exe(), [prefix + ".bed"], str(tmp_path / "o"), extra=["--all-references"])
+    assert got_cpp == want and "Matrix size: %d." % n in stdout
 
 
 def test_plink_reader_refuses_what_it_cannot_read(tmp_path):
@@ -626,6 +661,9 @@ def test_compiled_host_again_under_asan_and_ubsan(which, tmp_path, monkeypatch):
             test_plink_fileset_ingest_reproduces_the_reference_carrier_rows(name, d)
     elif which == "plink_refusals":
         test_plink_reader_refuses_what_it_cannot_read(tmp_path)
+        d = tmp_path / "sexchrom"
+        d.mkdir()
+        test_plink_sex_and_mitochondrial_chromosome_codes_are_dropped_like_x_y_mt_in_a_vcf(d)
     elif which == "same_stem":
         test_variant_sets_with_the_same_file_stem_keep_distinct_callsets(tmp_path)
     else:
