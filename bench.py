@@ -243,6 +243,15 @@ def main():
                 "what": "fp32 tiles at this N: the pre-pass of operand buffer k+1 runs beside the contraction of buffer k "
                         "(one workgroup per CU on pipeline_contraction_cus CUs, placed first; the pre-pass cannot share a CU "
                         "with it and takes the rest) -- DESIGN.md 4.1; PCOA_PIPELINE=0 disables it"}
+        # k-bits operand: the two kernels SHARE the CUs (persistent ring pre-pass, 40 VGPRs, beside a contraction held to 224)
+        cores = bool(tim["pipeline_pre_pass_cus"] + tim["pipeline_contraction_cus"] > cus and tim["pipeline_launches"] > 0)
+        info["co_resident"] = cores
+        if cores:
+            info["what"] = ("fp32 tiles at this N, k-bits operand: the pre-pass of operand buffer k+1 (pack_kbits_ring_kernel: "
+                            "persistent, LDS-DMA ring, two workgroups of 4 waves per CU, 40 VGPRs) runs on the SAME CUs as the "
+                            "contraction of buffer k (gram_kbits_kernel held to 224 VGPRs per wave, one workgroup on each of "
+                            "pipeline_contraction_cus CUs, placed first) -- DESIGN.md 4.1, profiles/r03s..u_coreside.txt; "
+                            "PCOA_KBITS_CORESIDE=0 gives the disjoint-CU form back, PCOA_PIPELINE=0 the serial order")
         kern_s = tim["gram_kernel_seconds"] / launches           # average Gram-kernel launch duration (HIP events)
         vpl = tim["gram_variants"] / launches                    # variants per contraction launch
         flops_per_launch = 2.0 * vpl * n * n                     # algorithmic 2*V*N^2
@@ -312,10 +321,15 @@ def main():
                          "traffic": (pmc["pack_hbm_bytes_per_mvariants"] * (tim["gram_variants"] / pl) / 1e6
                                      if "pack_hbm_bytes_per_mvariants" in pmc else pmc.get("pack_hbm_bytes_per_launch")),
                          "traffic_source": pmc_src,
-                         "kernel": ("pack_kbits_kernel<float, 4, true>" if kbits else "pack_fp4_kernel<float, 4, true>")
+                         "kernel": (("pack_kbits_ring_kernel<8, 2, 0>" if info.get("co_resident") else
+                                     "pack_kbits_kernel<float, 4, true>") if kbits else "pack_fp4_kernel<float, 4, true>")
                          if kind == 3 else "pack_f32_i8_kernel<4>",
                          "avg_launch_ms": 1e3 * pack_s, "launches": pl}
-            if pipe:
+            if pipe and info.get("co_resident"):
+                roof_pack["note"] = ("fp32 pipeline, co-resident form: this kernel's waves share all %d CUs with the %d workgroups "
+                                     "of the previous buffer's contraction, and have the chip to themselves once that is done -- "
+                                     "its launch duration ~ the step; alone on the chip: roofline_standalone" % (cus, gram_cus))
+            elif pipe:
                 roof_pack["note"] = ("fp32 pipeline: this kernel runs BESIDE the contraction of the previous buffer -- on the "
                                      "%d of %d CUs the contraction's %d workgroups leave, and on all of them once it is done -- "
                                      "so its launch duration ~ the step; alone on the whole chip it takes ~2.0 ms per 10^6 "

@@ -99,7 +99,9 @@ typedef struct pcoa_timings {
   int64_t lockstep_launches;    /* contraction launches in the lock-step form (all tiles of a k-stream resident)  */
   int64_t pipeline_launches;    /* of those: launched on the contraction stream beside the next buffer's pre-pass
                                    (fp32 pipeline)                                                  */
-  int32_t pipeline_pre_pass_cus;    /* CUs left to the pre-pass while such a contraction runs (0 = pipeline unavailable) */
+  int32_t pipeline_pre_pass_cus;    /* CUs the pre-pass runs on while such a contraction does (0 = pipeline unavailable).  k-bits
+                                       operand: all of them -- the ring pre-pass SHARES every CU with the contraction --, so
+                                       pipeline_pre_pass_cus + pipeline_contraction_cus > the CU count means "co-resident" */
   int32_t pipeline_contraction_cus; /* CUs that contraction occupies (one workgroup each)                        */
   int64_t evensplit_launches;   /* contraction launches in the even-split form (k-bits operand: every workgroup an equal
                                    run of (tile, stage) units, one workgroup per CU)                                */

@@ -104,6 +104,124 @@ __global__ __launch_bounds__(256) void pack_kbits_kernel(const T* __restrict__ x
   if (bad || badw) atomicOr(flag, 8);
 }
 
+// ---- persistent k-bits pre-pass fed by an LDS-DMA ring (fp32 tiles with ld % 4 == 0 and a 16-byte aligned base) ------------
+// Same output as pack_kbits_kernel<float, 4>, built to SHARE a CU with the contraction (the fp32 pipeline of pcoa_capi.hip):
+// 256 threads = one wave per SIMD, 40 VGPRs (a contraction held to 224 VGPRs per wave leaves 64 of a SIMD's 512), 4 * R KiB
+// of LDS, a fixed grid of one or two workgroups per CU that live for the whole launch.  With the FP4 operand sharing a CU
+// was negative-sum (r02: the contraction pulled 53 GB/s per CU of L2 hits through the same in-order vector-memory path);
+// the k-bits contraction pulls 13, and beside it this kernel keeps ~90 % of the rate it has alone (profiles/r03s .. r03u).  A wave owns units of (block of 128 variants, 256 samples) = 128 rows x 1 KiB; rows travel
+// HBM -> LDS by global_load_lds_dwordx4 into the wave's private ring of R one-row slots; per row the wave reads its 16 B
+// back (ds_read_b128), converts 4 values (bit 23 of the fp32 pattern is set for 1.0f and clear for 0.0f; fma(f, f, -f) is
+// +0 exactly for f in {0, -0, 1}) and re-issues the slot R rows ahead.
+template <int R, int AUX, int C>
+__device__ __forceinline__ void ring_rows_kbits(const char* xb, int64_t ldb, int nv, int blk, uint32_t voff, int blkn,
+                                                uint32_t voffn, uint8_t* myring, int lane, f32x4_t& a, uint32_t (&w)[4][4],
+                                                uint32_t (&bad4)[4]) {
+  auto issue = [&](int bq, uint32_t vo, int r, int slot) {
+    int row = bq * 128 + r;
+    row = row < nv ? row : nv - 1;
+    const char* src = xb + (int64_t)row * ldb + vo;
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(myring + slot * 1024), 16, 0, AUX);
+  };
+#pragma unroll
+  for (int t = 0; t < 32; ++t) {
+    constexpr int dummy = 0;
+    (void)dummy;
+    const int r = C * 32 + t;  // row of the unit
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): row r is in `a`, its slot is free
+    __builtin_amdgcn_sched_barrier(0);
+    if (r + R < 128) issue(blk, voff, r + R, t % R);
+    else issue(blkn, voffn, r + R - 128, t % R);
+    wait_vmcnt<R - 1>();  // row r + 1 has landed
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x4_t b = *reinterpret_cast<const f32x4_t*>(myring + ((t + 1) % R) * 1024 + lane * 16);
+    __builtin_amdgcn_sched_barrier(0);
+    if (blk * 128 + r < nv) {  // wave-uniform
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        const float f = a[s2];
+        bad4[s2] |= __float_as_uint(__builtin_fmaf(f, f, -f));
+        w[s2][C] |= ((__float_as_uint(f) >> 23) & 1u) << t;
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) asm volatile("" : "+v"(w[s2][C]), "+v"(bad4[s2]));
+    }
+    a = b;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int R, int AUX, int PRIO = 0>
+__global__ __launch_bounds__(256, 8) void pack_kbits_ring_kernel(const float* __restrict__ x, int64_t ld, int nv, int n, int npad,
+                                                                 int n_units, uint32_t* __restrict__ p,
+                                                                 int32_t* __restrict__ flag) {
+  static_assert(R == 8 || R == 16 || R == 32, "the slot of row t must be a compile-time constant of the 32-row unrolled body");
+  extern __shared__ __attribute__((aligned(16))) uint8_t ring_dyn_kbits[];  // 4 * R KiB, passed at launch (see pack_fp4_ring_kernel)
+  if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO);  // a memory-bound wave issues rarely: let it go first when it can
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gw = npad >> 8;  // 256-sample groups per block
+  const int stride = (int)gridDim.x * 4;
+  const int stride_b = stride / gw, stride_g = stride - stride_b * gw;
+  int u = (int)blockIdx.x * 4 + wave;
+  if (u >= n_units) return;  // no workgroup barrier anywhere below
+  int blk = u / gw, G = u - blk * gw;
+  uint8_t* const myring = ring_dyn_kbits + wave * (R * 1024);
+  const char* const xb = reinterpret_cast<const char*>(x);
+  const int64_t ldb = ld * 4;
+  uint32_t bad = 0;
+  auto lane_off = [&](int Gq) -> uint32_t {
+    const int col = Gq * 256 + lane * 4;
+    return col < ld ? (uint32_t)col * 4u : 0u;
+  };
+  uint32_t voff = lane_off(G);
+#pragma unroll
+  for (int t = 0; t < R; ++t) {
+    int row = blk * 128 + t;
+    row = row < nv ? row : nv - 1;
+    __builtin_amdgcn_global_load_lds((gptr_t)(xb + (int64_t)row * ldb + voff), (lptr_t)(myring + t * 1024), 16, 0, AUX);
+  }
+  wait_vmcnt<R - 1>();
+  f32x4_t a = *reinterpret_cast<const f32x4_t*>(myring + lane * 16);  // row 0 of the first unit
+  for (;;) {
+    int blkn = blk + stride_b, Gn = G + stride_g;
+    if (Gn >= gw) { Gn -= gw; blkn += 1; }
+    const bool last = u + stride >= n_units;
+    if (last) { blkn = blk; Gn = G; }  // a harmless re-read keeps the queue depth (and vmcnt) uniform
+    const uint32_t voffn = lane_off(Gn);
+    const int col = G * 256 + lane * 4;
+    uint32_t w[4][4], bad4[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      bad4[s2] = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[s2][q] = 0;
+    }
+    ring_rows_kbits<R, AUX, 0>(xb, ldb, nv, blk, voff, blkn, voffn, myring, lane, a, w, bad4);
+    ring_rows_kbits<R, AUX, 1>(xb, ldb, nv, blk, voff, blkn, voffn, myring, lane, a, w, bad4);
+    ring_rows_kbits<R, AUX, 2>(xb, ldb, nv, blk, voff, blkn, voffn, myring, lane, a, w, bad4);
+    ring_rows_kbits<R, AUX, 3>(xb, ldb, nv, blk, voff, blkn, voffn, myring, lane, a, w, bad4);
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      const uint32_t cm = (col + s2 < n) ? 0xffffffffu : 0u;  // samples >= n may hold anything
+      bad |= bad4[s2] & cm;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[s2][q] &= cm;
+    }
+    uint4* dst = reinterpret_cast<uint4*>(p + ((size_t)blk * npad + col) * 4);
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) dst[s2] = make_uint4(w[s2][0], w[s2][1], w[s2][2], w[s2][3]);
+    if (last) break;
+    u += stride;
+    blk = blkn;
+    G = Gn;
+    voff = voffn;
+  }
+  wait_vmcnt<0>();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (bad) atomicOr(flag, 8);
+}
+
 // uint8 tile, 8-byte loads (ld % 8 == 0, 8-byte aligned base): one thread = 128 variants x 8 samples.  Per batch of 8 rows
 // the 0/1 bytes of row t are OR-ed in at bit t, which leaves one byte of 8 row-bits per sample: byte q of word c.
 __global__ __launch_bounds__(256) void pack_u8x8_kbits_kernel(const uint8_t* __restrict__ x, int64_t ld, int64_t nv, int n,
@@ -467,7 +585,10 @@ __device__ __forceinline__ void ppb_stage(StageBits* lds, const int8_t* __restri
   if (s + 1 < ns) {
     const int rem = ns - 2 - s;
     const int keep = rem < D - 1 ? rem : D - 1;
-    if (keep >= 2) wait_vmcnt<(D >= 3 ? 2 * PER_WAVE : 0)>();
+    if (keep >= 5) wait_vmcnt<(D >= 6 ? 5 * PER_WAVE : 0)>();
+    else if (keep == 4) wait_vmcnt<(D >= 5 ? 4 * PER_WAVE : 0)>();
+    else if (keep == 3) wait_vmcnt<(D >= 4 ? 3 * PER_WAVE : 0)>();
+    else if (keep == 2) wait_vmcnt<(D >= 3 ? 2 * PER_WAVE : 0)>();
     else if (keep == 1) wait_vmcnt<(D >= 2 ? PER_WAVE : 0)>();
     else wait_vmcnt<0>();
   }
@@ -523,8 +644,13 @@ __device__ __forceinline__ void ppb_loop(StageBits* lds, const int8_t* __restric
 // gridDim.x equal runs, a workgroup walks its run and pays one epilogue per tile it touches (at most
 // ceil(run / nstages) + 1).  Every CU gets the same number of MFMAs whatever ntri is (55 tiles x split-K 4 leaves 36 of
 // 256 CUs idle in the lock-step launch).
+// The body is a device function wrapped by the kernel below it, which is held to 224 VGPRs per wave (the compiler takes all
+// 256 a 2-waves-per-SIMD kernel may have when left alone, and needs 196): two contraction waves then leave a SIMD 64 of its
+// 512 registers -- room for the waves of the persistent ring pre-pass (pack_kbits_ring_kernel), which shares the CU with
+// this kernel in the fp32 pipeline (profiles/r03s .. r03u_coreside.txt).
+#define PCOA_KBITS_CONTRACTION __device__ __forceinline__ void gram_kbits_body
 template <int NST, int LEFT, int ENC>
-__global__ __launch_bounds__(512, 2) void gram_kbits_kernel(const int8_t* __restrict__ p, int npad, int64_t nstages, int n,
+PCOA_KBITS_CONTRACTION(const int8_t* __restrict__ p, int npad, int64_t nstages, int n,
                                                             int ntile, int ntri, int splitk, int64_t stages_per,
                                                             int32_t* __restrict__ s32, int xcd_map,
                                                             const int32_t* __restrict__ skip, GramStrip strip) {
@@ -636,6 +762,22 @@ __global__ __launch_bounds__(512, 2) void gram_kbits_kernel(const int8_t* __rest
     // end with a barrier after the last reads; the epilogue touches no LDS)
   }
 }
+#undef PCOA_KBITS_CONTRACTION
+// amdgpu_num_vgpr counts halves of the unified register file on gfx90a+: 112 -> at most 224 registers per wave
+template <int NST, int LEFT, int ENC>
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(112))) void gram_kbits_kernel(
+    const int8_t* __restrict__ p, int npad, int64_t nstages, int n, int ntile, int ntri, int splitk, int64_t stages_per,
+    int32_t* __restrict__ s32, int xcd_map, const int32_t* __restrict__ skip, GramStrip strip) {
+  gram_kbits_body<NST, LEFT, ENC>(p, npad, nstages, n, ntile, ntri, splitk, stages_per, s32, xcd_map, skip, strip);
+}
+#ifdef PCOA_EXPERIMENTS
+template <int NST, int LEFT, int ENC>
+__global__ __launch_bounds__(512, 2) void gram_kbits_uncapped_kernel(
+    const int8_t* __restrict__ p, int npad, int64_t nstages, int n, int ntile, int ntri, int splitk, int64_t stages_per,
+    int32_t* __restrict__ s32, int xcd_map, const int32_t* __restrict__ skip, GramStrip strip) {
+  gram_kbits_body<NST, LEFT, ENC>(p, npad, nstages, n, ntile, ntri, splitk, stages_per, s32, xcd_map, skip, strip);
+}
+#endif
 
 #endif  // PCOA_KBITS_KERNELS
 
@@ -674,6 +816,44 @@ hipError_t launch_pack_kbits(const void* x, int is_u8, int64_t ld, int64_t nv, i
     if (vec) hipLaunchKernelGGL((pack_kbits_kernel<float, 4, true>), grid, block, 0, stream, xs, ld, nv, n, npad, nblk, pw, flag);
     else hipLaunchKernelGGL((pack_kbits_kernel<float, 1>), grid, block, 0, stream, xs, ld, nv, n, npad, nblk, pw, flag);
   }
+  return hipGetLastError();
+}
+
+// Persistent LDS-DMA-ring pre-pass (fp32 tile, pack_fp4_ring_ok(x, ld)): at most `wgs` workgroups of 4 waves.
+// ring = R + 100 * nontemporal + 1000 * (waves at s_setprio 3); the product uses 108 (R = 8 rows in flight per wave,
+// nontemporal loads), everything else is a harness knob.
+hipError_t launch_pack_kbits_ring(const float* x, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
+                                  hipStream_t stream, int64_t nblk_out, int wgs, int ring) {
+  if (nv <= 0) return hipSuccess;
+  if (!pack_fp4_ring_ok(x, ld) || nv > 0x3fffffffLL) return hipErrorInvalidValue;
+  const int npad = (int)gram_packed_npad(n);
+  const int64_t nblk = nblk_out > 0 ? nblk_out : (nv + 127) / 128;
+  const int64_t units = nblk * (npad >> 8);
+  if (units > 0x3fffffffLL) return hipErrorInvalidValue;  // 32-bit unit / row indices in the kernel
+  uint32_t* pw = reinterpret_cast<uint32_t*>(p);
+  const int64_t most = (units + 3) / 4;
+  const dim3 grid((unsigned)(wgs > 0 && wgs < most ? wgs : most)), block(256);
+#define PCOA_RINGK(R_, AUX_, PRIO_)                                                                                        \
+  hipLaunchKernelGGL((pack_kbits_ring_kernel<R_, AUX_, PRIO_>), grid, block, 4 * R_ * 1024, stream, x, ld, (int)nv, n, npad, \
+                     (int)units, pw, flag)
+#ifdef PCOA_EXPERIMENTS
+  const int R = ring % 100, nt = (ring / 100) % 10, prio = ring / 1000;
+#define PCOA_RINGK2(R_)                                                       \
+  do {                                                                        \
+    if (nt && prio) PCOA_RINGK(R_, 2, 3);                                     \
+    else if (nt) PCOA_RINGK(R_, 2, 0);                                        \
+    else if (prio) PCOA_RINGK(R_, 0, 3);                                      \
+    else PCOA_RINGK(R_, 0, 0);                                                \
+  } while (0)
+  if (R == 8) PCOA_RINGK2(8);
+  else if (R == 32) PCOA_RINGK2(32);
+  else PCOA_RINGK2(16);
+#undef PCOA_RINGK2
+#else
+  if (ring % 100 == 16) PCOA_RINGK(16, 2, 0);
+  else PCOA_RINGK(8, 2, 0);
+#endif
+#undef PCOA_RINGK
   return hipGetLastError();
 }
 
@@ -760,11 +940,19 @@ hipError_t launch_gram_kbits(const int8_t* p, int64_t nv, int32_t n, int32_t* s3
   hipLaunchKernelGGL((gram_kbits_kernel<NST_, LEFT_, ENC_>), grid, block, 0, stream, p, npad, nstages, n, ntile, ntri,      \
                      (int)splitk, stages_per, s32, xcd_map, skip, strip)
 #ifdef PCOA_EXPERIMENTS
+#define PCOA_LAUNCH_KBITS_UNCAPPED(NST_, LEFT_, ENC_)                                                                     \
+  hipLaunchKernelGGL((gram_kbits_uncapped_kernel<NST_, LEFT_, ENC_>), grid, block, 0, stream, p, npad, nstages, n, ntile,   \
+                     ntri, (int)splitk, stages_per, s32, xcd_map, skip, strip)
   switch (g_kbits_variant) {  // harness knob (tools/exp_bits.hip)
     case 1: PCOA_LAUNCH_KBITS(4, 2, 0); break;   // plain encoding (7 + 7 operations per word pair), whole expansion in the read phase
     case 2: PCOA_LAUNCH_KBITS(3, 2, 1); break;   // conjugate weights, whole expansion in the read phase
     case 3: PCOA_LAUNCH_KBITS(4, 2, 2); break;   // shipped schedule on a 4-stage ring
     case 4: PCOA_LAUNCH_KBITS(3, 0, 2); break;   // no MFMAs behind the phase barrier
+    case 5: PCOA_LAUNCH_KBITS(3, 2, 2); break;          // = default (kept for the r03s .. r03u harness numbering)
+    case 6: PCOA_LAUNCH_KBITS(4, 2, 2); break;          // 4-stage ring (3 stages in flight)
+    case 7: PCOA_LAUNCH_KBITS(6, 2, 2); break;          // 6-stage ring (5 stages = 40 KiB in flight per workgroup)
+    case 8: PCOA_LAUNCH_KBITS_UNCAPPED(6, 2, 2); break; // 6-stage ring, no register cap
+    case 9: PCOA_LAUNCH_KBITS_UNCAPPED(3, 2, 2); break; // shipped schedule, no register cap
     default: PCOA_LAUNCH_KBITS(3, 2, 2); break;
   }
 #else

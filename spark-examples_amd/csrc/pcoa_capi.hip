@@ -281,6 +281,9 @@ struct pcoa_ctx {
   hipEvent_t ev_fork = nullptr;
   bool lockstep_ok = false;          // the lock-step contraction launch fits this N on the whole chip
   int kbits_mode = 4;                // whole-chip launch form of the k-bits contraction: 4 even split, 2 lock-step, 0 split-K
+  bool coreside = false;             // fp32 pipeline, k-bits operand: ring pre-pass and whole-chip contraction share every CU
+  int coreside_mode = 4;             // launch form of that contraction: 2 lock-step where the shape fits, else 4 even split
+  int ring_wgs = 0;                  // workgroups of the ring pre-pass beside a contraction
   int64_t lockstep_launches = 0, pipeline_launches = 0, evensplit_launches = 0;
   int64_t pack_chunk = (int64_t)1 << 20;  // variants packed + contracted per launch pair
   int64_t pack_launches = 0;
@@ -490,7 +493,10 @@ int64_t kb_of(const pcoa_ctx* c, int64_t nv) {
 }
 // the three pre-passes onto the binary-tile operand, in the ctx's operand format
 hipError_t launch_pack_operand(const pcoa_ctx* c, const void* x, int is_u8, int64_t ld, int64_t nv, int8_t* dst, int32_t* flag,
-                               hipStream_t s, int64_t kb) {
+                               hipStream_t s, int64_t kb, int ring_wgs = 0) {
+  // ring_wgs > 0: the persistent ring pre-pass of the co-resident fp32 pipeline (fp32 tile, k-bits operand, ring_ok checked)
+  if (ring_wgs > 0 && c->op_fmt == 2 && !is_u8)
+    return launch_pack_kbits_ring(static_cast<const float*>(x), ld, nv, c->n, dst, flag, s, kb / 4, ring_wgs, 108);
   return c->op_fmt == 2 ? launch_pack_kbits(x, is_u8, ld, nv, c->n, dst, flag, s, kb / 4)
                         : launch_pack_fp4(x, is_u8, ld, nv, c->n, dst, flag, s, kb);
 }
@@ -577,6 +583,16 @@ int fp4_setup(pcoa_ctx* c) {
       c->pipe_gram_cus = half;
       if (c->op_fmt == 2 && k.kbits_pipe_wgs >= 8 && k.kbits_pipe_wgs <= c->num_cu) c->pipe_gram_cus = k.kbits_pipe_wgs / 8 * 8;
       c->fb_count = 2;
+      // k-bits operand: the two kernels SHARE every CU instead (r03s .. r03u): the contraction (224 VGPRs per wave, 24 KiB
+      // of LDS) takes the whole chip -- lock-step where the shape fits, so that the 36 CUs it leaves at N = 2504 run
+      // pre-pass waves only -- and two workgroups per CU of the persistent ring pre-pass (40 VGPRs, 32 KiB) land beside it.
+      // The head start still matters: the contraction's workgroups must find every CU able to take one.
+      if (c->op_fmt == 2 && k.kbits_coreside != 0) {
+        c->coreside = true;
+        c->coreside_mode = (ls > 0 && k.kbits_mode != 4) ? 2 : 4;
+        c->pipe_gram_cus = c->num_cu;
+        c->ring_wgs = (k.kbits_ring_wgs > 0) ? k.kbits_ring_wgs : 2 * c->num_cu;
+      }
     } else {
       (void)hipGetLastError();
       if (c->pack_stream) (void)hipStreamDestroy(c->pack_stream);
@@ -613,7 +629,7 @@ int fp4_launch(pcoa_ctx* c, int bi, bool overlapped) {
     hipError_t e = hipErrorInvalidValue;
     if (c->op_fmt == 2) {
       // k-bits: beside the pre-pass an even split over `pipe_gram_cus` workgroups, else the whole-chip form chosen in fp4_setup
-      const int mode = side ? 4 : c->kbits_mode;
+      const int mode = side ? (c->coreside ? c->coreside_mode : 4) : c->kbits_mode;
       e = launch_gram_kbits(b.p, b.kb * 32, c->n, c->s32, cus, gs, mode, skip, strip_of(c));
       if (e != hipSuccess && mode != 0) {
         (void)hipGetLastError();
@@ -896,7 +912,17 @@ int packed_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64
     if (autom && !can_defer) HIP_TRY(c, hipMemsetAsync(flag, 0, sizeof(int32_t), ps));
     {
       ScopedTimer t(c, T_PACK, ps);
-      hipError_t e = launch_pack_operand(c, x_chunk, is_u8, ld, cur, dst, flag, ps, kb);
+      // co-resident pipeline: the ring pre-pass for every fp32 tile that qualifies -- two workgroups per CU beside a
+      // contraction, one per CU with the chip to itself (as fast as pack_kbits_kernel there)
+      // (a ring wave wants several units of 128 variants x 256 samples to stream through: >= 4 per wave, else fewer
+      // workgroups; a tiny chunk takes the ordinary kernel)
+      int ring_wgs = 0;
+      if (c->coreside && deferrable_f32) {
+        const int64_t units = (kb / 4) * (gram_packed_npad(c->n) / 256);
+        const int64_t most = (ps == c->pack_stream) ? c->ring_wgs : c->num_cu;
+        if (units >= 64) ring_wgs = (int)std::max<int64_t>(1, std::min<int64_t>(most, units / 16));
+      }
+      hipError_t e = launch_pack_operand(c, x_chunk, is_u8, ld, cur, dst, flag, ps, kb, ring_wgs);
       if (e != hipSuccess) return hip_fail(c, e, "operand pre-pass launch");
     }
     c->pack_launches += 1;
@@ -1108,6 +1134,8 @@ const DebugKnobs& debug_knobs() {
     }
     if (const char* v = std::getenv("PCOA_KBITS_MODE")) k.kbits_mode = std::atoi(v);
     k.kbits_pipe_wgs = (int)num("PCOA_KBITS_PIPE_WGS");
+    if (const char* v = std::getenv("PCOA_KBITS_CORESIDE")) k.kbits_coreside = std::atoi(v) != 0;
+    k.kbits_ring_wgs = (int)num("PCOA_KBITS_RING_WGS");
     k.gram_cfg = (int)num("PCOA_GRAM_I8_CFG");
     k.gram_splitk = (int)num("PCOA_GRAM_I8_SPLITK");
     return k;
@@ -2030,8 +2058,9 @@ int pcoa_get_timings(pcoa_ctx* c, pcoa_timings* out) {
   {
     const int ls = c->pipe_ok ? gram_lockstep_splitk(c->n, c->pipe_gram_cus) : 0;
     int wgs = ls > 0 ? gram_lockstep_workgroups(c->n, ls) : 0;   // one workgroup per CU
-    if (c->pipe_ok && c->op_fmt == 2) wgs = c->pipe_gram_cus;         // even split: exactly that many workgroups
-    out->pipeline_pre_pass_cus = c->pipe_ok ? c->num_cu - wgs : 0;
+    if (c->pipe_ok && c->op_fmt == 2 && !(c->coreside && c->coreside_mode == 2)) wgs = c->pipe_gram_cus;  // even split: exactly that many workgroups
+    // co-resident form: the ring pre-pass has waves on EVERY CU, the contraction's workgroups share theirs with it
+    out->pipeline_pre_pass_cus = c->pipe_ok ? (c->coreside ? c->num_cu : c->num_cu - wgs) : 0;
     out->pipeline_contraction_cus = wgs;
   }
   out->pack_seconds = c->tsec[T_PACK];

@@ -35,6 +35,8 @@ struct DebugKnobs {
   int operand = 0;                 // PCOA_OPERAND = fp4 | bits -> 1 | 2: operand of the binary-tile contraction (0 = default)
   int kbits_mode = -1;             // PCOA_KBITS_MODE = 0 | 2 | 4: launch form of the k-bits contraction (whole chip)
   int kbits_pipe_wgs = 0;          // PCOA_KBITS_PIPE_WGS: workgroups of the k-bits contraction beside the fp32 pre-pass
+  int kbits_coreside = -1;         // PCOA_KBITS_CORESIDE = 0 | 1: fp32 pipeline with pre-pass and contraction on the SAME CUs (ring pre-pass)
+  int kbits_ring_wgs = 0;          // PCOA_KBITS_RING_WGS: workgroups of the ring pre-pass beside a contraction (default 2 per CU)
 };
 const DebugKnobs& debug_knobs();
 
@@ -82,6 +84,10 @@ hipError_t launch_transpose_bits_kbits(const uint32_t* bits, int64_t ld_words, i
 hipError_t launch_densify_csr_kbits(const int32_t* idx_dev, const int64_t* offs_dev, int64_t nv, int64_t offs_base,
                                     int8_t* p, int32_t n, int32_t* flag, hipStream_t stream, int64_t nblk_out);
 bool pack_fp4_ring_ok(const void* x, int64_t ld);
+// persistent LDS-DMA-ring form of the fp32 -> k-bits pre-pass (needs pack_fp4_ring_ok): <= wgs workgroups; ring: 108 = 8 rows
+// in flight per wave, nontemporal (default), 116 = 16 rows
+hipError_t launch_pack_kbits_ring(const float* x, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
+                                  hipStream_t stream, int64_t nblk_out, int wgs, int ring);
 hipError_t launch_pack_fp4_ring(const float* x, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
                                 hipStream_t stream, int64_t nkb_out, int wgs, int nt);
 // Strip owner (SURVEY 8e, N beyond one HBM): the launch computes S[:, col0 .. col0 + cols) -- every row block against the

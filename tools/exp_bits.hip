@@ -241,13 +241,305 @@ static int small_case(int n, int64_t v, int64_t ld, uint32_t thr, int num_cu, un
   return bad;
 }
 
+// ---- --pipe-study (r03r): what bounds the pipelined fp32 step? ------------------------------------------------------------
+//  * even split with 96 .. 160 contraction workgroups beside the pre-pass, with the duration of either kernel inside the pipeline;
+//  * the same with the contraction reading an ALIASED operand: the virtual range of a whole operand buffer backed by one 2-MiB
+//    physical chunk mapped over and over (hipMemMap), so that the contraction's operand stream hits in the L2s and costs no
+//    fabric / HBM traffic (S is garbage, the time is what is asked for): the upper bound of what sharing operand rows between
+//    workgroups could give.
+static int pipe_study_main(int n, int64_t v, int reps, int num_cu) {
+  const int npad = (int)gram_packed_npad(n);
+  const int64_t ld = n;
+  const int64_t nblk = gram_kb_pad(v, 2) / 4;
+  const size_t kbytes = (size_t)nblk * npad * 16;
+  float* x;
+  int8_t* k1[2];
+  int32_t *sb, *flag;
+  CK(hipMalloc(&x, (size_t)(v * ld * 4)));
+  for (int b = 0; b < 2; ++b) CK(hipMalloc(&k1[b], kbytes));
+  CK(hipMalloc(&sb, (size_t)n * n * 4));
+  CK(hipMalloc(&flag, 64));
+  CK(hipMemset(flag, 0, 64));
+  hipLaunchKernelGGL(fill_kernel, dim3(8192), dim3(256), 0, 0, x, v, (int64_t)n, ld, 777u, 0x18000000u);
+  CK(launch_pack_kbits(x, 0, ld, v, n, k1[0], flag, 0, nblk));
+  CK(launch_pack_kbits(x, 0, ld, v, n, k1[1], flag, 0, nblk));
+  CK(hipDeviceSynchronize());
+  // the aliased operand
+  int8_t* ka = nullptr;
+  {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    const size_t chunk = (size_t)2 << 20;
+    const size_t total = (kbytes + chunk - 1) / chunk * chunk;
+    void* va = nullptr;
+    CK(hipMemAddressReserve(&va, total, chunk, nullptr, 0));
+    hipMemGenericAllocationHandle_t h;
+    CK(hipMemCreate(&h, chunk, &prop, 0));
+    for (size_t off = 0; off < total; off += chunk) CK(hipMemMap((char*)va + off, chunk, 0, h, 0));
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    CK(hipMemSetAccess(va, total, &acc, 1));
+    ka = (int8_t*)va;
+    CK(hipMemcpy(ka, k1[0], chunk, hipMemcpyDeviceToDevice));
+    std::printf("aliased operand: %zu MiB of virtual range on one 2-MiB chunk\n", total >> 20);
+  }
+  const double mv = (double)v / 1e6;
+  auto line = [&](const char* what, float ms) { std::printf("time  %-66s %8.3f ms  (%.3f ms per 10^6 variants)\n", what, ms, ms / mv); };
+  line("pack_kbits<float> alone", time_ms(0, reps, [&] { CK(launch_pack_kbits(x, 0, ld, v, n, k1[0], flag, 0, nblk)); }));
+  for (int cus : {256, 128}) {
+    std::string t = " [" + std::to_string(cus) + " workgroups]";
+    line(("contraction even split, real operand" + t).c_str(), time_ms(0, reps, [&] { CK(launch_gram_kbits(k1[0], v, n, sb, cus, 0, 4)); }));
+    line(("contraction even split, ALIASED operand" + t).c_str(), time_ms(0, reps, [&] { CK(launch_gram_kbits(ka, v, n, sb, cus, 0, 4)); }));
+  }
+  line("contraction lock-step, real operand [whole chip]", time_ms(0, reps, [&] { CK(launch_gram_kbits(k1[0], v, n, sb, num_cu, 0, 2)); }));
+  line("contraction lock-step, ALIASED operand [whole chip]", time_ms(0, reps, [&] { CK(launch_gram_kbits(ka, v, n, sb, num_cu, 0, 2)); }));
+
+  hipStream_t ps, gs;
+  CK(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+  CK(hipStreamCreateWithFlags(&gs, hipStreamNonBlocking));
+  const int K = 12;
+  hipEvent_t packed[2], consumed[2], pe[K][2], ge[K][2];
+  for (int b = 0; b < 2; ++b) {
+    CK(hipEventCreateWithFlags(&packed[b], hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&consumed[b], hipEventDisableTiming));
+  }
+  for (int k = 0; k < K; ++k)
+    for (int j = 0; j < 2; ++j) { CK(hipEventCreate(&pe[k][j])); CK(hipEventCreate(&ge[k][j])); }
+  auto pipeline = [&](const char* what, int gram_mode, int gram_cus, int delay_us, bool aliased) {
+    double best = 1e30, bp = 0, bg = 0;
+    for (int round = 0; round < 3; ++round) {
+      CK(hipDeviceSynchronize());
+      const double t0 = now_ms();
+      for (int k = 0; k < K; ++k) {
+        const int b = k & 1;
+        if (k >= 2) CK(hipStreamWaitEvent(ps, consumed[b], 0));
+        if (k >= 1 && delay_us > 0) hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, ps, (long long)delay_us * 100);
+        CK(hipEventRecord(pe[k][0], ps));
+        CK(launch_pack_kbits(x, 0, ld, v, n, k1[b], flag, ps, nblk));
+        CK(hipEventRecord(pe[k][1], ps));
+        CK(hipEventRecord(packed[b], ps));
+        CK(hipStreamWaitEvent(gs, packed[b], 0));
+        CK(hipEventRecord(ge[k][0], gs));
+        CK(launch_gram_kbits(aliased ? ka : k1[b], v, n, sb, gram_cus, gs, gram_mode));
+        CK(hipEventRecord(ge[k][1], gs));
+        CK(hipEventRecord(consumed[b], gs));
+      }
+      CK(hipDeviceSynchronize());
+      const double t = (now_ms() - t0) / K;
+      double sp = 0, sg = 0;
+      for (int k = 2; k < K - 1; ++k) {  // steady state
+        float a = 0, c = 0;
+        CK(hipEventElapsedTime(&a, pe[k][0], pe[k][1]));
+        CK(hipEventElapsedTime(&c, ge[k][0], ge[k][1]));
+        sp += a; sg += c;
+      }
+      if (t < best) { best = t; bp = sp / (K - 3); bg = sg / (K - 3); }
+    }
+    std::printf("pipe  %-58s %8.3f ms per step (%.0f M variants/s); inside: pre-pass %.3f ms, contraction %.3f ms\n", what, best,
+                v / best / 1e3, bp, bg);
+  };
+  for (int cus : {96, 104, 112, 120, 128, 136, 144, 160}) {
+    std::string t = "even split, " + std::to_string(cus) + " workgroups";
+    pipeline(t.c_str(), 4, cus, 10, false);
+  }
+  for (int cus : {112, 128, 144}) {
+    std::string t = "even split, " + std::to_string(cus) + " workgroups, ALIASED operand";
+    pipeline(t.c_str(), 4, cus, 10, true);
+  }
+  pipeline("lock-step on half the chip (110)", 2, num_cu / 2, 10, false);
+  pipeline("lock-step on half the chip (110), ALIASED operand", 2, num_cu / 2, 10, true);
+  pipeline("even split 128, head start 20 us", 4, 128, 20, false);
+  pipeline("even split 128, head start 5 us", 4, 128, 5, false);
+  return 0;
+}
+
+// ---- --coreside (r03s): pre-pass and contraction on the SAME CUs ----------------------------------------------------------------
+// The contraction held to 224 VGPRs per wave (gram_kbits_capped_kernel) leaves every SIMD 64 registers: room for one wave of the
+// persistent LDS-DMA-ring pre-pass (pack_kbits_ring_kernel, <= 64 VGPRs, 64 KiB of LDS).  Contraction first (one workgroup per
+// CU, even split over the whole chip), then one ring workgroup lands on every CU beside it.
+static int coreside_main(int n, int64_t v, int reps, int num_cu, unsigned long long* cnt) {
+  const int npad = (int)gram_packed_npad(n);
+  const int64_t ld = n;
+  const int64_t nblk = gram_kb_pad(v, 2) / 4;
+  const size_t kbytes = (size_t)nblk * npad * 16;
+  float* x;
+  int8_t* k1[2];
+  int32_t *sa, *sb, *flag;
+  CK(hipMalloc(&x, (size_t)(v * ld * 4)));
+  for (int b = 0; b < 2; ++b) CK(hipMalloc(&k1[b], kbytes));
+  CK(hipMalloc(&sa, (size_t)n * n * 4));
+  CK(hipMalloc(&sb, (size_t)n * n * 4));
+  CK(hipMalloc(&flag, 64));
+  CK(hipMemset(flag, 0, 64));
+  hipLaunchKernelGGL(fill_kernel, dim3(8192), dim3(256), 0, 0, x, v, (int64_t)n, ld, 777u, 0x18000000u);
+  CK(launch_pack_kbits(x, 0, ld, v, n, k1[0], flag, 0, nblk));
+  CK(hipDeviceSynchronize());
+  int bad = 0;
+  for (int ring : {16, 116, 32, 8, 1108, 1016}) {
+    CK(hipMemset(k1[1], 0xa5, kbytes));
+    CK(launch_pack_kbits_ring(x, ld, v, n, k1[1], flag, 0, nblk, num_cu, ring));
+    CK(hipDeviceSynchronize());
+    const unsigned long long d = count_diff(k1[0], k1[1], (int64_t)kbytes, cnt);
+    std::printf("ring pre-pass (ring %d) operand vs pack_kbits operand: %s (%llu words differ)\n", ring, d ? "MISMATCH" : "identical", d);
+    bad += d != 0;
+  }
+  {  // ragged small shape through the ring kernel
+    const int n2 = 1000;
+    const int64_t v2 = 4100, ld2 = 1000;
+    const int npad2 = (int)gram_packed_npad(n2);
+    const int64_t nblk2 = gram_kb_pad(v2, 2) / 4;
+    float* x2;
+    int8_t *ka, *kb;
+    CK(hipMalloc(&x2, (size_t)(v2 * ld2 * 4)));
+    CK(hipMalloc(&ka, (size_t)nblk2 * npad2 * 16));
+    CK(hipMalloc(&kb, (size_t)nblk2 * npad2 * 16));
+    hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, x2, v2, (int64_t)n2, ld2, 99u, 0x30000000u);
+    CK(launch_pack_kbits(x2, 0, ld2, v2, n2, ka, flag, 0, nblk2));
+    CK(hipMemset(kb, 0x5a, (size_t)nblk2 * npad2 * 16));
+    CK(launch_pack_kbits_ring(x2, ld2, v2, n2, kb, flag, 0, nblk2, 7, 16));
+    CK(hipDeviceSynchronize());
+    const unsigned long long d = count_diff(ka, kb, nblk2 * npad2 * 16, cnt);
+    std::printf("ring pre-pass, n=1000 v=4100, 7 workgroups: %s (%llu words differ)\n", d ? "MISMATCH" : "identical", d);
+    bad += d != 0;
+    CK(hipFree(x2)); CK(hipFree(ka)); CK(hipFree(kb));
+  }
+  CK(launch_pack_kbits(x, 0, ld, v, n, k1[1], flag, 0, nblk));
+  g_kbits_variant = 0;
+  CK(hipMemset(sa, 0, (size_t)n * n * 4));
+  CK(launch_gram_kbits(k1[0], v, n, sa, num_cu, 0, 4));
+  const char* vname[9] = {"shipped (256 VGPRs, ring 3)", "", "", "ring 4", "", "capped 224, ring 3", "capped 224, ring 4", "capped 224, ring 6", "ring 6"};
+  for (int var : {5, 6, 7, 8}) {
+    g_kbits_variant = var;
+    CK(hipMemset(sb, 0, (size_t)n * n * 4));
+    CK(launch_gram_kbits(k1[0], v, n, sb, num_cu, 0, 4));
+    CK(hipDeviceSynchronize());
+    const unsigned long long d = count_diff(sa, sb, (int64_t)n * n * 4, cnt);
+    std::printf("S(%s) vs S(shipped): %s (%llu entries differ)\n", vname[var], d ? "MISMATCH" : "bit-identical", d);
+    bad += d != 0;
+  }
+  g_kbits_variant = 0;
+  const double mv = (double)v / 1e6;
+  auto line = [&](const char* what, float ms) { std::printf("time  %-66s %8.3f ms  (%.3f ms per 10^6 variants)\n", what, ms, ms / mv); };
+  line("pack_kbits<float> (shipped) alone", time_ms(0, reps, [&] { CK(launch_pack_kbits(x, 0, ld, v, n, k1[1], flag, 0, nblk)); }));
+  for (int ring : {16, 116, 1116, 108})
+    line(("ring pre-pass alone, 256 workgroups, ring " + std::to_string(ring)).c_str(),
+         time_ms(0, reps, [&] { CK(launch_pack_kbits_ring(x, ld, v, n, k1[1], flag, 0, nblk, num_cu, ring)); }));
+  line("ring pre-pass alone, 512 workgroups, ring 108", time_ms(0, reps, [&] { CK(launch_pack_kbits_ring(x, ld, v, n, k1[1], flag, 0, nblk, 2 * num_cu, 108)); }));
+  line("ring pre-pass alone, 512 workgroups, ring 116", time_ms(0, reps, [&] { CK(launch_pack_kbits_ring(x, ld, v, n, k1[1], flag, 0, nblk, 2 * num_cu, 116)); }));
+  for (int var : {0, 3, 5, 6, 7, 8}) {
+    g_kbits_variant = var;
+    line((std::string("contraction alone, even split 256: ") + vname[var]).c_str(), time_ms(0, reps, [&] { CK(launch_gram_kbits(k1[0], v, n, sb, num_cu, 0, 4)); }));
+  }
+  g_kbits_variant = 0;
+
+  hipStream_t ps, gs;
+  CK(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+  CK(hipStreamCreateWithFlags(&gs, hipStreamNonBlocking));
+  const int K = 12;
+  hipEvent_t packed[2], consumed[2], pe[K][2], ge[K][2];
+  for (int b = 0; b < 2; ++b) {
+    CK(hipEventCreateWithFlags(&packed[b], hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&consumed[b], hipEventDisableTiming));
+  }
+  for (int k = 0; k < K; ++k)
+    for (int j = 0; j < 2; ++j) { CK(hipEventCreate(&pe[k][j])); CK(hipEventCreate(&ge[k][j])); }
+  // ring < 0: the shipped pre-pass; gram_cus workgroups of contraction variant `var`
+  int8_t* ka = nullptr;
+  {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    const size_t chunk = (size_t)2 << 20;
+    const size_t total = (kbytes + chunk - 1) / chunk * chunk;
+    void* va = nullptr;
+    CK(hipMemAddressReserve(&va, total, chunk, nullptr, 0));
+    hipMemGenericAllocationHandle_t h;
+    CK(hipMemCreate(&h, chunk, &prop, 0));
+    for (size_t off = 0; off < total; off += chunk) CK(hipMemMap((char*)va + off, chunk, 0, h, 0));
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    CK(hipMemSetAccess(va, total, &acc, 1));
+    ka = (int8_t*)va;
+    CK(hipMemcpy(ka, k1[0], chunk, hipMemcpyDeviceToDevice));
+  }
+  int gram_mode = 4;
+  bool aliased = false;
+  auto pipeline = [&](const char* what, int var, int gram_cus, int ring, int ring_wgs, int delay_us) {
+    double best = 1e30, bp = 0, bg = 0;
+    for (int round = 0; round < 3; ++round) {
+      CK(hipDeviceSynchronize());
+      const double t0 = now_ms();
+      for (int k = 0; k < K; ++k) {
+        const int b = k & 1;
+        if (k >= 2) CK(hipStreamWaitEvent(ps, consumed[b], 0));
+        if (k >= 1 && delay_us > 0) hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, ps, (long long)delay_us * 100);
+        CK(hipEventRecord(pe[k][0], ps));
+        if (ring < 0) CK(launch_pack_kbits(x, 0, ld, v, n, k1[b], flag, ps, nblk));
+        else CK(launch_pack_kbits_ring(x, ld, v, n, k1[b], flag, ps, nblk, ring_wgs, ring));
+        CK(hipEventRecord(pe[k][1], ps));
+        CK(hipEventRecord(packed[b], ps));
+        CK(hipStreamWaitEvent(gs, packed[b], 0));
+        CK(hipEventRecord(ge[k][0], gs));
+        g_kbits_variant = var;
+        CK(launch_gram_kbits(aliased ? ka : k1[b], v, n, sb, gram_cus, gs, gram_mode));
+        g_kbits_variant = 0;
+        CK(hipEventRecord(ge[k][1], gs));
+        CK(hipEventRecord(consumed[b], gs));
+      }
+      CK(hipDeviceSynchronize());
+      const double t = (now_ms() - t0) / K;
+      double sp = 0, sg = 0;
+      for (int k = 2; k < K - 1; ++k) {
+        float a = 0, c = 0;
+        CK(hipEventElapsedTime(&a, pe[k][0], pe[k][1]));
+        CK(hipEventElapsedTime(&c, ge[k][0], ge[k][1]));
+        sp += a; sg += c;
+      }
+      if (t < best) { best = t; bp = sp / (K - 3); bg = sg / (K - 3); }
+    }
+    std::printf("pipe  %-74s %8.3f ms per step (%.0f M variants/s); inside: pre-pass %.3f ms, contraction %.3f ms\n", what, best,
+                v / best / 1e3, bp, bg);
+  };
+  pipeline("shipped: pack_kbits || even split 128 (disjoint CUs)", 0, 128, -1, 0, 10);
+  struct Cfg { const char* what; int var, mode, cus, ring, wgs; };
+  const Cfg cfgs[] = {
+      {"CO-RESIDENT: ring R16 nt || even split 256, capped ring 4", 6, 4, 256, 116, 256},
+      {"CO-RESIDENT: ring R16 nt || lock-step 220, capped ring 3", 5, 2, 256, 116, 256},
+      {"CO-RESIDENT: ring R16 nt prio3 || even split 256, capped ring 4", 6, 4, 256, 1116, 256},
+      {"CO-RESIDENT: ring R16 nt prio3 || lock-step 220, capped ring 3", 5, 2, 256, 1116, 256},
+      {"CO-RESIDENT: ring R16 nt prio3 || lock-step 220, capped ring 4", 6, 2, 256, 1116, 256},
+      {"CO-RESIDENT: ring R8 nt, 512 wgs (2 per CU) || even split 256, capped ring 4", 6, 4, 256, 108, 512},
+      {"CO-RESIDENT: ring R8 nt, 512 wgs || lock-step 220, capped ring 3", 5, 2, 256, 108, 512},
+      {"CO-RESIDENT: ring R8 nt prio3, 512 wgs || lock-step 220, capped ring 3", 5, 2, 256, 1108, 512},
+      {"CO-RESIDENT: ring R16 nt, 512 wgs || lock-step 220, capped ring 3", 5, 2, 256, 116, 512},
+      {"CO-RESIDENT: ring R16 nt prio3, 512 wgs || lock-step 220, capped ring 3", 5, 2, 256, 1116, 512},
+      {"CO-RESIDENT: ring R8 nt, 768 wgs || lock-step 220, capped ring 3", 5, 2, 256, 108, 768},
+      {"CO-RESIDENT: ring R16 (default policy) prio3 || lock-step 220, capped ring 3", 5, 2, 256, 1016, 256},
+  };
+  for (const Cfg& c : cfgs) {
+    gram_mode = c.mode;
+    pipeline(c.what, c.var, c.cus, c.ring, c.wgs, 10);
+  }
+  gram_mode = 4;
+  std::printf("%s\n", bad ? "RESULT: FAILED" : "RESULT: ok");
+  return bad ? 1 : 0;
+}
+
 int main(int argc, char** argv) {
   int n = 2504, reps = 5;
+  bool pipe_study = false, coreside = false;
   int64_t v = (int64_t)1 << 20;
   for (int i = 1; i < argc; ++i) {
     if (!std::strcmp(argv[i], "--n") && i + 1 < argc) n = std::atoi(argv[++i]);
     if (!std::strcmp(argv[i], "--v") && i + 1 < argc) v = std::atoll(argv[++i]);
     if (!std::strcmp(argv[i], "--reps") && i + 1 < argc) reps = std::atoi(argv[++i]);
+    if (!std::strcmp(argv[i], "--pipe-study")) pipe_study = true;
+    if (!std::strcmp(argv[i], "--coreside")) coreside = true;
   }
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
@@ -256,6 +548,8 @@ int main(int argc, char** argv) {
   unsigned long long* cnt;
   CK(hipMalloc(&cnt, 8));
 
+  if (pipe_study) return pipe_study_main(n, v, reps, num_cu);
+  if (coreside) return coreside_main(n, v, reps, num_cu, cnt);
   int bad = 0;
   bad += small_case(1000, 777, 1003, 0x30000000u, num_cu, cnt);   // odd stride: generic paths
   bad += small_case(1000, 4100, 1000, 0x08000000u, num_cu, cnt);  // vector paths, several blocks
