@@ -113,6 +113,8 @@ __global__ __launch_bounds__(256) void pack_kbits_kernel(const T* __restrict__ x
 // HBM -> LDS by global_load_lds_dwordx4 into the wave's private ring of R one-row slots; per row the wave reads its 16 B
 // back (ds_read_b128), converts 4 values (bit 23 of the fp32 pattern is set for 1.0f and clear for 0.0f; fma(f, f, -f) is
 // +0 exactly for f in {0, -0, 1}) and re-issues the slot R rows ahead.
+// (Tried, r03w: 12 instead of 16 conversion operations per row -- v_perm_b32 byte gathers into a permuted bit order, packed
+// fma, v_or3 -- changed nothing beside the contraction, 2.07 vs 2.06 ms per step, and cost 16 registers: not kept.)
 template <int R, int AUX, int C>
 __device__ __forceinline__ void ring_rows_kbits(const char* xb, int64_t ldb, int nv, int blk, uint32_t voff, int blkn,
                                                 uint32_t voffn, uint8_t* myring, int lane, f32x4_t& a, uint32_t (&w)[4][4],
@@ -120,13 +122,14 @@ __device__ __forceinline__ void ring_rows_kbits(const char* xb, int64_t ldb, int
   auto issue = [&](int bq, uint32_t vo, int r, int slot) {
     int row = bq * 128 + r;
     row = row < nv ? row : nv - 1;
-    const char* src = xb + (int64_t)row * ldb + vo;
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(myring + slot * 1024), 16, 0, AUX);
+    // the row address is wave-uniform: pinned into SGPRs so that the per-lane address is one 64-bit add (left alone the
+    // compiler hoists xb + vo into a per-lane base and pays a v_mad_u64_u32 + 2 more VALU operations per row)
+    const char* rowp = xb + (int64_t)row * ldb;
+    asm volatile("" : "+s"(rowp));
+    __builtin_amdgcn_global_load_lds((gptr_t)(rowp + vo), (lptr_t)(myring + slot * 1024), 16, 0, AUX);
   };
 #pragma unroll
   for (int t = 0; t < 32; ++t) {
-    constexpr int dummy = 0;
-    (void)dummy;
     const int r = C * 32 + t;  // row of the unit
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): row r is in `a`, its slot is free
     __builtin_amdgcn_sched_barrier(0);
@@ -136,13 +139,14 @@ __device__ __forceinline__ void ring_rows_kbits(const char* xb, int64_t ldb, int
     __builtin_amdgcn_sched_barrier(0);
     const f32x4_t b = *reinterpret_cast<const f32x4_t*>(myring + ((t + 1) % R) * 1024 + lane * 16);
     __builtin_amdgcn_sched_barrier(0);
-    if (blk * 128 + r < nv) {  // wave-uniform
+    if (blk * 128 + r < nv) {  // wave-uniform: rows beyond the tile re-read its last row and are skipped
 #pragma unroll
       for (int s2 = 0; s2 < 4; ++s2) {
         const float f = a[s2];
         bad4[s2] |= __float_as_uint(__builtin_fmaf(f, f, -f));
         w[s2][C] |= ((__float_as_uint(f) >> 23) & 1u) << t;
       }
+      // pin the conversion here (see ring_unit of gram_packed.hip)
 #pragma unroll
       for (int s2 = 0; s2 < 4; ++s2) asm volatile("" : "+v"(w[s2][C]), "+v"(bad4[s2]));
     }
@@ -836,6 +840,7 @@ hipError_t launch_pack_kbits_ring(const float* x, int64_t ld, int64_t nv, int32_
 #define PCOA_RINGK(R_, AUX_, PRIO_)                                                                                        \
   hipLaunchKernelGGL((pack_kbits_ring_kernel<R_, AUX_, PRIO_>), grid, block, 4 * R_ * 1024, stream, x, ld, (int)nv, n, npad, \
                      (int)units, pw, flag)
+  ring %= 10000;  // (+ 10000 selected the natural bit order while a permuted form existed, r03w)
 #ifdef PCOA_EXPERIMENTS
   const int R = ring % 100, nt = (ring / 100) % 10, prio = ring / 1000;
 #define PCOA_RINGK2(R_)                                                       \

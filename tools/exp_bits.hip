@@ -378,7 +378,7 @@ static int coreside_main(int n, int64_t v, int reps, int num_cu, unsigned long l
   CK(launch_pack_kbits(x, 0, ld, v, n, k1[0], flag, 0, nblk));
   CK(hipDeviceSynchronize());
   int bad = 0;
-  for (int ring : {16, 116, 32, 8, 1108, 1016}) {
+  for (int ring : {108, 116, 8, 16, 1108}) {
     CK(hipMemset(k1[1], 0xa5, kbytes));
     CK(launch_pack_kbits_ring(x, ld, v, n, k1[1], flag, 0, nblk, num_cu, ring));
     CK(hipDeviceSynchronize());
@@ -399,17 +399,26 @@ static int coreside_main(int n, int64_t v, int reps, int num_cu, unsigned long l
     hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, x2, v2, (int64_t)n2, ld2, 99u, 0x30000000u);
     CK(launch_pack_kbits(x2, 0, ld2, v2, n2, ka, flag, 0, nblk2));
     CK(hipMemset(kb, 0x5a, (size_t)nblk2 * npad2 * 16));
-    CK(launch_pack_kbits_ring(x2, ld2, v2, n2, kb, flag, 0, nblk2, 7, 16));
+    CK(launch_pack_kbits_ring(x2, ld2, v2, n2, kb, flag, 0, nblk2, 7, 108));
     CK(hipDeviceSynchronize());
     const unsigned long long d = count_diff(ka, kb, nblk2 * npad2 * 16, cnt);
     std::printf("ring pre-pass, n=1000 v=4100, 7 workgroups: %s (%llu words differ)\n", d ? "MISMATCH" : "identical", d);
     bad += d != 0;
     CK(hipFree(x2)); CK(hipFree(ka)); CK(hipFree(kb));
   }
-  CK(launch_pack_kbits(x, 0, ld, v, n, k1[1], flag, 0, nblk));
   g_kbits_variant = 0;
   CK(hipMemset(sa, 0, (size_t)n * n * 4));
   CK(launch_gram_kbits(k1[0], v, n, sa, num_cu, 0, 4));
+  {
+    CK(launch_pack_kbits_ring(x, ld, v, n, k1[1], flag, 0, nblk, 2 * num_cu, 108));
+    CK(hipMemset(sb, 0, (size_t)n * n * 4));
+    CK(launch_gram_kbits(k1[1], v, n, sb, num_cu, 0, 2));
+    CK(hipDeviceSynchronize());
+    const unsigned long long d = count_diff(sa, sb, (int64_t)n * n * 4, cnt);
+    std::printf("S(ring pre-pass operand, lock-step) vs S(pack_kbits operand, even split): %s (%llu entries differ)\n", d ? "MISMATCH" : "bit-identical", d);
+    bad += d != 0;
+  }
+  CK(launch_pack_kbits(x, 0, ld, v, n, k1[1], flag, 0, nblk));
   const char* vname[9] = {"shipped (256 VGPRs, ring 3)", "", "", "ring 4", "", "capped 224, ring 3", "capped 224, ring 4", "capped 224, ring 6", "ring 6"};
   for (int var : {5, 6, 7, 8}) {
     g_kbits_variant = var;
@@ -424,7 +433,7 @@ static int coreside_main(int n, int64_t v, int reps, int num_cu, unsigned long l
   const double mv = (double)v / 1e6;
   auto line = [&](const char* what, float ms) { std::printf("time  %-66s %8.3f ms  (%.3f ms per 10^6 variants)\n", what, ms, ms / mv); };
   line("pack_kbits<float> (shipped) alone", time_ms(0, reps, [&] { CK(launch_pack_kbits(x, 0, ld, v, n, k1[1], flag, 0, nblk)); }));
-  for (int ring : {16, 116, 1116, 108})
+  for (int ring : {108, 8, 116, 16})
     line(("ring pre-pass alone, 256 workgroups, ring " + std::to_string(ring)).c_str(),
          time_ms(0, reps, [&] { CK(launch_pack_kbits_ring(x, ld, v, n, k1[1], flag, 0, nblk, num_cu, ring)); }));
   line("ring pre-pass alone, 512 workgroups, ring 108", time_ms(0, reps, [&] { CK(launch_pack_kbits_ring(x, ld, v, n, k1[1], flag, 0, nblk, 2 * num_cu, 108)); }));
@@ -508,18 +517,15 @@ static int coreside_main(int n, int64_t v, int reps, int num_cu, unsigned long l
   pipeline("shipped: pack_kbits || even split 128 (disjoint CUs)", 0, 128, -1, 0, 10);
   struct Cfg { const char* what; int var, mode, cus, ring, wgs; };
   const Cfg cfgs[] = {
-      {"CO-RESIDENT: ring R16 nt || even split 256, capped ring 4", 6, 4, 256, 116, 256},
-      {"CO-RESIDENT: ring R16 nt || lock-step 220, capped ring 3", 5, 2, 256, 116, 256},
-      {"CO-RESIDENT: ring R16 nt prio3 || even split 256, capped ring 4", 6, 4, 256, 1116, 256},
-      {"CO-RESIDENT: ring R16 nt prio3 || lock-step 220, capped ring 3", 5, 2, 256, 1116, 256},
-      {"CO-RESIDENT: ring R16 nt prio3 || lock-step 220, capped ring 4", 6, 2, 256, 1116, 256},
-      {"CO-RESIDENT: ring R8 nt, 512 wgs (2 per CU) || even split 256, capped ring 4", 6, 4, 256, 108, 512},
-      {"CO-RESIDENT: ring R8 nt, 512 wgs || lock-step 220, capped ring 3", 5, 2, 256, 108, 512},
-      {"CO-RESIDENT: ring R8 nt prio3, 512 wgs || lock-step 220, capped ring 3", 5, 2, 256, 1108, 512},
-      {"CO-RESIDENT: ring R16 nt, 512 wgs || lock-step 220, capped ring 3", 5, 2, 256, 116, 512},
-      {"CO-RESIDENT: ring R16 nt prio3, 512 wgs || lock-step 220, capped ring 3", 5, 2, 256, 1116, 512},
-      {"CO-RESIDENT: ring R8 nt, 768 wgs || lock-step 220, capped ring 3", 5, 2, 256, 108, 768},
-      {"CO-RESIDENT: ring R16 (default policy) prio3 || lock-step 220, capped ring 3", 5, 2, 256, 1016, 256},
+      {"CO-RESIDENT: ring R8 nt natural, 512 wgs || lock-step 220, contraction ring 3", 5, 2, 256, 10108, 512},
+      {"CO-RESIDENT: ring R8 nt natural, 512 wgs || lock-step 220, contraction ring 4", 6, 2, 256, 10108, 512},
+      {"CO-RESIDENT: ring R8 nt natural, 512 wgs || lock-step 220, contraction ring 6", 7, 2, 256, 10108, 512},
+      {"CO-RESIDENT: ring R8 nt natural, 512 wgs || even split 256, contraction ring 4", 6, 4, 256, 10108, 512},
+      {"CO-RESIDENT: ring R8 nt natural, 512 wgs || even split 256, contraction ring 6", 7, 4, 256, 10108, 512},
+      {"CO-RESIDENT: ring R8 nt natural, 768 wgs || lock-step 220, contraction ring 4", 6, 2, 256, 10108, 768},
+      {"CO-RESIDENT: ring R8 nt natural, 512 wgs || lock-step 220, contraction ring 3 (again)", 5, 2, 256, 10108, 512},
+      {"CO-RESIDENT: ring R8 nt natural, 512 wgs || lock-step 220, contraction ring 4 (again)", 6, 2, 256, 10108, 512},
+      {"CO-RESIDENT: ring R8 nt natural, 512 wgs || lock-step 220, contraction ring 6 (again)", 7, 2, 256, 10108, 512},
   };
   for (const Cfg& c : cfgs) {
     gram_mode = c.mode;
