@@ -589,7 +589,10 @@ int fp4_setup(pcoa_ctx* c) {
       // The head start still matters: the contraction's workgroups must find every CU able to take one.
       if (c->op_fmt == 2 && k.kbits_coreside != 0) {
         c->coreside = true;
-        c->coreside_mode = (ls > 0 && k.kbits_mode != 4) ? 2 : 4;
+        // (lock-step only where it fills >= 80 % of the CUs: at N = 2048 it has 144 workgroups and the co-resident step
+        // loses to the disjoint form, 1.87 vs 1.65 ms, profiles/r03y; the even split always has one workgroup per CU)
+        c->coreside_mode = (ls > 0 && gram_lockstep_workgroups(c->n, ls) * 5 >= c->num_cu * 4 && k.kbits_mode != 4) ? 2 : 4;
+        if (k.kbits_mode == 2 && ls > 0) c->coreside_mode = 2;
         c->pipe_gram_cus = c->num_cu;
         c->ring_wgs = (k.kbits_ring_wgs > 0) ? k.kbits_ring_wgs : 2 * c->num_cu;
       }
@@ -912,15 +915,16 @@ int packed_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64
     if (autom && !can_defer) HIP_TRY(c, hipMemsetAsync(flag, 0, sizeof(int32_t), ps));
     {
       ScopedTimer t(c, T_PACK, ps);
-      // co-resident pipeline: the ring pre-pass for every fp32 tile that qualifies -- two workgroups per CU beside a
-      // contraction, one per CU with the chip to itself (as fast as pack_kbits_kernel there)
-      // (a ring wave wants several units of 128 variants x 256 samples to stream through: >= 4 per wave, else fewer
-      // workgroups; a tiny chunk takes the ordinary kernel)
+      // co-resident pipeline: the persistent ring pre-pass for every fp32 tile that qualifies -- two workgroups per CU; a
+      // ring wave wants several units of 128 variants x 256 samples to stream through (>= 4 per wave, else fewer
+      // workgroups; a tiny chunk takes the ordinary kernel).
+      // Only BESIDE a contraction (the generation fills on the pre-pass stream): with the chip to itself the ordinary
+      // kernel is as fast on big chunks and much faster on small ones (64 x 16,384-variant calls: 270 vs 194 M variants/s,
+      // profiles/r03y) -- a persistent wave wants many units to stream through.
       int ring_wgs = 0;
-      if (c->coreside && deferrable_f32) {
+      if (c->coreside && deferrable_f32 && ps == c->pack_stream) {
         const int64_t units = (kb / 4) * (gram_packed_npad(c->n) / 256);
-        const int64_t most = (ps == c->pack_stream) ? c->ring_wgs : c->num_cu;
-        if (units >= 64) ring_wgs = (int)std::max<int64_t>(1, std::min<int64_t>(most, units / 16));
+        if (units >= 64) ring_wgs = (int)std::max<int64_t>(1, std::min<int64_t>(c->ring_wgs, units / 16));
       }
       hipError_t e = launch_pack_operand(c, x_chunk, is_u8, ld, cur, dst, flag, ps, kb, ring_wgs);
       if (e != hipSuccess) return hip_fail(c, e, "operand pre-pass launch");

@@ -7,7 +7,12 @@ says which boundary of which shape it was (AMD_SERIALIZE_KERNEL=3 / HIP_LAUNCH_B
 Results are still compared with an integer matmul, so an out-of-bounds read that happened to land in mapped memory and
 changed S is caught as well.
 
-usage: guard_sweep.py <n_cases> <first_seed> [loops] [index of the first case]
+usage: guard_sweep.py <n_cases> <first_seed> [loops] [index of the first case] [ring]
+
+"ring": the co-resident fp32 pipeline instead -- shapes where it is on (N > 1024, stride a multiple of 4, several
+accumulate calls per job), meant to run with PCOA_DEBUG_MAX_LAUNCH small so that operand buffers fill, alternate and the
+persistent ring pre-pass (pack_kbits_ring_kernel) runs beside a contraction: its row clamp, its look-ahead into the wave's
+next unit and its column offsets all sit against unmapped pages then.
 """
 import ctypes
 import os
@@ -132,7 +137,43 @@ def one_case(seed, idx):
             hh.compute(2)
 
 
+def ring_case(seed, idx):
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([1025, 1279, 1280, 1281, 1536, 2504])) if rng.random() < 0.6 else int(rng.integers(1025, 2600))
+    ld = (n + 3) // 4 * 4 + 4 * int(rng.integers(0, 3))       # ring_ok: stride a multiple of 4 floats
+    calls = [int(rng.choice([127, 129, 1000, 2049, 4097, 5000])) for _ in range(int(rng.integers(3, 7)))]
+    dens = float(rng.choice([0.02, 0.2, 0.6]))
+    print("ring case seed=%d n=%d ld=%d calls=%s" % (seed, n, ld, calls), flush=True)
+    want = np.zeros((n, n), dtype=np.int64)
+    with P.PcoaEngine(n, gram_kernel=["auto", "fp4"][idx % 2]) as eng:
+        ctx = eng._ctx
+        bufs = []
+        for v in calls:
+            x = (rng.random((v, n)) < dens).astype(np.uint8)
+            want += int_gram(x)
+            a = np.full((v, ld), np.nan, dtype=np.float32)    # garbage in the padding columns
+            a[:, :n] = x
+            d = DevBuf(a)                                     # the allocation ends with the last row
+            bufs.append(d)
+            eng._check(lib.pcoa_accumulate_dense_f32(ctx, d.ptr, v, ld, 1))
+        check(eng, want, "f32 device tiles through the pipeline")
+        tim = eng.timings()
+        for d in bufs:
+            d.free()
+        return int(tim["pipeline_launches"])
+
+
 def main():
+    if len(sys.argv) > 5 and sys.argv[5] == "ring":
+        n_cases, first = int(sys.argv[1]), int(sys.argv[2])
+        mode = lib.pcoa_debug_guard_mode()
+        print("guard mode %d (ring)" % mode, flush=True)
+        piped = sum(ring_case(first + i, i) for i in range(n_cases))
+        assert hip.hipDeviceSynchronize() == 0
+        # the sweep must actually have reached the pipeline (else it proves nothing about the ring kernel)
+        assert piped > 0, "no contraction was launched beside a pre-pass: is PCOA_DEBUG_MAX_LAUNCH set?"
+        print("guard sweep ok: %d ring cases, %d pipelined contraction launches, mode %d" % (n_cases, piped, mode), flush=True)
+        return
     n_cases, first = int(sys.argv[1]), int(sys.argv[2])
     loops = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     idx0 = int(sys.argv[4]) if len(sys.argv) > 4 else 0   # reproduce case number idx0 of an earlier sweep on its own
