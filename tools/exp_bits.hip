@@ -517,15 +517,10 @@ static int coreside_main(int n, int64_t v, int reps, int num_cu, unsigned long l
   pipeline("shipped: pack_kbits || even split 128 (disjoint CUs)", 0, 128, -1, 0, 10);
   struct Cfg { const char* what; int var, mode, cus, ring, wgs; };
   const Cfg cfgs[] = {
-      {"CO-RESIDENT: ring R8 nt natural, 512 wgs || lock-step 220, contraction ring 3", 5, 2, 256, 10108, 512},
-      {"CO-RESIDENT: ring R8 nt natural, 512 wgs || lock-step 220, contraction ring 4", 6, 2, 256, 10108, 512},
-      {"CO-RESIDENT: ring R8 nt natural, 512 wgs || lock-step 220, contraction ring 6", 7, 2, 256, 10108, 512},
-      {"CO-RESIDENT: ring R8 nt natural, 512 wgs || even split 256, contraction ring 4", 6, 4, 256, 10108, 512},
-      {"CO-RESIDENT: ring R8 nt natural, 512 wgs || even split 256, contraction ring 6", 7, 4, 256, 10108, 512},
-      {"CO-RESIDENT: ring R8 nt natural, 768 wgs || lock-step 220, contraction ring 4", 6, 2, 256, 10108, 768},
-      {"CO-RESIDENT: ring R8 nt natural, 512 wgs || lock-step 220, contraction ring 3 (again)", 5, 2, 256, 10108, 512},
-      {"CO-RESIDENT: ring R8 nt natural, 512 wgs || lock-step 220, contraction ring 4 (again)", 6, 2, 256, 10108, 512},
-      {"CO-RESIDENT: ring R8 nt natural, 512 wgs || lock-step 220, contraction ring 6 (again)", 7, 2, 256, 10108, 512},
+      {"CO-RESIDENT: ring R8 nt, 512 wgs || lock-step 220", 5, 2, 256, 108, 512},
+      {"CO-RESIDENT: ring R8 nt, 512 wgs || even split 256", 5, 4, 256, 108, 512},
+      {"CO-RESIDENT: ring R8 nt, 512 wgs || lock-step 220 (again)", 5, 2, 256, 108, 512},
+      {"CO-RESIDENT: ring R8 nt, 512 wgs || lock-step 220, contraction ring 4", 6, 2, 256, 108, 512},
   };
   for (const Cfg& c : cfgs) {
     gram_mode = c.mode;

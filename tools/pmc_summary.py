@@ -13,7 +13,7 @@ for sub in sorted(glob.glob(os.path.join(out, "pmc_*"))):
         acc = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(set)
         for row in csv.DictReader(open(f)):
             k = row.get("Kernel_Name", "")
-            m = re.search(r"(gram_kbits_kernel|pack_kbits_kernel|pack_u8x8_kbits_kernel|transpose_bits_kbits_kernel|gram_packed_kernel|gram_i8_kernel|gram_f32_kernel|pack_u8x8_fp4_kernel|expand_bits_fp4_kernel|pack_f32_i8_kernel|pack_u8_i8_kernel|pack_fp4_kernel|"
+            m = re.search(r"(gram_kbits_kernel|pack_kbits_ring_kernel|pack_kbits_kernel|pack_u8x8_kbits_kernel|transpose_bits_kbits_kernel|gram_packed_kernel|gram_i8_kernel|gram_f32_kernel|pack_u8x8_fp4_kernel|expand_bits_fp4_kernel|pack_f32_i8_kernel|pack_u8_i8_kernel|pack_fp4_kernel|"
                           r"tridiag_update_kernel|symv_kernel)", k)
             if not m:
                 continue
