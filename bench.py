@@ -493,8 +493,11 @@ def main():
             out["alt_input_u8"] = {"value": v * steps / dt8, "unit": "variants/s", "ms_per_step": 1e3 * dt8 / steps,
                                    "pack_ms_per_step": 1e3 * t8["pack_seconds"] / steps,
                                    "gram_ms_per_step": 1e3 * t8["gram_kernel_seconds"] / steps,
+                                   "pipeline_launches": int(t8["pipeline_launches"]),
                                    "note": "same cohort handed over as uint8 [V][N] (pcoa_accumulate_dense_u8); "
-                                           "not the BASELINE configs[1] fp32 boundary, reported for reference"}
+                                           "not the BASELINE configs[1] fp32 boundary, reported for reference.  "
+                                           "pipeline_launches > 0: the pre-pass of one operand buffer ran beside the "
+                                           "contraction of the previous one (co-resident form), so pack + gram > step"}
             del x8
             # the bit-packed boundary (1 bit per genotype, 313 B per variant): expand to FP4 + the same contraction
             words = (n + 31) // 32
@@ -521,6 +524,7 @@ def main():
             out["alt_input_bits"] = {"value": v * steps / dtb, "unit": "variants/s", "ms_per_step": 1e3 * dtb / steps,
                                      "expand_ms_per_step": 1e3 * tb["pack_seconds"] / steps,
                                      "gram_ms_per_step": 1e3 * tb["gram_kernel_seconds"] / steps,
+                                     "pipeline_launches": int(tb["pipeline_launches"]),
                                      "bytes_per_variant": 4 * words,
                                      "same_gram_as_dense_input": bool(np.array_equal(eng.gram(), s_dense)),
                                      "note": "same cohort as carrier bitsets [V][ceil(N/32)] uint32 "

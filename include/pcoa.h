@@ -17,8 +17,8 @@
  *     host buffer passed in; a ctx is used from one host thread at a time, different ctxs are
  *     independent (one per Spark task / per rank);
  *   - matrices are row-major unless stated; "device pointer" means HIP device memory on the ctx's GPU;
- *   - accumulate calls only queue work (on the ctx stream and, for fp32 tiles, on two side streams the ctx owns and
- *     orders against it); the SYNCHRONISING calls are pcoa_sync, pcoa_gram_finalize, every read / load / export /
+ *   - accumulate calls only queue work (on the ctx stream and, for device tiles -- fp32, uint8, bitsets --, on two side
+ *     streams the ctx owns and orders against it: the pre-pass of one operand buffer runs while the previous one is contracted); the SYNCHRONISING calls are pcoa_sync, pcoa_gram_finalize, every read / load / export /
  *     import / all-reduce / compute call, pcoa_get_timings / pcoa_reset_timings and pcoa_set_stream.  A DEVICE input of an
  *     accumulate call must stay valid and unchanged until the next synchronising call returns: its pre-pass may still be
  *     running, and in the default (auto) mode a tile whose pre-pass met a carrier multiplicity is read a second time by

@@ -226,6 +226,136 @@ __global__ __launch_bounds__(256, 8) void pack_kbits_ring_kernel(const float* __
   if (bad) atomicOr(flag, 8);
 }
 
+// ---- the same persistent ring pre-pass for uint8 tiles (ld % 8 == 0, 8-byte aligned base) ----------------------------------
+// One wave per SIMD (<= 112 VGPRs beside the contraction), units of 128 variants x 1,024 samples: a row of a unit is the
+// 1 KiB of ONE global_load_lds_dwordx4, a lane owns 16 consecutive samples.  Per row 8 VALU operations (the 0/1 bytes of row
+// t of an 8-row group are OR-ed in at bit t: one byte of 8 row-bits per sample, as pack_u8x8_kbits_kernel; bytes > 1 raise
+// flag bit 3), per 8 rows 32 more to move the 16 bytes into their samples' words.  A lane whose 16 bytes would cross the end
+// of a row (ld % 16 == 8) reads the LAST 16 bytes of the row instead and uses the upper half -- no byte beyond the tile is
+// ever read.
+// ds_read_b128 as an asm statement: a plain load from the ring makes the compiler's wait-count pass put an
+// s_waitcnt vmcnt(0) in front of it -- inside a loop it cannot tell the slot being read from the slots the LDS-DMA in
+// flight writes -- which drains the ring at every row (measured: 1.59 instead of 0.5 ms per 10^6 variants).  The waits are
+// explicit here anyway (vmcnt(R - 1) before the read, lgkmcnt(0) before the value is used).
+__device__ __forceinline__ uint4 lds_read_b128_asm(uint32_t lds_addr) {
+  uint4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(lds_addr) : "memory");
+  return v;
+}
+template <int R, int AUX>
+__global__ __launch_bounds__(256, 4) void pack_u8_kbits_ring_kernel(const uint8_t* __restrict__ x, int64_t ld, int nv, int n,
+                                                                    int npad, int n_units, uint32_t* __restrict__ p,
+                                                                    int32_t* __restrict__ flag) {
+  static_assert(R == 8, "the slot of row t must be a compile-time constant of the 8-row unrolled body");
+  extern __shared__ __attribute__((aligned(16))) uint8_t ring_dyn_u8[];  // 4 * R KiB
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gw = (npad + 1023) >> 10;  // 1,024-sample groups per block
+  const int stride = (int)gridDim.x * 4;
+  const int stride_b = stride / gw, stride_g = stride - stride_b * gw;
+  int u = (int)blockIdx.x * 4 + wave;
+  if (u >= n_units) return;  // no workgroup barrier anywhere below
+  int blk = u / gw, G = u - blk * gw;
+  uint8_t* const myring = ring_dyn_u8 + wave * (R * 1024);
+  const char* const xb = reinterpret_cast<const char*>(x);
+  const int ldi = (int)ld;
+  // byte offset of the lane's 16 bytes inside a row, and whether they were moved back by 8 to stay inside it
+  auto lane_off = [&](int Gq, bool& shifted) -> uint32_t {
+    const int col = Gq * 1024 + lane * 16;
+    shifted = col < ldi && col + 16 > ldi;
+    return col + 16 <= ldi ? (uint32_t)col : (col < ldi ? (uint32_t)(ldi - 16) : 0u);
+  };
+  auto issue = [&](int bq, uint32_t vo, int r, int slot) {
+    int row = bq * 128 + r;
+    row = row < nv ? row : nv - 1;
+    const char* rowp = xb + (int64_t)row * ld;
+    asm volatile("" : "+s"(rowp));  // wave-uniform: one 64-bit add per lane and row (see ring_rows_kbits)
+    __builtin_amdgcn_global_load_lds((gptr_t)(rowp + vo), (lptr_t)(myring + slot * 1024), 16, 0, AUX);
+  };
+  bool shifted = false, shiftedn = false;
+  uint32_t voff = lane_off(G, shifted);
+  uint32_t bad = 0;
+#pragma unroll
+  for (int t = 0; t < R; ++t) issue(blk, voff, t, t);
+  wait_vmcnt<R - 1>();
+  const uint32_t lds_lane = (uint32_t)(uintptr_t)(lptr_t)(myring + lane * 16);  // the lane's 16 bytes of slot 0 (LDS offset)
+  uint4 a = lds_read_b128_asm(lds_lane);  // row 0 of the first unit
+  for (;;) {
+    int blkn = blk + stride_b, Gn = G + stride_g;
+    if (Gn >= gw) { Gn -= gw; blkn += 1; }
+    const bool last = u + stride >= n_units;
+    if (last) { blkn = blk; Gn = G; }  // a harmless re-read keeps the queue depth (and vmcnt) uniform
+    const uint32_t voffn = lane_off(Gn, shiftedn);
+    const int col = G * 1024 + lane * 16;
+    uint32_t w[16][4], badd[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[s2][q] = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll 1
+      for (int g = 0; g < 4; ++g) {  // a real loop: 8 rows of code per word instead of 32
+        uint32_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const int r = c * 32 + g * 8 + t;  // row of the unit
+          __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): row r is in `a`, its slot is free
+          __builtin_amdgcn_sched_barrier(0);
+          if (r + R < 128) issue(blk, voff, r + R, t % R);
+          else issue(blkn, voffn, r + R - 128, t % R);
+          wait_vmcnt<R - 1>();  // row r + 1 has landed
+          __builtin_amdgcn_sched_barrier(0);
+          const uint4 b = lds_read_b128_asm(lds_lane + ((t + 1) % R) * 1024);
+          __builtin_amdgcn_sched_barrier(0);
+          if (blk * 128 + r < nv) {  // wave-uniform: rows beyond the tile re-read its last row and are skipped
+            const uint32_t av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              badd[d] |= av[d] & 0xfefefefeu;
+              acc[d] |= av[d] << t;
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d) asm volatile("" : "+v"(acc[d]), "+v"(badd[d]));
+          }
+          a = b;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // the 16 bytes of 8 row-bits go to bits 8 g .. 8 g + 7 of word c of their samples (a shifted lane's samples sit in
+        // the upper 8 bytes)
+        if (shifted) { acc[0] = acc[2]; acc[1] = acc[3]; acc[2] = 0; acc[3] = 0; }
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) w[4 * d + bb][c] |= ((acc[d] >> (8 * bb)) & 0xffu) << (8 * g);
+      }
+    }
+    if (shifted) { badd[0] = badd[2]; badd[1] = badd[3]; badd[2] = 0; badd[3] = 0; }
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const bool livecol = col + s2 < n;  // samples >= n may hold anything
+      const uint32_t cm = livecol ? 0xffffffffu : 0u;
+      bad |= (badd[s2 >> 2] >> (8 * (s2 & 3))) & 0xffu & cm;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[s2][q] &= cm;
+    }
+    if (col < npad) {
+      uint4* dst = reinterpret_cast<uint4*>(p + ((size_t)blk * npad + col) * 4);
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) dst[s2] = make_uint4(w[s2][0], w[s2][1], w[s2][2], w[s2][3]);
+    }
+    if (last) break;
+    u += stride;
+    blk = blkn;
+    G = Gn;
+    voff = voffn;
+    shifted = shiftedn;
+  }
+  wait_vmcnt<0>();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (bad) atomicOr(flag, 8);
+}
+
 // uint8 tile, 8-byte loads (ld % 8 == 0, 8-byte aligned base): one thread = 128 variants x 8 samples.  Per batch of 8 rows
 // the 0/1 bytes of row t are OR-ed in at bit t, which leaves one byte of 8 row-bits per sample: byte q of word c.
 __global__ __launch_bounds__(256) void pack_u8x8_kbits_kernel(const uint8_t* __restrict__ x, int64_t ld, int64_t nv, int n,
@@ -859,6 +989,26 @@ hipError_t launch_pack_kbits_ring(const float* x, int64_t ld, int64_t nv, int32_
   else PCOA_RINGK(8, 2, 0);
 #endif
 #undef PCOA_RINGK
+  return hipGetLastError();
+}
+
+// The uint8 form (pack_u8_kbits_ring_kernel): ld % 8 == 0 and an 8-byte aligned base, ld >= 16.
+bool pack_u8_ring_ok(const void* x, int64_t ld) {
+  return ((ld & 7) == 0) && ld >= 16 && ((reinterpret_cast<uintptr_t>(x) & 7) == 0);
+}
+hipError_t launch_pack_kbits_ring_u8(const uint8_t* x, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
+                                     hipStream_t stream, int64_t nblk_out, int wgs, int ring) {
+  if (nv <= 0) return hipSuccess;
+  if (!pack_u8_ring_ok(x, ld) || nv > 0x3fffffffLL || ld > 0x3fffffffLL) return hipErrorInvalidValue;
+  const int npad = (int)gram_packed_npad(n);
+  const int64_t nblk = nblk_out > 0 ? nblk_out : (nv + 127) / 128;
+  const int64_t units = nblk * ((npad + 1023) >> 10);
+  if (units > 0x3fffffffLL) return hipErrorInvalidValue;
+  uint32_t* pw = reinterpret_cast<uint32_t*>(p);
+  const int64_t most = (units + 3) / 4;
+  const dim3 grid((unsigned)(wgs > 0 && wgs < most ? wgs : most)), block(256);
+  (void)ring;  // one form: 8 rows in flight per wave, nontemporal
+  hipLaunchKernelGGL((pack_u8_kbits_ring_kernel<8, 2>), grid, block, 32 << 10, stream, x, ld, (int)nv, n, npad, (int)units, pw, flag);
   return hipGetLastError();
 }
 

@@ -497,6 +497,8 @@ hipError_t launch_pack_operand(const pcoa_ctx* c, const void* x, int is_u8, int6
   // ring_wgs > 0: the persistent ring pre-pass of the co-resident fp32 pipeline (fp32 tile, k-bits operand, ring_ok checked)
   if (ring_wgs > 0 && c->op_fmt == 2 && !is_u8)
     return launch_pack_kbits_ring(static_cast<const float*>(x), ld, nv, c->n, dst, flag, s, kb / 4, ring_wgs, 108);
+  if (ring_wgs > 0 && c->op_fmt == 2 && is_u8)
+    return launch_pack_kbits_ring_u8(static_cast<const uint8_t*>(x), ld, nv, c->n, dst, flag, s, kb / 4, ring_wgs, 108);
   return c->op_fmt == 2 ? launch_pack_kbits(x, is_u8, ld, nv, c->n, dst, flag, s, kb / 4)
                         : launch_pack_fp4(x, is_u8, ld, nv, c->n, dst, flag, s, kb);
 }
@@ -609,7 +611,8 @@ int fp4_setup(pcoa_ctx* c) {
 
 // Queue the contraction of buffer b's current generation.  overlapped: more fp32 pre-passes are coming, so the
 // contraction goes to the contraction stream, sized for half the chip; otherwise it takes the whole chip on the ctx stream.
-int fp4_launch(pcoa_ctx* c, int bi, bool overlapped) {
+// side_kind: what will run beside it (the chunk that found the buffer full): 1 fp32 tile, 2 uint8 tile, 3 bitset tile.
+int fp4_launch(pcoa_ctx* c, int bi, bool overlapped, int side_kind = 1) {
   pcoa_ctx::Fp4Buf& b = c->fb[bi];
   if (b.kb == 0) return PCOA_OK;
   int rc = fold_if_needed(c, b.vars);
@@ -632,7 +635,8 @@ int fp4_launch(pcoa_ctx* c, int bi, bool overlapped) {
     hipError_t e = hipErrorInvalidValue;
     if (c->op_fmt == 2) {
       // k-bits: beside the pre-pass an even split over `pipe_gram_cus` workgroups, else the whole-chip form chosen in fp4_setup
-      const int mode = side ? (c->coreside ? c->coreside_mode : 4) : c->kbits_mode;
+      // (beside the short bitset transpose the even split wins: 1.07 vs 1.11 ms per step, profiles/r04d)
+      const int mode = side ? ((c->coreside && side_kind != 3) ? c->coreside_mode : 4) : c->kbits_mode;
       e = launch_gram_kbits(b.p, b.kb * 32, c->n, c->s32, cus, gs, mode, skip, strip_of(c));
       if (e != hipSuccess && mode != 0) {
         (void)hipGetLastError();
@@ -789,19 +793,21 @@ int fp4_grow(pcoa_ctx* c, int bi, int64_t kb, int64_t chunk_variants) {
 // Where the next `kb` k-blocks of packed operand go: *dst in the active buffer, to be written on *stream (already
 // ordered behind the ctx stream).  deferrable_f32: the chunk is an fp32 device tile whose pre-pass may run on the
 // masked stream beside a contraction in flight; verify: its pre-pass reports non-binary values through *flag.
-int fp4_reserve(pcoa_ctx* c, int64_t kb, int64_t chunk_variants, bool deferrable_f32, bool verify, int8_t** dst,
+int fp4_reserve(pcoa_ctx* c, int64_t kb, int64_t chunk_variants, int side_kind, bool verify, int8_t** dst,
                 hipStream_t* stream, int32_t** flag) {
   int rc = fp4_setup(c);
   if (rc != PCOA_OK) return rc;
   pcoa_ctx::Fp4Buf* b = &c->fb[c->fb_active];
-  const bool want_side = deferrable_f32 && c->pipe_ok;
+  // side_kind: 0 = the chunk's pre-pass must run on the ctx stream; 1 = fp32 device tile that may run beside a contraction
+  // (either pipeline form); 2 / 3 = uint8 / bitset device tile: only the co-resident form has pre-passes that fit beside one
+  const bool want_side = c->pipe_ok && (side_kind == 1 || (side_kind > 1 && c->coreside));
   // a generation filling on the masked stream only takes chunks that may run there; a generation that does not report
   // through its flag cannot start to (an earlier launch decision may already have been made without it)
   // (nor the other way round: a skipped launch would drop chunks that cannot be redone)
   const bool misfit = b->kb > 0 && ((b->fill_stream != c->stream && !want_side) || (verify != b->verify));
   const bool full = b->kb > 0 && b->kb + kb > std::max(fp4_target_kb(c), kb);
   if (misfit || full) {
-    if ((rc = fp4_launch(c, c->fb_active, want_side)) != PCOA_OK) return rc;
+    if ((rc = fp4_launch(c, c->fb_active, want_side, side_kind)) != PCOA_OK) return rc;
     if (c->fb_count == 2) c->fb_active ^= 1;
     b = &c->fb[c->fb_active];
   }
@@ -907,7 +913,9 @@ int packed_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64
     hipStream_t ps = nullptr;
     int32_t* bflag = nullptr;
     const bool deferrable_f32 = can_defer && !is_u8 && pack_fp4_ring_ok(x_chunk, ld);
-    if ((rc = fp4_reserve(c, kb, cur, deferrable_f32, autom && can_defer, &dst, &ps, &bflag)) != PCOA_OK) return rc;
+    const bool deferrable_u8 = can_defer && is_u8 && c->coreside && pack_u8_ring_ok(x_chunk, ld);
+    const int side_kind = deferrable_f32 ? 1 : deferrable_u8 ? 2 : 0;
+    if ((rc = fp4_reserve(c, kb, cur, side_kind, autom && can_defer, &dst, &ps, &bflag)) != PCOA_OK) return rc;
     // where the pre-pass reports a value other than 0 / 1: the generation's flag (auto, deferred), a scratch word that
     // is read back at once (auto, staging tile), or the ctx error word (FP4 forced: an error)
     int32_t* flag = c->err_flag;
@@ -925,6 +933,12 @@ int packed_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64
       if (c->coreside && deferrable_f32 && ps == c->pack_stream) {
         const int64_t units = (kb / 4) * (gram_packed_npad(c->n) / 256);
         if (units >= 64) ring_wgs = (int)std::max<int64_t>(1, std::min<int64_t>(c->ring_wgs, units / 16));
+      }
+      // uint8 tiles: the ring form with one workgroup per CU (94 VGPRs: one wave per SIMD beside the contraction), units
+      // of 128 variants x 1,024 samples
+      if (c->coreside && deferrable_u8 && ps == c->pack_stream) {
+        const int64_t units = (kb / 4) * ((gram_packed_npad(c->n) + 1023) / 1024);
+        if (units >= 64) ring_wgs = (int)std::max<int64_t>(1, std::min<int64_t>(c->num_cu, units / 16));
       }
       hipError_t e = launch_pack_operand(c, x_chunk, is_u8, ld, cur, dst, flag, ps, kb, ring_wgs);
       if (e != hipSuccess) return hip_fail(c, e, "operand pre-pass launch");
@@ -1404,7 +1418,9 @@ int pcoa_accumulate_dense_u8(pcoa_ctx* c, const uint8_t* x, int64_t n_variants, 
 
 namespace {
 // bit-packed tile resident on the device -> FP4 operand -> FP4 contraction
-int gram_device_bits(pcoa_ctx* c, const uint32_t* bits_dev, int64_t nv, int64_t ld_words) {
+// can_defer: a caller's device pointer (valid until the next synchronising call): in the co-resident pipeline its transpose
+// (68 VGPRs: one wave per SIMD fits beside the contraction) runs while the previous buffer is contracted
+int gram_device_bits(pcoa_ctx* c, const uint32_t* bits_dev, int64_t nv, int64_t ld_words, bool can_defer) {
   int64_t done = 0;
   const int64_t max_cur = std::min(c->max_launch, c->pack_chunk);
   while (done < nv) {
@@ -1412,7 +1428,7 @@ int gram_device_bits(pcoa_ctx* c, const uint32_t* bits_dev, int64_t nv, int64_t 
     const int64_t kb = kb_of(c, cur);
     int8_t* dst = nullptr;
     hipStream_t ps = nullptr;
-    int rc = fp4_reserve(c, kb, cur, false, false, &dst, &ps, nullptr);  // bitsets are binary by construction
+    int rc = fp4_reserve(c, kb, cur, can_defer ? 3 : 0, false, &dst, &ps, nullptr);  // bitsets are binary by construction
     if (rc != PCOA_OK) return rc;
     {
       ScopedTimer t(c, T_PACK, ps);
@@ -1437,7 +1453,7 @@ int pcoa_accumulate_bits(pcoa_ctx* c, const uint32_t* bits, int64_t n_variants, 
   if (!c->use_i8)
     return fail(c, PCOA_ERR_INVALID_ARG, "the bit-packed boundary needs a packed-operand engine (not PCOA_FLAG_GRAM_F32_MFMA)");
   if (n_variants == 0) return PCOA_OK;
-  if (is_device_ptr) return gram_device_bits(c, bits, n_variants, ld_words);
+  if (is_device_ptr) return gram_device_bits(c, bits, n_variants, ld_words, true);
   // host bitsets: staged densely (ceil(N/32) words per row) through the tile buffer, at most 256 MiB at a time
   const int64_t rows_cap = std::max<int64_t>(1, std::min<int64_t>(n_variants, ((int64_t)64 << 20) / need_words));
   int rc = ensure(c, &c->tile, &c->tile_elems, rows_cap * need_words);
@@ -1447,7 +1463,7 @@ int pcoa_accumulate_bits(pcoa_ctx* c, const uint32_t* bits, int64_t n_variants, 
     const int64_t rows = std::min(rows_cap, n_variants - v0);
     HIP_TRY(c, hipMemcpy2DAsync(stage, (size_t)need_words * 4, bits + v0 * ld_words, (size_t)ld_words * 4,
                                 (size_t)need_words * 4, (size_t)rows, hipMemcpyHostToDevice, c->stream));
-    rc = gram_device_bits(c, stage, rows, need_words);
+    rc = gram_device_bits(c, stage, rows, need_words, false);
     if (rc != PCOA_OK) return rc;
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));

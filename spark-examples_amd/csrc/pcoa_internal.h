@@ -90,6 +90,10 @@ hipError_t launch_pack_kbits_ring(const float* x, int64_t ld, int64_t nv, int32_
                                   hipStream_t stream, int64_t nblk_out, int wgs, int ring);
 hipError_t launch_pack_fp4_ring(const float* x, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
                                 hipStream_t stream, int64_t nkb_out, int wgs, int nt);
+// the uint8 form: units of 128 variants x 1,024 samples, one wave per SIMD (ld % 8 == 0, 8-byte aligned base)
+bool pack_u8_ring_ok(const void* x, int64_t ld);
+hipError_t launch_pack_kbits_ring_u8(const uint8_t* x, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
+                                     hipStream_t stream, int64_t nblk_out, int wgs, int ring);
 // Strip owner (SURVEY 8e, N beyond one HBM): the launch computes S[:, col0 .. col0 + cols) -- every row block against the
 // column blocks of the strip, BOTH triangles -- into a row-major [n][cols] matrix.  cols == 0: the ordinary symmetric job.
 struct GramStrip {

@@ -148,15 +148,30 @@ def ring_case(seed, idx):
     with P.PcoaEngine(n, gram_kernel=["auto", "fp4"][idx % 2]) as eng:
         ctx = eng._ctx
         bufs = []
-        for v in calls:
+        for j, v in enumerate(calls):
             x = (rng.random((v, n)) < dens).astype(np.uint8)
             want += int_gram(x)
-            a = np.full((v, ld), np.nan, dtype=np.float32)    # garbage in the padding columns
-            a[:, :n] = x
-            d = DevBuf(a)                                     # the allocation ends with the last row
+            fmt = (idx + j) % 3 if idx % 4 else 0              # every fourth case fp32 only, else fp32 / uint8 / bitsets mixed
+            if fmt == 0:
+                a = np.full((v, ld), np.nan, dtype=np.float32)    # garbage in the padding columns
+                a[:, :n] = x
+                d = DevBuf(a)                                     # the allocation ends with the last row
+                eng._check(lib.pcoa_accumulate_dense_f32(ctx, d.ptr, v, ld, 1))
+            elif fmt == 1:
+                ld8 = (n + 7) // 8 * 8 + 8 * int(rng.integers(0, 3))   # u8 ring: stride a multiple of 8 bytes (% 16 == 8 too)
+                a8 = np.full((v, ld8), 255, dtype=np.uint8)
+                a8[:, :n] = x
+                d = DevBuf(a8)
+                eng._check(lib.pcoa_accumulate_dense_u8(ctx, d.ptr, v, ld8, 1))
+            else:
+                pw = int(rng.integers(0, 3))
+                bits = ingest.pack_bits(x, pad_words=pw)
+                if pw:
+                    bits[:, (n + 31) // 32:] = 0xa5a5a5a5
+                d = DevBuf(bits)
+                eng._check(lib.pcoa_accumulate_bits(ctx, d.ptr, v, bits.shape[1], 1))
             bufs.append(d)
-            eng._check(lib.pcoa_accumulate_dense_f32(ctx, d.ptr, v, ld, 1))
-        check(eng, want, "f32 device tiles through the pipeline")
+        check(eng, want, "device tiles (fp32 / uint8 / bitsets) through the pipeline")
         tim = eng.timings()
         for d in bufs:
             d.free()

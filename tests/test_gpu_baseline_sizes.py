@@ -382,8 +382,8 @@ with P.PcoaEngine(n) as eng:
     t = eng.timings()
     out["launches"] = int(t["gram_kernel_launches"]); out["fallbacks"] = int(t["fp4_fallbacks"])
     out["kind"] = int(t["gram_kernel_kind"]); out["variants"] = int(t["gram_variants"])
-    want = O.similarity_from_dense_blas(x.cpu().numpy())
-    want = 3 * want + O.similarity_from_dense_blas(x[:77777].cpu().numpy())
+    want_x = O.similarity_from_dense_blas(x.cpu().numpy())
+    want = 3 * want_x + O.similarity_from_dense_blas(x[:77777].cpu().numpy())
     out["binary_exact"] = bool(np.array_equal(s, want))
     # (2) a multiplicity deep inside one generation of a device tile: the device-side predicate skips that
     #     generation's contraction, the host redoes its chunks on the int8 kernel -- no error, exact S
@@ -443,6 +443,32 @@ with P.PcoaEngine(n) as eng:
     except IndexError:
         out["index_error"] = True
     out["after_error_exact"] = bool(np.array_equal(eng.gram(), want_a))
+    # (7) the same cohort as uint8 and as carrier bitsets, device-resident, many generations: in the co-resident pipeline
+    #     their pre-passes (uint8 ring kernel / bitset transpose) run beside the contraction of the previous buffer;
+    #     a multiplicity inside a uint8 tile takes the deferred int8 redo like an fp32 one
+    x8 = x.to(torch.uint8)
+    eng.reset(); eng.reset_timings()
+    eng.accumulate_dense_u8(x8)
+    eng.accumulate_dense_u8(x8[:77777])
+    t7 = eng.timings()
+    out["u8_exact"] = bool(np.array_equal(eng.gram(), want_x + O.similarity_from_dense_blas(x[:77777].cpu().numpy())))
+    out["u8_pipeline_launches"] = int(t7["pipeline_launches"])
+    ingest = load_pkg("ingest")
+    bits = torch.from_numpy(ingest.pack_bits(x8.cpu().numpy(), pad_words=1).view(np.int32)).cuda()
+    eng.reset(); eng.reset_timings()
+    eng.accumulate_bits(bits)
+    eng.accumulate_bits(bits[:50000])
+    t8 = eng.timings()
+    out["bits_exact"] = bool(np.array_equal(eng.gram(), want_x + O.similarity_from_dense_blas(x[:50000].cpu().numpy())))
+    out["bits_pipeline_launches"] = int(t8["pipeline_launches"])
+    y8 = x8.clone()
+    y8[200123, 17] = 3
+    eng.reset(); eng.reset_timings()
+    eng.accumulate_dense_u8(y8)
+    s9 = eng.gram()
+    a = y8[200123].cpu().numpy().astype(np.int64); b = x8[200123].cpu().numpy().astype(np.int64)   # the row with / without it
+    out["u8_mult_exact"] = bool(np.array_equal(s9, want_x + np.outer(a, a) - np.outer(b, b)))
+    out["u8_mult_fallbacks"] = int(eng.timings()["fp4_fallbacks"])
 print(json.dumps(out))
 '''
 
@@ -468,3 +494,7 @@ def test_fp32_pipeline_and_deferred_verification_on_device_tiles(env):
     assert out["released_exact"]
     assert out["reset_exact"] and out["load_exact"] and out["stream_exact"]
     assert out["index_error"] and out["after_error_exact"]
+    assert out["u8_exact"] and out["bits_exact"], out
+    assert out["u8_mult_exact"] and out["u8_mult_fallbacks"] >= 1, out
+    if not env:   # the default: the co-resident pipeline takes uint8 and bitset tiles as well
+        assert out["u8_pipeline_launches"] >= 1 and out["bits_pipeline_launches"] >= 1, out

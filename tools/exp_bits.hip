@@ -531,9 +531,188 @@ static int coreside_main(int n, int64_t v, int reps, int num_cu, unsigned long l
   return bad ? 1 : 0;
 }
 
+// ---- --coreside-alt (r04d): the uint8 and bitset boundaries with their pre-pass beside the contraction -------------------------
+static int u8_ring_case(int n, int64_t v, int64_t ld8, uint32_t thr, int wgs, unsigned long long* cnt, int32_t* flag) {
+  const int npad = (int)gram_packed_npad(n);
+  const int64_t nblk = gram_kb_pad(v, 2) / 4;
+  const size_t kbytes = (size_t)nblk * npad * 16;
+  float* xf;
+  uint8_t* x8;
+  int8_t *ka, *kb;
+  CK(hipMalloc(&xf, (size_t)(v * n * 4)));
+  CK(hipMalloc(&x8, (size_t)(v * ld8)));   // exactly the tile: a read beyond its last row is out of the allocation
+  CK(hipMalloc(&ka, kbytes));
+  CK(hipMalloc(&kb, kbytes));
+  hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, xf, v, (int64_t)n, (int64_t)n, 4242u + (uint32_t)n, thr);
+  hipLaunchKernelGGL(to_u8_kernel, dim3(1024), dim3(256), 0, 0, xf, x8, v, (int64_t)n, (int64_t)n, ld8);
+  CK(launch_pack_kbits(x8, 1, ld8, v, n, ka, flag, 0, nblk));
+  CK(hipMemset(kb, 0x5a, kbytes));
+  CK(launch_pack_kbits_ring_u8(x8, ld8, v, n, kb, flag, 0, nblk, wgs, 8));
+  CK(hipDeviceSynchronize());
+  const unsigned long long d = count_diff(ka, kb, (int64_t)kbytes, cnt);
+  std::printf("u8 ring pre-pass n=%d v=%lld ld=%lld (%d workgroups) vs pack_kbits<uint8>: %s (%llu words differ)\n", n, (long long)v,
+              (long long)ld8, wgs, d ? "MISMATCH" : "identical", d);
+  CK(hipFree(xf)); CK(hipFree(x8)); CK(hipFree(ka)); CK(hipFree(kb));
+  return d != 0;
+}
+
+static int coreside_alt_main(int n, int64_t v, int reps, int num_cu, unsigned long long* cnt) {
+  const int npad = (int)gram_packed_npad(n);
+  const int64_t ld = n;
+  const int64_t nblk = gram_kb_pad(v, 2) / 4;
+  const size_t kbytes = (size_t)nblk * npad * 16;
+  int32_t *sa, *sb, *flag;
+  CK(hipMalloc(&flag, 64));
+  CK(hipMemset(flag, 0, 64));
+  int bad = 0;
+  bad += u8_ring_case(1000, 4100, 1000, 0x30000000u, 7, cnt, flag);     // ld % 16 == 8: the last lane of a row is shifted
+  bad += u8_ring_case(257, 129, 264, 0xc0000000u, 3, cnt, flag);
+  bad += u8_ring_case(2504, 3000, 2512, 0x20000000u, 64, cnt, flag);    // ld % 16 == 0, padding columns
+  bad += u8_ring_case(1025, 777, 1032, 0x20000000u, 5, cnt, flag);
+  bad += u8_ring_case(33, 1000, 40, 0x60000000u, 2, cnt, flag);
+  int32_t hflag = 0;
+  CK(hipMemcpy(&hflag, flag, 4, hipMemcpyDeviceToHost));
+  std::printf("flag word after the binary cases: %d\n", hflag);
+  float* x;
+  int8_t* k1[2];
+  CK(hipMalloc(&x, (size_t)(v * ld * 4)));
+  for (int b = 0; b < 2; ++b) CK(hipMalloc(&k1[b], kbytes));
+  CK(hipMalloc(&sa, (size_t)n * n * 4));
+  CK(hipMalloc(&sb, (size_t)n * n * 4));
+  hipLaunchKernelGGL(fill_kernel, dim3(8192), dim3(256), 0, 0, x, v, (int64_t)n, ld, 777u, 0x18000000u);
+  const int64_t ld8 = (n + 7) / 8 * 8;
+  uint8_t* x8;
+  CK(hipMalloc(&x8, (size_t)(v * ld8)));
+  hipLaunchKernelGGL(to_u8_kernel, dim3(8192), dim3(256), 0, 0, x, x8, v, (int64_t)n, ld, ld8);
+  const int64_t ldw = ((n + 31) / 32 + 3) / 4 * 4;
+  uint32_t* bits;
+  CK(hipMalloc(&bits, (size_t)(v * ldw * 4)));
+  hipLaunchKernelGGL(to_bits_kernel, dim3(8192), dim3(256), 0, 0, x, bits, v, (int64_t)n, ld, ldw);
+  CK(launch_pack_kbits(x8, 1, ld8, v, n, k1[0], flag, 0, nblk));
+  CK(hipMemset(k1[1], 0x33, kbytes));
+  CK(launch_pack_kbits_ring_u8(x8, ld8, v, n, k1[1], flag, 0, nblk, num_cu, 8));
+  CK(hipDeviceSynchronize());
+  {
+    const unsigned long long d = count_diff(k1[0], k1[1], (int64_t)kbytes, cnt);
+    std::printf("full size: u8 ring operand vs pack_u8x8_kbits operand: %s (%llu words differ)\n", d ? "MISMATCH" : "identical", d);
+    bad += d != 0;
+  }
+  {  // a multiplicity must raise the flag
+    uint8_t two = 2;
+    CK(hipMemcpy(x8 + 12345 * ld8 + 77, &two, 1, hipMemcpyHostToDevice));
+    CK(hipMemset(flag, 0, 64));
+    CK(launch_pack_kbits_ring_u8(x8, ld8, v, n, k1[1], flag, 0, nblk, num_cu, 8));
+    CK(hipMemcpy(&hflag, flag, 4, hipMemcpyDeviceToHost));
+    std::printf("a byte of value 2 in the tile: flag word %d (%s)\n", hflag, (hflag & 8) ? "raised" : "NOT RAISED");
+    bad += (hflag & 8) == 0;
+    uint8_t back = 0;  // restore from the fp32 source
+    float f = 0;
+    CK(hipMemcpy(&f, x + 12345 * ld + 77, 4, hipMemcpyDeviceToHost));
+    back = (uint8_t)f;
+    CK(hipMemcpy(x8 + 12345 * ld8 + 77, &back, 1, hipMemcpyHostToDevice));
+    CK(hipMemset(flag, 0, 64));
+  }
+  const double mv = (double)v / 1e6;
+  auto line = [&](const char* what, float ms) { std::printf("time  %-66s %8.3f ms  (%.3f ms per 10^6 variants)\n", what, ms, ms / mv); };
+  line("pack_u8x8_kbits (shipped) alone", time_ms(0, reps, [&] { CK(launch_pack_kbits(x8, 1, ld8, v, n, k1[1], flag, 0, nblk)); }));
+  line("u8 ring pre-pass alone, 256 workgroups", time_ms(0, reps, [&] { CK(launch_pack_kbits_ring_u8(x8, ld8, v, n, k1[1], flag, 0, nblk, num_cu, 8)); }));
+  line("u8 ring pre-pass alone, 512 workgroups", time_ms(0, reps, [&] { CK(launch_pack_kbits_ring_u8(x8, ld8, v, n, k1[1], flag, 0, nblk, 2 * num_cu, 8)); }));
+  {  // the same tile with rows padded to a multiple of 16 bytes: is it the alignment of the 16-byte lane accesses?
+    const int64_t ld16 = (n + 15) / 16 * 16;
+    uint8_t* x16;
+    CK(hipMalloc(&x16, (size_t)(v * ld16)));
+    hipLaunchKernelGGL(to_u8_kernel, dim3(8192), dim3(256), 0, 0, x, x16, v, (int64_t)n, ld, ld16);
+    line("u8 ring pre-pass alone, 256 workgroups, ld % 16 == 0", time_ms(0, reps, [&] { CK(launch_pack_kbits_ring_u8(x16, ld16, v, n, k1[1], flag, 0, nblk, num_cu, 8)); }));
+    line("u8 ring pre-pass alone, 512 workgroups, ld % 16 == 0", time_ms(0, reps, [&] { CK(launch_pack_kbits_ring_u8(x16, ld16, v, n, k1[1], flag, 0, nblk, 2 * num_cu, 8)); }));
+    line("pack_u8x8_kbits alone, ld % 16 == 0", time_ms(0, reps, [&] { CK(launch_pack_kbits(x16, 1, ld16, v, n, k1[1], flag, 0, nblk)); }));
+    CK(hipFree(x16));
+  }
+  line("transpose_bits_kbits alone", time_ms(0, reps, [&] { CK(launch_transpose_bits_kbits(bits, ldw, v, n, k1[1], 0, nblk)); }));
+  line("contraction alone, even split 256", time_ms(0, reps, [&] { CK(launch_gram_kbits(k1[0], v, n, sb, num_cu, 0, 4)); }));
+  line("contraction alone, lock-step 220", time_ms(0, reps, [&] { CK(launch_gram_kbits(k1[0], v, n, sb, num_cu, 0, 2)); }));
+  line("serial step u8 (pack_u8x8 + even split, one stream)", time_ms(0, reps, [&] {
+         CK(launch_pack_kbits(x8, 1, ld8, v, n, k1[0], flag, 0, nblk));
+         CK(launch_gram_kbits(k1[0], v, n, sb, num_cu, 0, 4));
+       }));
+  line("serial step bits (transpose + even split, one stream)", time_ms(0, reps, [&] {
+         CK(launch_transpose_bits_kbits(bits, ldw, v, n, k1[0], 0, nblk));
+         CK(launch_gram_kbits(k1[0], v, n, sb, num_cu, 0, 4));
+       }));
+  hipStream_t ps, gs;
+  CK(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+  CK(hipStreamCreateWithFlags(&gs, hipStreamNonBlocking));
+  const int K = 12;
+  hipEvent_t packed[2], consumed[2], pe[K][2], ge[K][2];
+  for (int b = 0; b < 2; ++b) {
+    CK(hipEventCreateWithFlags(&packed[b], hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&consumed[b], hipEventDisableTiming));
+  }
+  for (int k = 0; k < K; ++k)
+    for (int j = 0; j < 2; ++j) { CK(hipEventCreate(&pe[k][j])); CK(hipEventCreate(&ge[k][j])); }
+  // kind: 2 = pack_u8x8 (shipped), 3 = u8 ring with `wgs` workgroups, 4 = bitset transpose
+  auto pipeline = [&](const char* what, int kind, int wgs, int gram_mode, int gram_cus, int delay_us) {
+    double best = 1e30, bp = 0, bg = 0;
+    for (int round = 0; round < 3; ++round) {
+      CK(hipDeviceSynchronize());
+      const double t0 = now_ms();
+      for (int k = 0; k < K; ++k) {
+        const int b = k & 1;
+        if (k >= 2) CK(hipStreamWaitEvent(ps, consumed[b], 0));
+        if (k >= 1 && delay_us > 0) hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, ps, (long long)delay_us * 100);
+        CK(hipEventRecord(pe[k][0], ps));
+        if (kind == 2) CK(launch_pack_kbits(x8, 1, ld8, v, n, k1[b], flag, ps, nblk));
+        else if (kind == 3) CK(launch_pack_kbits_ring_u8(x8, ld8, v, n, k1[b], flag, ps, nblk, wgs, 8));
+        else CK(launch_transpose_bits_kbits(bits, ldw, v, n, k1[b], ps, nblk));
+        CK(hipEventRecord(pe[k][1], ps));
+        CK(hipEventRecord(packed[b], ps));
+        CK(hipStreamWaitEvent(gs, packed[b], 0));
+        CK(hipEventRecord(ge[k][0], gs));
+        CK(launch_gram_kbits(k1[b], v, n, sb, gram_cus, gs, gram_mode));
+        CK(hipEventRecord(ge[k][1], gs));
+        CK(hipEventRecord(consumed[b], gs));
+      }
+      CK(hipDeviceSynchronize());
+      const double t = (now_ms() - t0) / K;
+      double sp = 0, sg = 0;
+      for (int k = 2; k < K - 1; ++k) {
+        float a = 0, c = 0;
+        CK(hipEventElapsedTime(&a, pe[k][0], pe[k][1]));
+        CK(hipEventElapsedTime(&c, ge[k][0], ge[k][1]));
+        sp += a; sg += c;
+      }
+      if (t < best) { best = t; bp = sp / (K - 3); bg = sg / (K - 3); }
+    }
+    std::printf("pipe  %-74s %8.3f ms per step (%.0f M variants/s); inside: pre-pass %.3f ms, contraction %.3f ms\n", what, best,
+                v / best / 1e3, bp, bg);
+  };
+  pipeline("u8: pack_u8x8 (184 VGPRs, cannot share a CU) || even split 256", 2, 0, 4, num_cu, 10);
+  pipeline("u8: pack_u8x8 || lock-step 220 (36 CUs free)", 2, 0, 2, num_cu, 10);
+  pipeline("u8 CO-RESIDENT: u8 ring, 256 wgs || lock-step 220", 3, num_cu, 2, num_cu, 10);
+  pipeline("u8 CO-RESIDENT: u8 ring, 256 wgs || even split 256", 3, num_cu, 4, num_cu, 10);
+  pipeline("u8 CO-RESIDENT: u8 ring, 128 wgs || even split 256", 3, num_cu / 2, 4, num_cu, 10);
+  pipeline("bits CO-RESIDENT: transpose (68 VGPRs) || lock-step 220", 4, 0, 2, num_cu, 10);
+  pipeline("bits CO-RESIDENT: transpose || even split 256", 4, 0, 4, num_cu, 10);
+  pipeline("bits CO-RESIDENT: transpose || even split 256, no head start", 4, 0, 4, num_cu, 0);
+  // S through the co-resident u8 pipeline == S of the serial path
+  CK(hipMemset(sa, 0, (size_t)n * n * 4));
+  CK(launch_pack_kbits(x8, 1, ld8, v, n, k1[0], flag, 0, nblk));
+  CK(launch_gram_kbits(k1[0], v, n, sa, num_cu, 0, 4));
+  CK(hipMemset(sb, 0, (size_t)n * n * 4));
+  CK(launch_pack_kbits_ring_u8(x8, ld8, v, n, k1[1], flag, 0, nblk, num_cu, 8));
+  CK(launch_gram_kbits(k1[1], v, n, sb, num_cu, 0, 2));
+  CK(hipDeviceSynchronize());
+  {
+    const unsigned long long d = count_diff(sa, sb, (int64_t)n * n * 4, cnt);
+    std::printf("S(u8 ring, lock-step) vs S(pack_u8x8, even split): %s (%llu entries differ)\n", d ? "MISMATCH" : "bit-identical", d);
+    bad += d != 0;
+  }
+  std::printf("%s\n", bad ? "RESULT: FAILED" : "RESULT: ok");
+  return bad ? 1 : 0;
+}
+
 int main(int argc, char** argv) {
   int n = 2504, reps = 5;
-  bool pipe_study = false, coreside = false;
+  bool pipe_study = false, coreside = false, coreside_alt = false;
   int64_t v = (int64_t)1 << 20;
   for (int i = 1; i < argc; ++i) {
     if (!std::strcmp(argv[i], "--n") && i + 1 < argc) n = std::atoi(argv[++i]);
@@ -541,6 +720,7 @@ int main(int argc, char** argv) {
     if (!std::strcmp(argv[i], "--reps") && i + 1 < argc) reps = std::atoi(argv[++i]);
     if (!std::strcmp(argv[i], "--pipe-study")) pipe_study = true;
     if (!std::strcmp(argv[i], "--coreside")) coreside = true;
+    if (!std::strcmp(argv[i], "--coreside-alt")) coreside_alt = true;
   }
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
@@ -551,6 +731,7 @@ int main(int argc, char** argv) {
 
   if (pipe_study) return pipe_study_main(n, v, reps, num_cu);
   if (coreside) return coreside_main(n, v, reps, num_cu, cnt);
+  if (coreside_alt) return coreside_alt_main(n, v, reps, num_cu, cnt);
   int bad = 0;
   bad += small_case(1000, 777, 1003, 0x30000000u, num_cu, cnt);   // odd stride: generic paths
   bad += small_case(1000, 4100, 1000, 0x08000000u, num_cu, cnt);  // vector paths, several blocks
