@@ -635,7 +635,7 @@ int fp4_launch(pcoa_ctx* c, int bi, bool overlapped, int side_kind = 1) {
     hipError_t e = hipErrorInvalidValue;
     if (c->op_fmt == 2) {
       // k-bits: beside the pre-pass an even split over `pipe_gram_cus` workgroups, else the whole-chip form chosen in fp4_setup
-      // (beside the short bitset transpose the even split wins: 1.07 vs 1.11 ms per step, profiles/r04d)
+      // (beside the short bitset transpose the even split wins: 1.07 vs 1.11 ms per step, profiles/r03zd)
       const int mode = side ? ((c->coreside && side_kind != 3) ? c->coreside_mode : 4) : c->kbits_mode;
       e = launch_gram_kbits(b.p, b.kb * 32, c->n, c->s32, cus, gs, mode, skip, strip_of(c));
       if (e != hipSuccess && mode != 0) {

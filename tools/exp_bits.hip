@@ -531,7 +531,7 @@ static int coreside_main(int n, int64_t v, int reps, int num_cu, unsigned long l
   return bad ? 1 : 0;
 }
 
-// ---- --coreside-alt (r04d): the uint8 and bitset boundaries with their pre-pass beside the contraction -------------------------
+// ---- --coreside-alt (r03zd): the uint8 and bitset boundaries with their pre-pass beside the contraction -------------------------
 static int u8_ring_case(int n, int64_t v, int64_t ld8, uint32_t thr, int wgs, unsigned long long* cnt, int32_t* flag) {
   const int npad = (int)gram_packed_npad(n);
   const int64_t nblk = gram_kb_pad(v, 2) / 4;

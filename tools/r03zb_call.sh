@@ -1,12 +1,12 @@
-OUT=gpurun_out/r04b; mkdir -p $OUT
+OUT=gpurun_out/r03zb; mkdir -p $OUT
 export TMPDIR=/tmp
 # 1. PMC passes of the driver's command (co-resident default)
-bash tools/gpu_round.sh r04b pmc
+bash tools/gpu_round.sh r03zb pmc
 # 2. kernel trace with timestamps: gaps between consecutive pre-passes
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OLDPWD/$OUT/prof -o trace -- python $OLDPWD/bench.py --gpus 1 --steps 20 --warmup 5 --no-extras --no-cpu-baseline --pcoa-reps 1 > $OLDPWD/$OUT/prof_bench.json 2> $OLDPWD/$OUT/prof.err; echo "prof exit $?" | tee -a $OLDPWD/$OUT/summary.txt )
-python - <<'PY' | tee -a gpurun_out/r04b/summary.txt
+python - <<'PY' | tee -a gpurun_out/r03zb/summary.txt
 import csv, glob
-f = glob.glob("gpurun_out/r04b/prof/**/*kernel_trace.csv", recursive=True)
+f = glob.glob("gpurun_out/r03zb/prof/**/*kernel_trace.csv", recursive=True)
 rows = list(csv.DictReader(open(f[0])))
 ev = []
 for r in rows:

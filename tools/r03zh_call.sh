@@ -1,4 +1,4 @@
-OUT=gpurun_out/r04h; mkdir -p $OUT
+OUT=gpurun_out/r03zh; mkdir -p $OUT
 export TMPDIR=/tmp
 date > $OUT/summary.txt
 ( timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 800 --durations=8 > $OUT/tests.log 2>&1; echo "tests exit $?" | tee -a $OUT/summary.txt )
