@@ -484,6 +484,7 @@ int fold_if_needed(pcoa_ctx* c, int64_t cur) {
 constexpr int64_t kBatchVariants = (int64_t)1 << 22;   // variants per FP4 contraction launch (fp32 exact below 2^24)
 constexpr int64_t kBatchBytes = (int64_t)6 << 30;      // cap of an FP4 operand buffer
 constexpr int64_t kPipeVariants = (int64_t)1 << 20;    // buffer size where two buffers alternate (pipeline / lock-step)
+constexpr int64_t kCoresideMaxNpad = 8192;             // co-resident pipeline: largest padded sample count (measured up to here)
 
 int64_t fp4_kb_bytes(const pcoa_ctx* c) { return gram_packed_npad(c->n) * (c->op_fmt == 2 ? 4 : 16); }
 // k-blocks (of 32 variants) a chunk of nv variants takes in the operand buffer
@@ -574,8 +575,15 @@ int fp4_setup(pcoa_ctx* c) {
   const int lsh = gram_lockstep_splitk(c->n, half);
   // (worth it whenever the contraction is a real share of the step: from ~5 tile columns, N > 1024)
   bool want = !c->is_strip && c->num_cu >= 64 && lsh > 0 && gram_packed_npad(c->n) >= 5 * 256;
+  // the co-resident form (k-bits operand) does not need a lock-step launch that fits half the chip: any N whose contraction
+  // is a real share of the step, up to kCoresideMaxNpad: +25 % at N = 3,072, +30 % at 4,096, +23 % at 8,192 over the serial
+  // order, which is what these N had before (profiles/r03zi_coreside_large_n.txt)
+  const int64_t cores_max = k.kbits_coreside_max_npad > 0 ? k.kbits_coreside_max_npad : kCoresideMaxNpad;
+  const bool cores_shape = !c->is_strip && c->num_cu >= 64 && c->op_fmt == 2 && k.kbits_coreside != 0 &&
+                           gram_packed_npad(c->n) >= 5 * 256 && gram_packed_npad(c->n) <= cores_max;
+  want = want || cores_shape;
   if (k.pipeline == 0) want = false;
-  if (k.pipeline == 1) want = !c->is_strip && lsh > 0;
+  if (k.pipeline == 1) want = !c->is_strip && (lsh > 0 || cores_shape);
   if (c->flags & PCOA_FLAG_NO_PIPELINE) want = false;
   if (want) {
     hipError_t e1 = hipStreamCreateWithFlags(&c->pack_stream, hipStreamNonBlocking);
@@ -593,7 +601,7 @@ int fp4_setup(pcoa_ctx* c) {
         c->coreside = true;
         // (lock-step only where it fills >= 80 % of the CUs: at N = 2048 it has 144 workgroups and the co-resident step
         // loses to the disjoint form, 1.87 vs 1.65 ms, profiles/r03y; the even split always has one workgroup per CU)
-        c->coreside_mode = (ls > 0 && gram_lockstep_workgroups(c->n, ls) * 5 >= c->num_cu * 4 && k.kbits_mode != 4) ? 2 : 4;
+        c->coreside_mode = (ls > 0 && gram_lockstep_workgroups(c->n, ls) * 5 >= c->num_cu * 4 && k.kbits_mode != 4) ? 2 : c->kbits_mode;
         if (k.kbits_mode == 2 && ls > 0) c->coreside_mode = 2;
         c->pipe_gram_cus = c->num_cu;
         c->ring_wgs = (k.kbits_ring_wgs > 0) ? k.kbits_ring_wgs : 2 * c->num_cu;
@@ -636,7 +644,7 @@ int fp4_launch(pcoa_ctx* c, int bi, bool overlapped, int side_kind = 1) {
     if (c->op_fmt == 2) {
       // k-bits: beside the pre-pass an even split over `pipe_gram_cus` workgroups, else the whole-chip form chosen in fp4_setup
       // (beside the short bitset transpose the even split wins: 1.07 vs 1.11 ms per step, profiles/r03zd)
-      const int mode = side ? ((c->coreside && side_kind != 3) ? c->coreside_mode : 4) : c->kbits_mode;
+      const int mode = !side ? c->kbits_mode : !c->coreside ? 4 : (side_kind == 3 ? c->kbits_mode : c->coreside_mode);
       e = launch_gram_kbits(b.p, b.kb * 32, c->n, c->s32, cus, gs, mode, skip, strip_of(c));
       if (e != hipSuccess && mode != 0) {
         (void)hipGetLastError();
@@ -1154,6 +1162,7 @@ const DebugKnobs& debug_knobs() {
     k.kbits_pipe_wgs = (int)num("PCOA_KBITS_PIPE_WGS");
     if (const char* v = std::getenv("PCOA_KBITS_CORESIDE")) k.kbits_coreside = std::atoi(v) != 0;
     k.kbits_ring_wgs = (int)num("PCOA_KBITS_RING_WGS");
+    k.kbits_coreside_max_npad = (int)num("PCOA_KBITS_CORESIDE_MAX_NPAD");
     k.gram_cfg = (int)num("PCOA_GRAM_I8_CFG");
     k.gram_splitk = (int)num("PCOA_GRAM_I8_SPLITK");
     return k;

@@ -37,6 +37,7 @@ struct DebugKnobs {
   int kbits_pipe_wgs = 0;          // PCOA_KBITS_PIPE_WGS: workgroups of the k-bits contraction beside the fp32 pre-pass
   int kbits_coreside = -1;         // PCOA_KBITS_CORESIDE = 0 | 1: fp32 pipeline with pre-pass and contraction on the SAME CUs (ring pre-pass)
   int kbits_ring_wgs = 0;          // PCOA_KBITS_RING_WGS: workgroups of the ring pre-pass beside a contraction (default 2 per CU)
+  int kbits_coreside_max_npad = 0; // PCOA_KBITS_CORESIDE_MAX_NPAD: largest padded sample count the co-resident pipeline is used for
 };
 const DebugKnobs& debug_knobs();
 

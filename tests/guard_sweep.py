@@ -139,7 +139,7 @@ def one_case(seed, idx):
 
 def ring_case(seed, idx):
     rng = np.random.default_rng(seed)
-    n = int(rng.choice([1025, 1279, 1280, 1281, 1536, 2504])) if rng.random() < 0.6 else int(rng.integers(1025, 2600))
+    n = int(rng.choice([1025, 1279, 1280, 1281, 1536, 2504, 2561, 3000, 4100])) if rng.random() < 0.7 else int(rng.integers(1025, 2600))
     ld = (n + 3) // 4 * 4 + 4 * int(rng.integers(0, 3))       # ring_ok: stride a multiple of 4 floats
     calls = [int(rng.choice([127, 129, 1000, 2049, 4097, 5000])) for _ in range(int(rng.integers(3, 7)))]
     dens = float(rng.choice([0.02, 0.2, 0.6]))
