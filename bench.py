@@ -418,8 +418,10 @@ def main():
             gs = ts["gram_kernel_seconds"] / max(int(ts["gram_kernel_launches"]), 1)
             gv = ts["gram_variants"] / max(int(ts["gram_kernel_launches"]), 1)
             out["roofline_standalone"] = {
-                "note": "the same two kernels without the pipeline (PCOA_FLAG_NO_PIPELINE engine, 3 steps): each alone on all %d "
-                        "CUs; ms_per_step is what the serial order costs on this box" % cus,
+                "note": "pre-pass and contraction without the pipeline (PCOA_FLAG_NO_PIPELINE engine, 3 steps): each alone on all "
+                        "%d CUs -- the pre-pass as pack_kbits_kernel (the ring form only runs beside a contraction; alone the two "
+                        "are equally fast, profiles/r03s..w), the contraction as the even-split launch; ms_per_step is what the "
+                        "serial order costs on this box" % cus,
                 "ms_per_step": 1e3 * dts / 3, "variants_per_s": 3 * vs / dts,
                 "pre_pass": {"bound": "hbm", "avg_launch_ms": 1e3 * ps, "achieved": 4.0 * vs * n / ps / 1e9, "peak": PEAK_HBM_GBS,
                              "unit": "GB/s", "frac": 4.0 * vs * n / ps / 1e9 / PEAK_HBM_GBS,
