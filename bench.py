@@ -321,7 +321,7 @@ def main():
                          "traffic": (pmc["pack_hbm_bytes_per_mvariants"] * (tim["gram_variants"] / pl) / 1e6
                                      if "pack_hbm_bytes_per_mvariants" in pmc else pmc.get("pack_hbm_bytes_per_launch")),
                          "traffic_source": pmc_src,
-                         "kernel": (("pack_kbits_ring_kernel<8, 2, 0>" if info.get("co_resident") else
+                         "kernel": (("pack_kbits_ring_kernel<8, 0, 0>" if info.get("co_resident") else
                                      "pack_kbits_kernel<float, 4, true>") if kbits else "pack_fp4_kernel<float, 4, true>")
                          if kind == 3 else "pack_f32_i8_kernel<4>",
                          "avg_launch_ms": 1e3 * pack_s, "launches": pl}

@@ -954,8 +954,9 @@ hipError_t launch_pack_kbits(const void* x, int is_u8, int64_t ld, int64_t nv, i
 }
 
 // Persistent LDS-DMA-ring pre-pass (fp32 tile, pack_fp4_ring_ok(x, ld)): at most `wgs` workgroups of 4 waves.
-// ring = R + 100 * nontemporal + 1000 * (waves at s_setprio 3); the product uses 108 (R = 8 rows in flight per wave,
-// nontemporal loads), everything else is a harness knob.
+// ring = R + 100 * nontemporal + 1000 * (waves at s_setprio 3); the product uses 8 (R = 8 rows in flight per wave, default
+// cache policy: beside the contraction, with two workgroups per CU, 2.19 vs 2.25 ms per step for nontemporal loads --
+// which win when the kernel has the chip to itself or one workgroup per CU, profiles/r03zl), the rest are harness knobs.
 hipError_t launch_pack_kbits_ring(const float* x, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
                                   hipStream_t stream, int64_t nblk_out, int wgs, int ring) {
   if (nv <= 0) return hipSuccess;
@@ -972,6 +973,17 @@ hipError_t launch_pack_kbits_ring(const float* x, int64_t ld, int64_t nv, int32_
                      (int)units, pw, flag)
   ring %= 10000;  // (+ 10000 selected the natural bit order while a permuted form existed, r03w)
 #ifdef PCOA_EXPERIMENTS
+  if (ring >= 5000) {  // 5000 + aux: R = 8, the cache-policy bits of the LDS-DMA given directly (sc0 = 1, nt = 2, sc1 = 16)
+    switch (ring - 5000) {
+      case 1: PCOA_RINGK(8, 1, 0); break;
+      case 3: PCOA_RINGK(8, 3, 0); break;
+      case 16: PCOA_RINGK(8, 16, 0); break;
+      case 17: PCOA_RINGK(8, 17, 0); break;
+      case 18: PCOA_RINGK(8, 18, 0); break;
+      default: PCOA_RINGK(8, 0, 0); break;
+    }
+    return hipGetLastError();
+  }
   const int R = ring % 100, nt = (ring / 100) % 10, prio = ring / 1000;
 #define PCOA_RINGK2(R_)                                                       \
   do {                                                                        \
@@ -985,8 +997,8 @@ hipError_t launch_pack_kbits_ring(const float* x, int64_t ld, int64_t nv, int32_
   else PCOA_RINGK2(16);
 #undef PCOA_RINGK2
 #else
-  if (ring % 100 == 16) PCOA_RINGK(16, 2, 0);
-  else PCOA_RINGK(8, 2, 0);
+  if ((ring / 100) % 10) PCOA_RINGK(8, 2, 0);
+  else PCOA_RINGK(8, 0, 0);
 #endif
 #undef PCOA_RINGK
   return hipGetLastError();

@@ -497,7 +497,7 @@ hipError_t launch_pack_operand(const pcoa_ctx* c, const void* x, int is_u8, int6
                                hipStream_t s, int64_t kb, int ring_wgs = 0) {
   // ring_wgs > 0: the persistent ring pre-pass of the co-resident fp32 pipeline (fp32 tile, k-bits operand, ring_ok checked)
   if (ring_wgs > 0 && c->op_fmt == 2 && !is_u8)
-    return launch_pack_kbits_ring(static_cast<const float*>(x), ld, nv, c->n, dst, flag, s, kb / 4, ring_wgs, 108);
+    return launch_pack_kbits_ring(static_cast<const float*>(x), ld, nv, c->n, dst, flag, s, kb / 4, ring_wgs, 8);
   if (ring_wgs > 0 && c->op_fmt == 2 && is_u8)
     return launch_pack_kbits_ring_u8(static_cast<const uint8_t*>(x), ld, nv, c->n, dst, flag, s, kb / 4, ring_wgs, 108);
   return c->op_fmt == 2 ? launch_pack_kbits(x, is_u8, ld, nv, c->n, dst, flag, s, kb / 4)

@@ -85,8 +85,8 @@ hipError_t launch_transpose_bits_kbits(const uint32_t* bits, int64_t ld_words, i
 hipError_t launch_densify_csr_kbits(const int32_t* idx_dev, const int64_t* offs_dev, int64_t nv, int64_t offs_base,
                                     int8_t* p, int32_t n, int32_t* flag, hipStream_t stream, int64_t nblk_out);
 bool pack_fp4_ring_ok(const void* x, int64_t ld);
-// persistent LDS-DMA-ring form of the fp32 -> k-bits pre-pass (needs pack_fp4_ring_ok): <= wgs workgroups; ring: 108 = 8 rows
-// in flight per wave, nontemporal (default), 116 = 16 rows
+// persistent LDS-DMA-ring form of the fp32 -> k-bits pre-pass (needs pack_fp4_ring_ok): <= wgs workgroups; ring: 8 = 8 rows
+// in flight per wave, default cache policy (what the library uses), 108 = nontemporal loads
 hipError_t launch_pack_kbits_ring(const float* x, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,
                                   hipStream_t stream, int64_t nblk_out, int wgs, int ring);
 hipError_t launch_pack_fp4_ring(const float* x, int64_t ld, int64_t nv, int32_t n, int8_t* p, int32_t* flag,

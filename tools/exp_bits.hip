@@ -378,7 +378,7 @@ static int coreside_main(int n, int64_t v, int reps, int num_cu, unsigned long l
   CK(launch_pack_kbits(x, 0, ld, v, n, k1[0], flag, 0, nblk));
   CK(hipDeviceSynchronize());
   int bad = 0;
-  for (int ring : {108, 116, 8, 16, 1108}) {
+  for (int ring : {108, 116, 8, 5016, 5018, 5001}) {
     CK(hipMemset(k1[1], 0xa5, kbytes));
     CK(launch_pack_kbits_ring(x, ld, v, n, k1[1], flag, 0, nblk, num_cu, ring));
     CK(hipDeviceSynchronize());
@@ -433,7 +433,7 @@ static int coreside_main(int n, int64_t v, int reps, int num_cu, unsigned long l
   const double mv = (double)v / 1e6;
   auto line = [&](const char* what, float ms) { std::printf("time  %-66s %8.3f ms  (%.3f ms per 10^6 variants)\n", what, ms, ms / mv); };
   line("pack_kbits<float> (shipped) alone", time_ms(0, reps, [&] { CK(launch_pack_kbits(x, 0, ld, v, n, k1[1], flag, 0, nblk)); }));
-  for (int ring : {108, 8, 116, 16})
+  for (int ring : {108, 5000, 5016, 5001})
     line(("ring pre-pass alone, 256 workgroups, ring " + std::to_string(ring)).c_str(),
          time_ms(0, reps, [&] { CK(launch_pack_kbits_ring(x, ld, v, n, k1[1], flag, 0, nblk, num_cu, ring)); }));
   line("ring pre-pass alone, 512 workgroups, ring 108", time_ms(0, reps, [&] { CK(launch_pack_kbits_ring(x, ld, v, n, k1[1], flag, 0, nblk, 2 * num_cu, 108)); }));
@@ -517,10 +517,16 @@ static int coreside_main(int n, int64_t v, int reps, int num_cu, unsigned long l
   pipeline("shipped: pack_kbits || even split 128 (disjoint CUs)", 0, 128, -1, 0, 10);
   struct Cfg { const char* what; int var, mode, cus, ring, wgs; };
   const Cfg cfgs[] = {
-      {"CO-RESIDENT: ring R8 nt, 512 wgs || lock-step 220", 5, 2, 256, 108, 512},
-      {"CO-RESIDENT: ring R8 nt, 512 wgs || even split 256", 5, 4, 256, 108, 512},
-      {"CO-RESIDENT: ring R8 nt, 512 wgs || lock-step 220 (again)", 5, 2, 256, 108, 512},
-      {"CO-RESIDENT: ring R8 nt, 512 wgs || lock-step 220, contraction ring 4", 6, 2, 256, 108, 512},
+      {"CO-RESIDENT: ring R8 aux 0 (default policy), 512 wgs || lock-step 220", 5, 2, 256, 5000, 512},
+      {"CO-RESIDENT: ring R8 aux 2 (nt), 512 wgs || lock-step 220", 5, 2, 256, 108, 512},
+      {"CO-RESIDENT: ring R8 aux 1 (sc0), 512 wgs || lock-step 220", 5, 2, 256, 5001, 512},
+      {"CO-RESIDENT: ring R8 aux 3 (sc0 nt), 512 wgs || lock-step 220", 5, 2, 256, 5003, 512},
+      {"CO-RESIDENT: ring R8 aux 16 (sc1), 512 wgs || lock-step 220", 5, 2, 256, 5016, 512},
+      {"CO-RESIDENT: ring R8 aux 17 (sc0 sc1), 512 wgs || lock-step 220", 5, 2, 256, 5017, 512},
+      {"CO-RESIDENT: ring R8 aux 18 (sc1 nt), 512 wgs || lock-step 220", 5, 2, 256, 5018, 512},
+      {"CO-RESIDENT: ring R8 aux 0 (default policy), 512 wgs || lock-step 220 (again)", 5, 2, 256, 5000, 512},
+      {"CO-RESIDENT: ring R8 aux 0, 512 wgs || even split 256", 5, 4, 256, 5000, 512},
+      {"CO-RESIDENT: ring R8 aux 0, 768 wgs || lock-step 220", 5, 2, 256, 5000, 768},
   };
   for (const Cfg& c : cfgs) {
     gram_mode = c.mode;
