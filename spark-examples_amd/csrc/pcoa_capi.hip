@@ -484,7 +484,7 @@ int fold_if_needed(pcoa_ctx* c, int64_t cur) {
 constexpr int64_t kBatchVariants = (int64_t)1 << 22;   // variants per FP4 contraction launch (fp32 exact below 2^24)
 constexpr int64_t kBatchBytes = (int64_t)6 << 30;      // cap of an FP4 operand buffer
 constexpr int64_t kPipeVariants = (int64_t)1 << 20;    // buffer size where two buffers alternate (pipeline / lock-step)
-constexpr int64_t kCoresideMaxNpad = 8192;             // co-resident pipeline: largest padded sample count (measured up to here)
+constexpr int64_t kCoresideMaxNpad = 16384;            // co-resident pipeline: largest padded sample count (measured up to here)
 
 int64_t fp4_kb_bytes(const pcoa_ctx* c) { return gram_packed_npad(c->n) * (c->op_fmt == 2 ? 4 : 16); }
 // k-blocks (of 32 variants) a chunk of nv variants takes in the operand buffer
@@ -577,7 +577,8 @@ int fp4_setup(pcoa_ctx* c) {
   bool want = !c->is_strip && c->num_cu >= 64 && lsh > 0 && gram_packed_npad(c->n) >= 5 * 256;
   // the co-resident form (k-bits operand) does not need a lock-step launch that fits half the chip: any N whose contraction
   // is a real share of the step, up to kCoresideMaxNpad: +25 % at N = 3,072, +30 % at 4,096, +23 % at 8,192 over the serial
-  // order, which is what these N had before (profiles/r03zi_coreside_large_n.txt)
+  // order, which is what these N had before, +8 .. 9 % at N = 10,240 .. 16,384 where the contraction dominates
+  // (profiles/r03zi_coreside_large_n.txt, r03zn_coreside_n10k_16k.txt)
   const int64_t cores_max = k.kbits_coreside_max_npad > 0 ? k.kbits_coreside_max_npad : kCoresideMaxNpad;
   const bool cores_shape = !c->is_strip && c->num_cu >= 64 && c->op_fmt == 2 && k.kbits_coreside != 0 &&
                            gram_packed_npad(c->n) >= 5 * 256 && gram_packed_npad(c->n) <= cores_max;
