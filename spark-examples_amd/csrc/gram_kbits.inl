@@ -22,14 +22,20 @@
 // ---------------------------------------------------------------------------------------------- pre-passes -> K1
 // fp32 / uint8 tile -> k-bits; verifies that every value is exactly 0 or 1 (flag bit 3), like pack_fp4_kernel.
 // One thread: 128 variants x 4 samples, in 8 batches of 16 rows (all 16 loads of a batch issued before the arithmetic).
-template <typename T, int VEC, bool NT = false>
+// CS (small calls): a wave takes ONE of the four 32-variant words of its samples instead of all four -- 4x the waves, each a
+// quarter as long; a 4,096-variant call is 320 waves of 8 dependent load batches otherwise, on a chip with 5,000 wave slots
+// (256 x 4,096-variant calls: 106 M variants/s with the k-bits operand against 155 with the FP4 one, whose pre-pass had
+// 32-variant units).
+template <typename T, int VEC, bool NT = false, bool CS = false>
 __global__ __launch_bounds__(256) void pack_kbits_kernel(const T* __restrict__ x, int64_t ld, int64_t nv, int n, int npad,
                                                          int64_t nblk, uint32_t* __restrict__ p,
                                                          int32_t* __restrict__ flag) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int gw = npad >> 8;  // waves per block of 128 variants
-  const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+  int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+  const int c_only = CS ? (int)(wid & 3) : -1;  // wave-uniform
+  if (CS) wid >>= 2;
   const int64_t blk = wid / gw;
   const int g = (int)(wid - blk * gw) * 64 + lane;
   if (blk >= nblk) return;
@@ -43,6 +49,7 @@ __global__ __launch_bounds__(256) void pack_kbits_kernel(const T* __restrict__ x
     for (int q = 0; q < 4; ++q) w[s][q] = 0;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
+    if (CS && c != c_only) continue;  // (a scalar branch around the unrolled body: the register indices stay static)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       if constexpr (VEC == 4) {
@@ -98,9 +105,16 @@ __global__ __launch_bounds__(256) void pack_kbits_kernel(const T* __restrict__ x
       }
     }
   }
-  uint4* dst = reinterpret_cast<uint4*>(p + ((size_t)blk * npad + i0) * 4);
+  if constexpr (CS) {
+    uint32_t* dst = p + ((size_t)blk * npad + i0) * 4 + c_only;
 #pragma unroll
-  for (int s = 0; s < 4; ++s) dst[s] = make_uint4(w[s][0], w[s][1], w[s][2], w[s][3]);
+    for (int s = 0; s < 4; ++s)
+      dst[4 * s] = c_only == 0 ? w[s][0] : c_only == 1 ? w[s][1] : c_only == 2 ? w[s][2] : w[s][3];
+  } else {
+    uint4* dst = reinterpret_cast<uint4*>(p + ((size_t)blk * npad + i0) * 4);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) dst[s] = make_uint4(w[s][0], w[s][1], w[s][2], w[s][3]);
+  }
   if (bad || badw) atomicOr(flag, 8);
 }
 
@@ -947,7 +961,12 @@ hipError_t launch_pack_kbits(const void* x, int is_u8, int64_t ld, int64_t nv, i
   } else {
     const bool vec = ((ld & 3) == 0) && ((addr & 15) == 0);
     const float* xs = static_cast<const float*>(x);
-    if (vec) hipLaunchKernelGGL((pack_kbits_kernel<float, 4, true>), grid, block, 0, stream, xs, ld, nv, n, npad, nblk, pw, flag);
+    // small calls (fewer waves than half the chip's wave slots): one 32-variant word per wave
+    const bool small = nblk * (npad >> 8) < 2560;
+    if (vec && small)
+      hipLaunchKernelGGL((pack_kbits_kernel<float, 4, true, true>), dim3((unsigned)(nblk * (npad >> 8))), block, 0, stream, xs, ld, nv,
+                         n, npad, nblk, pw, flag);
+    else if (vec) hipLaunchKernelGGL((pack_kbits_kernel<float, 4, true>), grid, block, 0, stream, xs, ld, nv, n, npad, nblk, pw, flag);
     else hipLaunchKernelGGL((pack_kbits_kernel<float, 1>), grid, block, 0, stream, xs, ld, nv, n, npad, nblk, pw, flag);
   }
   return hipGetLastError();
