@@ -238,7 +238,8 @@ int pcoa_synth_fill_f32(pcoa_ctx* ctx, const pcoa_synth_params* params, int64_t 
                         int64_t n_variants, float* x_dev, int64_t ld);
 
 /* Completes the local accumulation: contracts what the accumulate calls have only packed so far (binary tiles
- * are re-laid out into the FP4 operand buffer when they arrive and contracted once per <= 2^22 buffered variants,
+ * are re-laid out into a packed operand buffer (1 bit per genotype by default) when they arrive and contracted when the
+ * buffer is full: 2^20 variants where two buffers alternate, never more than 2^22,
  * or here -- every reader of S below does the same), mirrors the computed triangle, folds int32 partials.
  * After it the full symmetric S of THIS ctx is readable.  Accumulation may continue afterwards
  * (S is additive: a natural checkpoint/resume point).  Inputs of the accumulate calls are consumed by their
