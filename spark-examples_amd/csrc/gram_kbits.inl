@@ -1038,8 +1038,11 @@ hipError_t launch_pack_kbits_ring_u8(const uint8_t* x, int64_t ld, int64_t nv, i
   uint32_t* pw = reinterpret_cast<uint32_t*>(p);
   const int64_t most = (units + 3) / 4;
   const dim3 grid((unsigned)(wgs > 0 && wgs < most ? wgs : most)), block(256);
-  (void)ring;  // one form: 8 rows in flight per wave, nontemporal
-  hipLaunchKernelGGL((pack_u8_kbits_ring_kernel<8, 2>), grid, block, 32 << 10, stream, x, ld, (int)nv, n, npad, (int)units, pw, flag);
+  // 8 rows in flight per wave; ring / 100 odd = nontemporal loads
+  if ((ring / 100) % 10)
+    hipLaunchKernelGGL((pack_u8_kbits_ring_kernel<8, 2>), grid, block, 32 << 10, stream, x, ld, (int)nv, n, npad, (int)units, pw, flag);
+  else
+    hipLaunchKernelGGL((pack_u8_kbits_ring_kernel<8, 0>), grid, block, 32 << 10, stream, x, ld, (int)nv, n, npad, (int)units, pw, flag);
   return hipGetLastError();
 }
 

@@ -499,7 +499,7 @@ hipError_t launch_pack_operand(const pcoa_ctx* c, const void* x, int is_u8, int6
   if (ring_wgs > 0 && c->op_fmt == 2 && !is_u8)
     return launch_pack_kbits_ring(static_cast<const float*>(x), ld, nv, c->n, dst, flag, s, kb / 4, ring_wgs, 8);
   if (ring_wgs > 0 && c->op_fmt == 2 && is_u8)
-    return launch_pack_kbits_ring_u8(static_cast<const uint8_t*>(x), ld, nv, c->n, dst, flag, s, kb / 4, ring_wgs, 108);
+    return launch_pack_kbits_ring_u8(static_cast<const uint8_t*>(x), ld, nv, c->n, dst, flag, s, kb / 4, ring_wgs, 8);
   return c->op_fmt == 2 ? launch_pack_kbits(x, is_u8, ld, nv, c->n, dst, flag, s, kb / 4)
                         : launch_pack_fp4(x, is_u8, ld, nv, c->n, dst, flag, s, kb);
 }

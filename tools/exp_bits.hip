@@ -553,7 +553,7 @@ static int u8_ring_case(int n, int64_t v, int64_t ld8, uint32_t thr, int wgs, un
   hipLaunchKernelGGL(to_u8_kernel, dim3(1024), dim3(256), 0, 0, xf, x8, v, (int64_t)n, (int64_t)n, ld8);
   CK(launch_pack_kbits(x8, 1, ld8, v, n, ka, flag, 0, nblk));
   CK(hipMemset(kb, 0x5a, kbytes));
-  CK(launch_pack_kbits_ring_u8(x8, ld8, v, n, kb, flag, 0, nblk, wgs, 8));
+  CK(launch_pack_kbits_ring_u8(x8, ld8, v, n, kb, flag, 0, nblk, wgs, (n & 1) ? 8 : 108));
   CK(hipDeviceSynchronize());
   const unsigned long long d = count_diff(ka, kb, (int64_t)kbytes, cnt);
   std::printf("u8 ring pre-pass n=%d v=%lld ld=%lld (%d workgroups) vs pack_kbits<uint8>: %s (%llu words differ)\n", n, (long long)v,
@@ -667,7 +667,8 @@ static int coreside_alt_main(int n, int64_t v, int reps, int num_cu, unsigned lo
         if (k >= 1 && delay_us > 0) hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, ps, (long long)delay_us * 100);
         CK(hipEventRecord(pe[k][0], ps));
         if (kind == 2) CK(launch_pack_kbits(x8, 1, ld8, v, n, k1[b], flag, ps, nblk));
-        else if (kind == 3) CK(launch_pack_kbits_ring_u8(x8, ld8, v, n, k1[b], flag, ps, nblk, wgs, 8));
+        else if (kind == 3) CK(launch_pack_kbits_ring_u8(x8, ld8, v, n, k1[b], flag, ps, nblk, wgs, 108));
+        else if (kind == 5) CK(launch_pack_kbits_ring_u8(x8, ld8, v, n, k1[b], flag, ps, nblk, wgs, 8));
         else CK(launch_transpose_bits_kbits(bits, ldw, v, n, k1[b], ps, nblk));
         CK(hipEventRecord(pe[k][1], ps));
         CK(hipEventRecord(packed[b], ps));
@@ -693,7 +694,11 @@ static int coreside_alt_main(int n, int64_t v, int reps, int num_cu, unsigned lo
   };
   pipeline("u8: pack_u8x8 (184 VGPRs, cannot share a CU) || even split 256", 2, 0, 4, num_cu, 10);
   pipeline("u8: pack_u8x8 || lock-step 220 (36 CUs free)", 2, 0, 2, num_cu, 10);
-  pipeline("u8 CO-RESIDENT: u8 ring, 256 wgs || lock-step 220", 3, num_cu, 2, num_cu, 10);
+  pipeline("u8 CO-RESIDENT: u8 ring nt, 256 wgs || lock-step 220", 3, num_cu, 2, num_cu, 10);
+  pipeline("u8 CO-RESIDENT: u8 ring default policy, 256 wgs || lock-step 220", 5, num_cu, 2, num_cu, 10);
+  pipeline("u8 CO-RESIDENT: u8 ring nt, 256 wgs || lock-step 220 (again)", 3, num_cu, 2, num_cu, 10);
+  pipeline("u8 CO-RESIDENT: u8 ring default policy, 256 wgs || lock-step 220 (again)", 5, num_cu, 2, num_cu, 10);
+  pipeline("u8 CO-RESIDENT: u8 ring default policy, 256 wgs || even split 256", 5, num_cu, 4, num_cu, 10);
   pipeline("u8 CO-RESIDENT: u8 ring, 256 wgs || even split 256", 3, num_cu, 4, num_cu, 10);
   pipeline("u8 CO-RESIDENT: u8 ring, 128 wgs || even split 256", 3, num_cu / 2, 4, num_cu, 10);
   pipeline("bits CO-RESIDENT: transpose (68 VGPRs) || lock-step 220", 4, 0, 2, num_cu, 10);
