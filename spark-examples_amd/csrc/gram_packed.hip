@@ -1182,6 +1182,9 @@ __global__ __launch_bounds__(64 * NWM * (8 / NNI), (NNI == 2) ? 2 : 1) void gram
 #define PCOA_KBITS_KERNELS
 #include "gram_kbits.inl"
 #undef PCOA_KBITS_KERNELS
+#define PCOA_KBITS_W4_KERNELS
+#include "gram_kbits_w4.inl"
+#undef PCOA_KBITS_W4_KERNELS
 
 }  // namespace
 
@@ -1382,6 +1385,9 @@ hipError_t launch_gram_packed_lockstep(const int8_t* p, int fmt, int64_t nv, int
 #define PCOA_KBITS_LAUNCHERS
 #include "gram_kbits.inl"
 #undef PCOA_KBITS_LAUNCHERS
+#define PCOA_KBITS_W4_LAUNCHERS
+#include "gram_kbits_w4.inl"
+#undef PCOA_KBITS_W4_LAUNCHERS
 
 hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, int32_t* s32, int num_cu,
                               hipStream_t stream, int* splitk_out, const int32_t* skip, GramStrip strip) {

@@ -111,6 +111,9 @@ hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, i
 // k-bits contraction; mode 0 = split-K launch, 2 = lock-step, 4 = even split of the (tile, stage) units over num_cu workgroups
 hipError_t launch_gram_kbits(const int8_t* p, int64_t nv, int32_t n, int32_t* s32, int num_cu, hipStream_t stream, int mode,
                              const int32_t* skip = nullptr, GramStrip strip = GramStrip{});
+// the same contraction with one wave per SIMD and 128 x 128 wave tiles (gram_kbits_w4.inl); same modes
+hipError_t launch_gram_kbits_w4(const int8_t* p, int64_t nv, int32_t n, int32_t* s32, int num_cu, hipStream_t stream, int mode,
+                                const int32_t* skip = nullptr, GramStrip strip = GramStrip{});
 int gram_lockstep_splitk(int32_t n, int cus);
 int gram_lockstep_workgroups(int32_t n, int splitk);
 hipError_t launch_gram_packed_lockstep(const int8_t* p, int fmt, int64_t nv, int32_t n, int32_t* s32, int num_cu,

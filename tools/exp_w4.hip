@@ -1,0 +1,178 @@
+// exp_w4.hip -- correctness + A/B harness of the one-wave-per-SIMD k-bits contraction (spark-examples_amd/csrc/gram_kbits_w4.inl,
+// VERDICT r03 item 1).  On one MI355X, with the library's own kernels (gram_packed.hip is included):
+//   1. a random k-bits operand (density as the synthetic cohort, ~8 %) of N samples x V variants, built on the device;
+//   2. S of every w4 variant / launch mode == S of the shipped gram_kbits_kernel<3,2,2> (itself oracle-checked in tests/), bit for
+//      bit, on ragged shapes and at BASELINE configs[1] size;
+//   3. ms per launch for each.
+// Not part of the product.  Build: make -C tools exp_w4.  Prints one line per measurement.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#include "../spark-examples_amd/csrc/gram_packed.hip"
+
+namespace pcoa {
+const DebugKnobs& debug_knobs() {
+  static const DebugKnobs k;
+  return k;
+}
+}  // namespace pcoa
+using namespace pcoa;
+
+#define CK(expr)                                                                                  \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      std::fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+      std::exit(1);                                                                               \
+    }                                                                                             \
+  } while (0)
+
+// K1[blk][npad][4 words]; samples >= n and variants >= v are zero (as the pre-passes leave them)
+__global__ void fill_operand(uint32_t* k1, int64_t nblk, int npad, int n, int64_t v, uint32_t seed, uint32_t thr) {
+  const int64_t words = nblk * npad * 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (int64_t)gridDim.x * blockDim.x) {
+    const int w = (int)(i & 3);
+    const int64_t rest = i >> 2;
+    const int sample = (int)(rest % npad);
+    const int64_t blk = rest / npad;
+    uint32_t out = 0;
+    if (sample < n) {
+      for (int b = 0; b < 32; ++b) {
+        const int64_t var = blk * 128 + w * 32 + b;
+        uint32_t h = (uint32_t)(i * 32 + b) * 2654435761u ^ (uint32_t)((i * 32 + b) >> 32) * 40503u ^ seed;
+        h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+        if (var < v && h < thr) out |= 1u << b;
+      }
+    }
+    k1[i] = out;
+  }
+}
+__global__ void diff_kernel(const uint32_t* a, const uint32_t* b, int64_t words, unsigned long long* out) {
+  unsigned long long d = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (int64_t)gridDim.x * blockDim.x)
+    d += (a[i] != b[i]);
+  if (d) atomicAdd(out, d);
+}
+static unsigned long long count_diff(const void* a, const void* b, int64_t bytes, unsigned long long* cnt) {
+  CK(hipMemset(cnt, 0, 8));
+  hipLaunchKernelGGL(diff_kernel, dim3(2048), dim3(256), 0, 0, (const uint32_t*)a, (const uint32_t*)b, bytes / 4, cnt);
+  unsigned long long h = 0;
+  CK(hipMemcpy(&h, cnt, 8, hipMemcpyDeviceToHost));
+  return h;
+}
+static float time_ms(int reps, const std::function<void()>& body) {
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b));
+  body();
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(a, 0));
+  for (int r = 0; r < reps; ++r) body();
+  CK(hipEventRecord(b, 0));
+  CK(hipEventSynchronize(b));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, a, b));
+  CK(hipEventDestroy(a));
+  CK(hipEventDestroy(b));
+  return ms / reps;
+}
+
+struct Case {
+  int n;
+  int64_t v;
+};
+
+int main(int argc, char** argv) {
+  int n = 2504, reps = 10, num_cu = 256;
+  int64_t v = 1 << 20;
+  bool small = true, big = true;
+  uint32_t thr = 0x14000000u;  // ~7.8 %
+  std::vector<int> variants = {0, 1, 2, 3};
+  for (int i = 1; i < argc; ++i) {
+    if (!std::strcmp(argv[i], "--n") && i + 1 < argc) n = std::atoi(argv[++i]);
+    if (!std::strcmp(argv[i], "--v") && i + 1 < argc) v = std::atoll(argv[++i]);
+    if (!std::strcmp(argv[i], "--reps") && i + 1 < argc) reps = std::atoi(argv[++i]);
+    if (!std::strcmp(argv[i], "--no-small")) small = false;
+    if (!std::strcmp(argv[i], "--no-big")) big = false;
+    if (!std::strcmp(argv[i], "--dense")) thr = 0x80000000u;
+    if (!std::strcmp(argv[i], "--variants") && i + 1 < argc) {
+      variants.clear();
+      for (char* t = std::strtok(argv[++i], ","); t; t = std::strtok(nullptr, ",")) variants.push_back(std::atoi(t));
+    }
+  }
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  num_cu = prop.multiProcessorCount;
+  std::printf("device %s, %d CUs\n", prop.name, num_cu);
+  unsigned long long* cnt;
+  CK(hipMalloc(&cnt, 8));
+  int fails = 0;
+
+  auto run_case = [&](int cn, int64_t cv, bool timeit) {
+    const int npad = (int)gram_packed_npad(cn);
+    const int64_t nblk = gram_kb_pad(cv, 2) / 4;
+    const int64_t kbytes = nblk * npad * 16;
+    int8_t* k1;
+    CK(hipMalloc(&k1, (size_t)kbytes + 4096));
+    hipLaunchKernelGGL(fill_operand, dim3(4096), dim3(256), 0, 0, (uint32_t*)k1, nblk, npad, cn, cv, 777u + (uint32_t)cn, thr);
+    const int64_t sbytes = (int64_t)cn * cn * 4;
+    int32_t *s_ref, *s_new;
+    CK(hipMalloc(&s_ref, (size_t)sbytes));
+    CK(hipMalloc(&s_new, (size_t)sbytes));
+    CK(hipMemset(s_ref, 0, (size_t)sbytes));
+    const int ntile = npad / 256;
+    const int ntri = ntile * (ntile + 1) / 2;
+    const int ref_mode = (ntri <= 4 * num_cu) ? 4 : 0;
+    CK(launch_gram_kbits(k1, cv, cn, s_ref, num_cu, 0, ref_mode));
+    CK(hipDeviceSynchronize());
+    if (timeit) {
+      const float t = time_ms(reps, [&] { CK(launch_gram_kbits(k1, cv, cn, s_ref, num_cu, 0, ref_mode)); });
+      std::printf("n %d v %lld  shipped gram_kbits<3,2,2> mode %d: %.4f ms\n", cn, (long long)cv, ref_mode, t);
+      if (gram_lockstep_splitk(cn, num_cu) > 0) {
+        const float t2 = time_ms(reps, [&] { CK(launch_gram_kbits(k1, cv, cn, s_ref, num_cu, 0, 2)); });
+        std::printf("n %d v %lld  shipped gram_kbits<3,2,2> mode 2: %.4f ms\n", cn, (long long)cv, t2);
+      }
+      CK(hipMemset(s_ref, 0, (size_t)sbytes));
+      CK(launch_gram_kbits(k1, cv, cn, s_ref, num_cu, 0, ref_mode));
+      CK(hipDeviceSynchronize());
+    }
+    for (int var : variants) {
+      g_w4_variant = var;
+      for (int mode : {4, 2, 0}) {
+        if (mode == 2 && gram_lockstep_splitk(cn, num_cu) == 0) continue;
+        if (mode == 4 && ntri > 4 * num_cu) continue;
+        if (!timeit && mode == 0 && cv > (1 << 16)) continue;
+        CK(hipMemset(s_new, 0, (size_t)sbytes));
+        CK(launch_gram_kbits_w4(k1, cv, cn, s_new, num_cu, 0, mode));
+        CK(hipDeviceSynchronize());
+        const unsigned long long d = count_diff(s_ref, s_new, sbytes, cnt);
+        if (d) ++fails;
+        if (timeit) {
+          const float t = time_ms(reps, [&] { CK(launch_gram_kbits_w4(k1, cv, cn, s_new, num_cu, 0, mode)); });
+          std::printf("n %d v %lld  w4 variant %d mode %d: %.4f ms   diff %llu %s\n", cn, (long long)cv, var, mode, t, d,
+                      d ? "MISMATCH" : "ok");
+        } else {
+          std::printf("n %d v %lld  w4 variant %d mode %d: diff %llu %s\n", cn, (long long)cv, var, mode, d, d ? "MISMATCH" : "ok");
+        }
+      }
+    }
+    CK(hipFree(k1));
+    CK(hipFree(s_ref));
+    CK(hipFree(s_new));
+  };
+
+  if (small) {
+    const Case cases[] = {{5, 7}, {33, 129}, {130, 2100}, {257, 4096}, {300, 5000}, {513, 12345}, {1000, 70000}, {2504, 40000}, {3000, 9000}};
+    for (const Case& c : cases) run_case(c.n, c.v, false);
+  }
+  if (big) {
+    run_case(n, v, true);
+    // repeat the correctness check a few times at full size (a hazard shows on some launches only)
+    for (int r = 0; r < 3; ++r) run_case(n, v - 128 * r - 5, false);
+  }
+  std::printf("%s (%d mismatching cases)\n", fails ? "FAILED" : "ALL OK", fails);
+  return fails ? 1 : 0;
+}
