@@ -21,247 +21,333 @@
 // s_waitcnt vmcnt(PER * (NST - 2)) always means "my share of stage s+1 has landed".
 #ifdef PCOA_KBITS_W4_KERNELS
 
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct FragsW4 {
   i32x4 a[4];
   i32x4 b[4];
 };
 
-// MFMA T of a k-step: (mi, ni) = (T / 4, T % 4).  NOP wait states inside the statement (gram_kbits.inl: an MFMA issued in
-// the cycle after a VALU instruction was seen to return rows 0, 1, 4, 5 of its tile wrong; nothing can be scheduled between
-// the pad and the instruction here).
+// MFMA T of a k-step: (mi, ni) = (T / 4, T % 4).  NOP wait states inside the statement, where nothing can be scheduled
+// between the pad and the instruction.  (gram_kbits.inl pads every MFMA: its late expansions write registers an MFMA issued
+// a cycle later may still read.  Here nothing an MFMA reads is written within 16 MFMAs of it and the accumulators are AGPRs no
+// VALU instruction touches: NOP = 0 is bit-exact on every shape and launch of tools/exp_w4, profiles/r04a.)
 template <int T, int NOP>
-__device__ __forceinline__ void w4_mfma(const FragsW4& f, f32x16 (&acc)[4][4]) {
-  constexpr int mi = T / 4, ni = T % 4;
+__device__ __forceinline__ void w4_mfma(const FragsW4& f) {
+  constexpr int mi = T / 4, ni = T % 4, lo = 16 * T, up = 16 * T + 15;
   if constexpr (NOP == 2)
-    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, %0 cbsz:4 blgp:4" : "+a"(acc[mi][ni]) : "v"(f.a[mi]), "v"(f.b[ni]));
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x64_f8f6f4 a[%c2:%c3], %0, %1, a[%c2:%c3] cbsz:4 blgp:4" ::"v"(f.a[mi]), "v"(f.b[ni]), "n"(lo), "n"(up));
   else if constexpr (NOP == 1)
-    asm volatile("s_nop 0\n\tv_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, %0 cbsz:4 blgp:4" : "+a"(acc[mi][ni]) : "v"(f.a[mi]), "v"(f.b[ni]));
+    asm volatile("s_nop 0\n\tv_mfma_f32_32x32x64_f8f6f4 a[%c2:%c3], %0, %1, a[%c2:%c3] cbsz:4 blgp:4" ::"v"(f.a[mi]), "v"(f.b[ni]), "n"(lo), "n"(up));
   else
-    asm volatile("v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, %0 cbsz:4 blgp:4" : "+a"(acc[mi][ni]) : "v"(f.a[mi]), "v"(f.b[ni]));
+    asm volatile("v_mfma_f32_32x32x64_f8f6f4 a[%c2:%c3], %0, %1, a[%c2:%c3] cbsz:4 blgp:4" ::"v"(f.a[mi]), "v"(f.b[ni]), "n"(lo), "n"(up));
+}
+
+// The 256 accumulator registers are a[0:255] BY NAME: tuple (mi, ni) = a[16 (4 mi + ni) : +15].  They are not C++ variables:
+// with all 256 AGPRs live the register allocator has no temporary to shuffle tuples with, and whenever it decided to move
+// one (through VGPRs, through scratch) it did so with v_accvgpr_read / write right behind an asm MFMA whose wait states it
+// cannot know -- wrong sums on some launches (profiles/r04j).  The compiler never allocates an AGPR in this kernel (it
+// needs < 160 of the 256 architectural VGPRs); the clobber list of w4_zero_acc makes the kernel descriptor reserve them.
+#define W4_A16(b) "a" #b "0", "a" #b "1", "a" #b "2", "a" #b "3", "a" #b "4", "a" #b "5", "a" #b "6", "a" #b "7", "a" #b "8", "a" #b "9"
+__device__ __forceinline__ void w4_zero_acc() {
+  i32x4 z = {0, 0, 0, 0};
+  // sixteen MFMAs on a zero fragment with the constant 0 as C: 0.2 us, no temporary tuple
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_mfma_f32_32x32x64_f8f6f4 a[0:15], %0, %0, 0 cbsz:4 blgp:4\n\t"
+      "v_mfma_f32_32x32x64_f8f6f4 a[16:31], %0, %0, 0 cbsz:4 blgp:4\n\t"
+      "v_mfma_f32_32x32x64_f8f6f4 a[32:47], %0, %0, 0 cbsz:4 blgp:4\n\t"
+      "v_mfma_f32_32x32x64_f8f6f4 a[48:63], %0, %0, 0 cbsz:4 blgp:4\n\t"
+      "v_mfma_f32_32x32x64_f8f6f4 a[64:79], %0, %0, 0 cbsz:4 blgp:4\n\t"
+      "v_mfma_f32_32x32x64_f8f6f4 a[80:95], %0, %0, 0 cbsz:4 blgp:4\n\t"
+      "v_mfma_f32_32x32x64_f8f6f4 a[96:111], %0, %0, 0 cbsz:4 blgp:4\n\t"
+      "v_mfma_f32_32x32x64_f8f6f4 a[112:127], %0, %0, 0 cbsz:4 blgp:4\n\t"
+      "v_mfma_f32_32x32x64_f8f6f4 a[128:143], %0, %0, 0 cbsz:4 blgp:4\n\t"
+      "v_mfma_f32_32x32x64_f8f6f4 a[144:159], %0, %0, 0 cbsz:4 blgp:4\n\t"
+      "v_mfma_f32_32x32x64_f8f6f4 a[160:175], %0, %0, 0 cbsz:4 blgp:4\n\t"
+      "v_mfma_f32_32x32x64_f8f6f4 a[176:191], %0, %0, 0 cbsz:4 blgp:4\n\t"
+      "v_mfma_f32_32x32x64_f8f6f4 a[192:207], %0, %0, 0 cbsz:4 blgp:4\n\t"
+      "v_mfma_f32_32x32x64_f8f6f4 a[208:223], %0, %0, 0 cbsz:4 blgp:4\n\t"
+      "v_mfma_f32_32x32x64_f8f6f4 a[224:239], %0, %0, 0 cbsz:4 blgp:4\n\t"
+      "v_mfma_f32_32x32x64_f8f6f4 a[240:255], %0, %0, 0 cbsz:4 blgp:4"
+      :
+      : "v"(z)
+      : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", W4_A16(1), W4_A16(2), W4_A16(3), W4_A16(4), W4_A16(5), W4_A16(6),
+        W4_A16(7), W4_A16(8), W4_A16(9), W4_A16(10), W4_A16(11), W4_A16(12), W4_A16(13), W4_A16(14), W4_A16(15), W4_A16(16),
+        W4_A16(17), W4_A16(18), W4_A16(19), W4_A16(20), W4_A16(21), W4_A16(22), W4_A16(23), W4_A16(24), "a250", "a251", "a252",
+        "a253", "a254", "a255");
+}
+#undef W4_A16
+// accumulator register K of the file -> a VGPR (the caller has put the MFMA -> read wait states behind the last MFMA)
+template <int K>
+__device__ __forceinline__ int w4_acc_to_int() {
+  float x;
+  asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(x) : "n"(K));
+  return (int)x;  // exact integers below 2^24
+}
+
+// The raw words of a stage: raw[q] = one ds_read2_b64 = {row 2q word 0, row 2q word 1, row 2q+1 word 0, row 2q+1 word 1} of the
+// lane's half (rows 0-3: the wave's A rows, 4-7: its B rows; word = k-step).
+template <int ROW, int WORD>
+__device__ __forceinline__ uint32_t w4_word(const u32x4 (&raw)[4]) {
+  return raw[ROW >> 1][(ROW & 1) * 2 + WORD];
 }
 
 // The expansion work placed behind MFMA T: fragments (A_g, B_g), g = T / 4, of the next k-step, 12 operations over four
-// gaps as 3 + 3 + 4 + 2.  raw[0..3] = the words of the wave's 4 A rows, raw[4..7] = of its 4 B rows; WORD = k-step.
-// The empty asm statements pin the arithmetic between the two MFMA statements around it (asm volatile statements keep
-// their order; the arithmetic cannot rise above the statement that "redefines" its input nor sink below the one that
-// "redefines" its output).
-template <int T, int WORD>
-__device__ __forceinline__ void w4_gap(u32x2 (&raw)[8], FragsW4& nf) {
+// gaps as 3 + 3 + 4 + 2 (conjugate weights of gram_kbits.inl: A class 0..3 -> E2M1 0.5, 1, 2, 2; B -> 2, 1, 0.5, 0.5).
+// w4_pin_in<T> "redefines" the words gap T reads and w4_pin_out<T> the fragments it writes: asm volatile statements keep
+// their order, so the arithmetic of gap T can neither rise above its pin_in nor sink below its pin_out.
+template <int T>
+__device__ __forceinline__ void w4_pin_in(u32x4 (&raw)[4]) {
   constexpr int g = T / 4, j = T % 4;
+  if constexpr (j == 0) asm volatile("" : "+v"(raw[g >> 1]));
+  else if constexpr (j == 1) asm volatile("" : "+v"(raw[g >> 1]), "+v"(raw[2 + (g >> 1)]));
+  else asm volatile("" : "+v"(raw[2 + (g >> 1)]));
+}
+template <int T>
+__device__ __forceinline__ void w4_pin_out(FragsW4& nf) {
+  constexpr int g = T / 4, j = T % 4;
+  if constexpr (j == 0) asm volatile("" : "+v"(nf.a[g]));
+  else if constexpr (j == 1) asm volatile("" : "+v"(nf.a[g]), "+v"(nf.b[g]));
+  else asm volatile("" : "+v"(nf.b[g]));
+}
+template <int T, int WORD>
+__device__ __forceinline__ void w4_ops(const u32x4 (&raw)[4], FragsW4& nf) {
+  constexpr int g = T / 4, j = T % 4;
+  const uint32_t wa = w4_word<g, WORD>(raw), wb = w4_word<4 + g, WORD>(raw);
   if constexpr (j == 0) {
-    asm volatile("" : "+v"(raw[g]));
-    const uint32_t w = raw[g][WORD];
-    nf.a[g][0] = (int)(w & 0x11111111u);
-    nf.a[g][1] = (int)(w & 0x22222222u);
-    nf.a[g][2] = (int)(w & 0x44444444u);
-    asm volatile("" : "+v"(nf.a[g]));
+    nf.a[g][0] = (int)(wa & 0x11111111u);
+    nf.a[g][1] = (int)(wa & 0x22222222u);
+    nf.a[g][2] = (int)(wa & 0x44444444u);
   } else if constexpr (j == 1) {
-    asm volatile("" : "+v"(raw[g]), "+v"(raw[4 + g]));
-    const uint32_t wa = raw[g][WORD], wb = raw[4 + g][WORD];
     nf.a[g][3] = (int)((wa >> 1) & 0x44444444u);
     nf.b[g][1] = (int)(wb & 0x22222222u);
-    asm volatile("" : "+v"(nf.a[g]), "+v"(nf.b[g]));
   } else if constexpr (j == 2) {
-    asm volatile("" : "+v"(raw[4 + g]));
-    const uint32_t wb = raw[4 + g][WORD];
     nf.b[g][0] = (int)((wb << 2) & 0x44444444u);
     nf.b[g][2] = (int)((wb >> 2) & 0x11111111u);
-    asm volatile("" : "+v"(nf.b[g]));
   } else {
-    asm volatile("" : "+v"(raw[4 + g]));
-    const uint32_t wb = raw[4 + g][WORD];
     nf.b[g][3] = (int)((wb >> 3) & 0x11111111u);
-    asm volatile("" : "+v"(nf.b[g]));
   }
+}
+template <int T, int WORD>
+__device__ __forceinline__ void w4_gap(u32x4 (&raw)[4], FragsW4& nf) {
+  w4_pin_in<T>(raw);
+  w4_ops<T, WORD>(raw, nf);
+  w4_pin_out<T>(nf);
+}
+
+// One statement that reads and "redefines" all eight fragments of a buffer: it keeps the buffer's live range unbroken across
+// the k-step in which nothing reads it, so that the register allocator never moves it -- left free (OPT & 8 without this),
+// it puts a fragment of the NEXT k-step into the registers of a fragment that died one MFMA ago, and an MFMA keeps reading its
+// A / B registers for some cycles after it has issued (gram_kbits.inl, profiles/r03g_kbits_hazards.txt).
+__device__ __forceinline__ void w4_tie(FragsW4& f) {
+  asm volatile("" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0]), "+v"(f.b[1]), "+v"(f.b[2]), "+v"(f.b[3]));
 }
 
 // all eight fragments of one k-step at once (prologue of a run: nothing to hide behind)
 template <int WORD>
-__device__ __forceinline__ void w4_expand_all(u32x2 (&raw)[8], FragsW4& nf) {
+__device__ __forceinline__ void w4_expand_all(u32x4 (&raw)[4], FragsW4& nf) {
   w4_gap<0, WORD>(raw, nf);  w4_gap<1, WORD>(raw, nf);  w4_gap<2, WORD>(raw, nf);  w4_gap<3, WORD>(raw, nf);
   w4_gap<4, WORD>(raw, nf);  w4_gap<5, WORD>(raw, nf);  w4_gap<6, WORD>(raw, nf);  w4_gap<7, WORD>(raw, nf);
   w4_gap<8, WORD>(raw, nf);  w4_gap<9, WORD>(raw, nf);  w4_gap<10, WORD>(raw, nf); w4_gap<11, WORD>(raw, nf);
   w4_gap<12, WORD>(raw, nf); w4_gap<13, WORD>(raw, nf); w4_gap<14, WORD>(raw, nf); w4_gap<15, WORD>(raw, nf);
 }
 
-// The words of slot SLOT: rows FIRST .. FIRST + COUNT - 1 of `raw` (0-3: A rows, 4-7: B rows), one ds_read_b64 each.  As asm
-// statements: the compiler's wait-count pass cannot tell a ring slot being read from the slots the LDS-DMA in flight writes
-// and would put s_waitcnt vmcnt(0) in front of a plain load (gram_kbits.inl, pack_u8_kbits_ring_kernel).  The wait is the
-// caller's (w4_wait_words).
-template <int SLOT, int R>
-__device__ __forceinline__ void w4_read_one(uint32_t addr_a, uint32_t addr_b, u32x2 (&raw)[8]) {
-  if constexpr (R < 4) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(raw[R]) : "v"(addr_a), "n"(SLOT * 8192 + (R & 3) * 512));
-  else asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(raw[R]) : "v"(addr_b), "n"(SLOT * 8192 + (R & 3) * 512));
+// raw[Q] of a slot: rows 2Q and 2Q+1 (512 bytes apart) by one ds_read2_b64.  As asm statements: the compiler's wait-count
+// pass cannot tell a ring slot being read from the slots the LDS-DMA in flight writes and would put s_waitcnt vmcnt(0) in
+// front of a plain load (gram_kbits.inl, pack_u8_kbits_ring_kernel).  The wait is the caller's (w4_wait_words).
+// addr = the lane's address of row 0 (A) / row 4 (B) in that slot.
+template <int Q>
+__device__ __forceinline__ void w4_read(uint32_t addr_a, uint32_t addr_b, u32x4 (&raw)[4]) {
+  if constexpr (Q < 2) asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(raw[Q]) : "v"(addr_a), "n"(Q * 128), "n"(Q * 128 + 64));
+  else asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(raw[Q]) : "v"(addr_b), "n"((Q - 2) * 128), "n"((Q - 2) * 128 + 64));
 }
-template <int SLOT, int FIRST, int COUNT>
-__device__ __forceinline__ void w4_read(uint32_t addr_a, uint32_t addr_b, u32x2 (&raw)[8]) {
-  w4_read_one<SLOT, FIRST>(addr_a, addr_b, raw);
-  if constexpr (COUNT > 1) w4_read<SLOT, FIRST + 1, COUNT - 1>(addr_a, addr_b, raw);
-}
-__device__ __forceinline__ void w4_wait_words(u32x2 (&raw)[8]) {
-  asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]), "+v"(raw[7]));
+__device__ __forceinline__ void w4_wait_words(u32x4 (&raw)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]));
 }
 
-// DMA of one stage into slot SLOT: wave w brings in quarter w of panel I and (off the diagonal) quarter w of panel J.
-// `base` = the block's first byte (wave-uniform, kept in SGPRs), off_i / off_j = the lane's byte offset inside the block.
-template <int SLOT, bool DIAG>
-__device__ __forceinline__ void w4_issue(StageBits* lds, const int8_t* base, uint32_t off_i, uint32_t off_j, int wave) {
-  asm volatile("" : "+s"(base));
-  __builtin_amdgcn_global_load_lds((gptr_t)(base + off_i), (lptr_t)&lds[SLOT].pi[wave * 64][0], 16, 0, 0);
-  if constexpr (!DIAG)
-    __builtin_amdgcn_global_load_lds((gptr_t)(base + off_j), (lptr_t)&lds[SLOT].pj[wave * 64][0], 16, 0, 0);
-}
-
+template <int NST>
 struct W4Run {
   const int8_t* next;  // block the next DMA reads (wave-uniform)
   int rem;             // blocks between `next` and the operand's last block: the clamp (may run negative)
   int64_t pitch;       // bytes per block = npad * 16
-  uint32_t off_i, off_j, addr_a, addr_b;
+  uint32_t off_i, off_j;            // the lane's byte offsets inside a block (its 16 bytes of panel I / J)
+  uint32_t addr_a[NST], addr_b[NST];  // the lane's LDS read addresses per slot
+  uint32_t dst_i[NST], dst_j[NST];    // the wave's LDS-DMA destinations per slot (wave-uniform)
 };
-__device__ __forceinline__ void w4_advance(W4Run& run) {  // scalar unit only
+template <int NST>
+__device__ __forceinline__ void w4_advance(W4Run<NST>& run) {  // scalar unit only
   const int64_t step = run.rem > 0 ? run.pitch : 0;
   run.rem -= 1;
   run.next += step;
 }
 
-// One stage.  Entry: f[0] = fragments of (stage s, k-step 0); raw[PAR] = words of stage s; this wave's DMA is issued through
-// stage s + NST - 1.  Exit: the same for stage s + 1 with PAR flipped.
-template <int NST, int SLOT, int PAR, bool DIAG, bool IDLE, int NOP>
-__device__ __forceinline__ void w4_stage(StageBits* lds, W4Run& run, int wave, f32x16 (&acc)[4][4], FragsW4 (&f)[2],
-                                         u32x2 (&raw)[2][8]) {
-  constexpr int PER = DIAG ? 1 : 2;
-  constexpr int NSLOT = (SLOT + 1) % NST;
-  // ---- k-step 0 of stage s; behind its MFMAs: barrier, the words of stage s+1, the DMA of stage s+NST, fragments of k-step 1
-  if constexpr (!IDLE) w4_mfma<0, NOP>(f[0], acc);
-  wait_vmcnt<PER * (NST - 2)>();  // my share of stage s+1 has landed
-  raw_barrier();                  // everybody's has; everybody holds the words of stage s in registers
-  if constexpr (!IDLE) {
-    w4_gap<0, 1>(raw[PAR], f[1]);
-    w4_mfma<1, NOP>(f[0], acc);
-    w4_read<NSLOT, 0, 2>(run.addr_a, run.addr_b, raw[PAR ^ 1]);
-    w4_gap<1, 1>(raw[PAR], f[1]);
-    w4_mfma<2, NOP>(f[0], acc);
-    w4_gap<2, 1>(raw[PAR], f[1]);
-    w4_mfma<3, NOP>(f[0], acc);
-    w4_read<NSLOT, 2, 2>(run.addr_a, run.addr_b, raw[PAR ^ 1]);
-    w4_gap<3, 1>(raw[PAR], f[1]);
-    w4_mfma<4, NOP>(f[0], acc);
-    w4_gap<4, 1>(raw[PAR], f[1]);
-    w4_mfma<5, NOP>(f[0], acc);
-    w4_read<NSLOT, 4, 2>(run.addr_a, run.addr_b, raw[PAR ^ 1]);
-    w4_gap<5, 1>(raw[PAR], f[1]);
-    w4_mfma<6, NOP>(f[0], acc);
-    w4_gap<6, 1>(raw[PAR], f[1]);
-    w4_mfma<7, NOP>(f[0], acc);
-    w4_read<NSLOT, 6, 2>(run.addr_a, run.addr_b, raw[PAR ^ 1]);
-    w4_gap<7, 1>(raw[PAR], f[1]);
-    w4_mfma<8, NOP>(f[0], acc);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  w4_issue<SLOT, DIAG>(lds, run.next, run.off_i, run.off_j, wave);
-  w4_advance(run);
-  __builtin_amdgcn_sched_barrier(0);
-  if constexpr (!IDLE) {
-    w4_gap<8, 1>(raw[PAR], f[1]);
-    w4_mfma<9, NOP>(f[0], acc);
-    w4_gap<9, 1>(raw[PAR], f[1]);
-    w4_mfma<10, NOP>(f[0], acc);
-    w4_gap<10, 1>(raw[PAR], f[1]);
-    w4_mfma<11, NOP>(f[0], acc);
-    w4_gap<11, 1>(raw[PAR], f[1]);
-    w4_mfma<12, NOP>(f[0], acc);
-    w4_gap<12, 1>(raw[PAR], f[1]);
-    w4_mfma<13, NOP>(f[0], acc);
-    w4_gap<13, 1>(raw[PAR], f[1]);
-    w4_mfma<14, NOP>(f[0], acc);
-    w4_gap<14, 1>(raw[PAR], f[1]);
-    w4_mfma<15, NOP>(f[0], acc);
-    w4_gap<15, 1>(raw[PAR], f[1]);
-    // ---- k-step 1 of stage s; behind its MFMAs: fragments of (stage s+1, k-step 0)
-    w4_mfma<0, NOP>(f[1], acc);
-    w4_wait_words(raw[PAR ^ 1]);
-    w4_gap<0, 0>(raw[PAR ^ 1], f[0]);
-    w4_mfma<1, NOP>(f[1], acc);
-    w4_gap<1, 0>(raw[PAR ^ 1], f[0]);
-    w4_mfma<2, NOP>(f[1], acc);
-    w4_gap<2, 0>(raw[PAR ^ 1], f[0]);
-    w4_mfma<3, NOP>(f[1], acc);
-    w4_gap<3, 0>(raw[PAR ^ 1], f[0]);
-    w4_mfma<4, NOP>(f[1], acc);
-    w4_gap<4, 0>(raw[PAR ^ 1], f[0]);
-    w4_mfma<5, NOP>(f[1], acc);
-    w4_gap<5, 0>(raw[PAR ^ 1], f[0]);
-    w4_mfma<6, NOP>(f[1], acc);
-    w4_gap<6, 0>(raw[PAR ^ 1], f[0]);
-    w4_mfma<7, NOP>(f[1], acc);
-    w4_gap<7, 0>(raw[PAR ^ 1], f[0]);
-    w4_mfma<8, NOP>(f[1], acc);
-    w4_gap<8, 0>(raw[PAR ^ 1], f[0]);
-    w4_mfma<9, NOP>(f[1], acc);
-    w4_gap<9, 0>(raw[PAR ^ 1], f[0]);
-    w4_mfma<10, NOP>(f[1], acc);
-    w4_gap<10, 0>(raw[PAR ^ 1], f[0]);
-    w4_mfma<11, NOP>(f[1], acc);
-    w4_gap<11, 0>(raw[PAR ^ 1], f[0]);
-    w4_mfma<12, NOP>(f[1], acc);
-    w4_gap<12, 0>(raw[PAR ^ 1], f[0]);
-    w4_mfma<13, NOP>(f[1], acc);
-    w4_gap<13, 0>(raw[PAR ^ 1], f[0]);
-    w4_mfma<14, NOP>(f[1], acc);
-    w4_gap<14, 0>(raw[PAR ^ 1], f[0]);
-    w4_mfma<15, NOP>(f[1], acc);
-    w4_gap<15, 0>(raw[PAR ^ 1], f[0]);
+// One 1-KiB piece of a stage into slot SLOT: J = 0 quarter `wave` of panel I, J = 1 of panel J.  OPT & 1: as one asm
+// statement in the SGPR-base + 32-bit-VGPR-offset form (the builtin adds base and offset per lane with a 64-bit VALU add
+// right in front of the load, and re-materialises M0 around it).
+template <int NST, int SLOT, int J, int OPT>
+__device__ __forceinline__ void w4_issue_one(StageBits* lds, const W4Run<NST>& run, int wave) {
+  const uint32_t off = J ? run.off_j : run.off_i;
+  if constexpr (OPT & 1) {
+    const uint32_t dst = J ? run.dst_j[SLOT] : run.dst_i[SLOT];
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(run.next), "s"(dst) : "memory");
+  } else {
+    const int8_t* base = run.next;
+    asm volatile("" : "+s"(base));
+    if constexpr (J) __builtin_amdgcn_global_load_lds((gptr_t)(base + off), (lptr_t)&lds[SLOT].pj[wave * 64][0], 16, 0, 0);
+    else __builtin_amdgcn_global_load_lds((gptr_t)(base + off), (lptr_t)&lds[SLOT].pi[wave * 64][0], 16, 0, 0);
   }
 }
+template <int NST, int SLOT, bool DIAG, int OPT>
+__device__ __forceinline__ void w4_issue(StageBits* lds, W4Run<NST>& run, int wave) {
+  w4_issue_one<NST, SLOT, 0, OPT>(lds, run, wave);
+  if constexpr (!DIAG) w4_issue_one<NST, SLOT, 1, OPT>(lds, run, wave);
+  w4_advance(run);
+}
 
-template <int NST, bool DIAG, bool IDLE, int NOP, int... Is>
-__device__ __forceinline__ void w4_round(StageBits* lds, W4Run& run, int count, int wave, f32x16 (&acc)[4][4],
-                                         FragsW4 (&f)[2], u32x2 (&raw)[2][8], std::integer_sequence<int, Is...>) {
-  ((Is < count ? w4_stage<NST, Is % NST, Is & 1, DIAG, IDLE, NOP>(lds, run, wave, acc, f, raw) : (void)0), ...);
+// gap T of a k-step.  OPT & 2: pin_in sits in FRONT of the MFMA statement (hipcc pads one wait state between an asm
+// statement and a VALU instruction that reads its outputs; with the MFMA in between the pad is not needed -- the arithmetic
+// may then also be scheduled in front of that MFMA, i.e. a gap earlier, which is as good).
+#define W4_STEP(T_, K_, W_, P_)                                                                        \
+  do {                                                                                                 \
+    if constexpr (!(DBG & 1) && (OPT & 2) && !(OPT & 88)) w4_pin_in<T_>(raw[P_]);                      \
+    if constexpr (!(DBG & 16)) w4_mfma<T_, NOP>(f[K_]);                                           \
+    if constexpr (!(DBG & 1)) {                                                                        \
+      if constexpr (OPT & 88) __builtin_amdgcn_sched_barrier(0);                                       \
+      if constexpr ((OPT & 16) && (T_) < 15) w4_pin_in<((T_) < 15 ? (T_) + 1 : 15)>(raw[P_]);          \
+      if constexpr (!(OPT & 2) && !(OPT & 88)) w4_pin_in<T_>(raw[P_]);                                 \
+      w4_ops<T_, W_>(raw[P_], f[(K_) ^ 1]);                                                            \
+      if constexpr (OPT & 8) __builtin_amdgcn_sched_barrier(0);                                        \
+      else w4_pin_out<T_>(f[(K_) ^ 1]);                                                                \
+    }                                                                                                  \
+  } while (0)
+#define W4_READ(Q_) do { if constexpr (!(DBG & 4)) w4_read<Q_>(run.addr_a[NSLOT], run.addr_b[NSLOT], raw[PAR ^ 1]); } while (0)
+// One stage.  Entry: f[0] = fragments of (stage s, k-step 0); raw[PAR] = words of stage s; this wave's DMA is issued through
+// stage s + NST - 1.  Exit: the same for stage s + 1 with PAR flipped.
+template <int NST, int SLOT, int PAR, bool DIAG, bool IDLE, int NOP, int OPT, int DBG>
+__device__ __forceinline__ void w4_stage(StageBits* lds, W4Run<NST>& run, int wave, FragsW4 (&f)[2],
+                                         u32x4 (&raw)[2][4]) {
+  constexpr int PER = DIAG ? 1 : 2;
+  constexpr int NSLOT = (SLOT + 1) % NST;
+  if constexpr (IDLE) {
+    if constexpr (!(DBG & 8)) wait_vmcnt<PER * (NST - 2)>();
+    if constexpr (!(DBG & 2)) raw_barrier();
+    if constexpr (!(DBG & 8)) w4_issue<NST, SLOT, DIAG, OPT>(lds, run, wave);
+    return;
+  }
+  // ---- k-step 0 of stage s: MFMAs on f[0]; behind them the barrier, the words of stage s+1, DMA of stage s+NST, and the
+  //      fragments of k-step 1 (word 1 of raw[PAR] -> f[1])
+  if constexpr (!(DBG & 1) && (OPT & 2) && !(OPT & 88)) w4_pin_in<0>(raw[PAR]);
+  if constexpr (!(DBG & 1) && (OPT & 32)) w4_tie(f[1]);
+  if constexpr (!(DBG & 16)) w4_mfma<0, NOP>(f[0]);
+  if constexpr (!(DBG & 8)) wait_vmcnt<PER * (NST - 2)>();  // my share of stage s+1 has landed
+  if constexpr (!(DBG & 2)) raw_barrier();  // everybody's has; everybody holds the words of stage s in registers
+  if constexpr (!(DBG & 1)) {
+    if constexpr (OPT & 16) w4_pin_in<1>(raw[PAR]);
+    if constexpr (!(OPT & 2) && !(OPT & 88)) w4_pin_in<0>(raw[PAR]);
+    w4_ops<0, 1>(raw[PAR], f[1]);
+    if constexpr (OPT & 8) __builtin_amdgcn_sched_barrier(0);
+    else w4_pin_out<0>(f[1]);
+  }
+  W4_STEP(1, 0, 1, PAR);
+  W4_READ(0);
+  W4_STEP(2, 0, 1, PAR);
+  W4_STEP(3, 0, 1, PAR);
+  W4_READ(1);
+  W4_STEP(4, 0, 1, PAR);
+  W4_STEP(5, 0, 1, PAR);
+  W4_READ(2);
+  W4_STEP(6, 0, 1, PAR);
+  W4_STEP(7, 0, 1, PAR);
+  W4_READ(3);
+  W4_STEP(8, 0, 1, PAR);
+  if constexpr (!(DBG & 8)) {
+    __builtin_amdgcn_sched_barrier(0);
+    w4_issue_one<NST, SLOT, 0, OPT>(lds, run, wave);
+    if constexpr (!DIAG && !(OPT & 4)) w4_issue_one<NST, SLOT, 1, OPT>(lds, run, wave);
+    if constexpr (DIAG || !(OPT & 4)) w4_advance(run);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  W4_STEP(9, 0, 1, PAR);
+  W4_STEP(10, 0, 1, PAR);
+  W4_STEP(11, 0, 1, PAR);
+  W4_STEP(12, 0, 1, PAR);
+  W4_STEP(13, 0, 1, PAR);
+  W4_STEP(14, 0, 1, PAR);
+  W4_STEP(15, 0, 1, PAR);
+  // ---- k-step 1 of stage s: MFMAs on f[1]; behind them the fragments of (stage s+1, k-step 0) (word 0 of raw[PAR^1] -> f[0])
+  if constexpr (!(DBG & 4)) w4_wait_words(raw[PAR ^ 1]);
+  if constexpr (!(DBG & 1) && (OPT & 32)) w4_tie(f[0]);
+  W4_STEP(0, 1, 0, PAR ^ 1);
+  W4_STEP(1, 1, 0, PAR ^ 1);
+  W4_STEP(2, 1, 0, PAR ^ 1);
+  W4_STEP(3, 1, 0, PAR ^ 1);
+  W4_STEP(4, 1, 0, PAR ^ 1);
+  W4_STEP(5, 1, 0, PAR ^ 1);
+  W4_STEP(6, 1, 0, PAR ^ 1);
+  W4_STEP(7, 1, 0, PAR ^ 1);
+  W4_STEP(8, 1, 0, PAR ^ 1);
+  if constexpr (!(DBG & 8) && !DIAG && (OPT & 4)) {
+    __builtin_amdgcn_sched_barrier(0);
+    w4_issue_one<NST, SLOT, 1, OPT>(lds, run, wave);
+    w4_advance(run);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  W4_STEP(9, 1, 0, PAR ^ 1);
+  W4_STEP(10, 1, 0, PAR ^ 1);
+  W4_STEP(11, 1, 0, PAR ^ 1);
+  W4_STEP(12, 1, 0, PAR ^ 1);
+  W4_STEP(13, 1, 0, PAR ^ 1);
+  W4_STEP(14, 1, 0, PAR ^ 1);
+  W4_STEP(15, 1, 0, PAR ^ 1);
+}
+#undef W4_STEP
+#undef W4_READ
+
+template <int NST, bool DIAG, bool IDLE, int NOP, int OPT, int DBG, int... Is>
+__device__ __forceinline__ void w4_round(StageBits* lds, W4Run<NST>& run, int count, int wave,
+                                         FragsW4 (&f)[2], u32x4 (&raw)[2][4], std::integer_sequence<int, Is...>) {
+  ((Is < count ? w4_stage<NST, Is % NST, Is & 1, DIAG, IDLE, NOP, OPT, DBG>(lds, run, wave, f, raw) : (void)0), ...);
+}
+
+template <int NST, bool DIAG, int OPT, int I = 0>
+__device__ __forceinline__ void w4_prologue_issue(StageBits* lds, W4Run<NST>& run, int wave) {
+  if constexpr (I < NST) {
+    w4_issue<NST, I, DIAG, OPT>(lds, run, wave);
+    w4_prologue_issue<NST, DIAG, OPT, I + 1>(lds, run, wave);
+  }
 }
 
 // One run of `ns` stages of one tile, starting at block `first` (pointer to its first byte).
-template <int NST, bool DIAG, bool IDLE, int NOP>
-__device__ __forceinline__ void w4_loop(StageBits* lds, W4Run& run, const int8_t* first, int ns, int wave,
-                                        f32x16 (&acc)[4][4]) {
+template <int NST, bool DIAG, bool IDLE, int NOP, int OPT, int DBG>
+__device__ __forceinline__ void w4_loop(StageBits* lds, W4Run<NST>& run, const int8_t* first, int ns, int wave) {
   static_assert(NST % 2 == 0, "the raw-word parity of a slot must be a compile-time constant");
   constexpr int PER = DIAG ? 1 : 2;
   FragsW4 f[2];
-  u32x2 raw[2][8];
-  run.next = first;
+  u32x4 raw[2][4];
+  {  // workgroup-uniform, but it comes out of a 64-bit division done on the vector unit: the asm DMA wants it in SGPRs
+    const uint64_t a = (uint64_t)(uintptr_t)first;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    run.next = reinterpret_cast<const int8_t*>(((uint64_t)hi << 32) | lo);
+  }
   // prologue: stages 0 .. NST-1 go in flight (every slot is free: the previous run ended with vmcnt(0) + barrier)
-  w4_issue<0, DIAG>(lds, run.next, run.off_i, run.off_j, wave);
-  w4_advance(run);
-  w4_issue<1, DIAG>(lds, run.next, run.off_i, run.off_j, wave);
-  w4_advance(run);
-  if constexpr (NST > 2) {
-    w4_issue<2 % NST, DIAG>(lds, run.next, run.off_i, run.off_j, wave);
-    w4_advance(run);
-    w4_issue<3 % NST, DIAG>(lds, run.next, run.off_i, run.off_j, wave);
-    w4_advance(run);
-  }
-  if constexpr (NST > 4) {
-    w4_issue<4 % NST, DIAG>(lds, run.next, run.off_i, run.off_j, wave);
-    w4_advance(run);
-    w4_issue<5 % NST, DIAG>(lds, run.next, run.off_i, run.off_j, wave);
-    w4_advance(run);
-  }
-  static_assert(NST == 2 || NST == 4 || NST == 6, "prologue written for 2, 4 or 6 stages");
+  w4_prologue_issue<NST, DIAG, OPT>(lds, run, wave);
   wait_vmcnt<PER * (NST - 1)>();  // stage 0
   raw_barrier();
   if constexpr (!IDLE) {
-    w4_read<0, 0, 8>(run.addr_a, run.addr_b, raw[0]);
+    w4_read<0>(run.addr_a[0], run.addr_b[0], raw[0]);
+    w4_read<1>(run.addr_a[0], run.addr_b[0], raw[0]);
+    w4_read<2>(run.addr_a[0], run.addr_b[0], raw[0]);
+    w4_read<3>(run.addr_a[0], run.addr_b[0], raw[0]);
     w4_wait_words(raw[0]);
     w4_expand_all<0>(raw[0], f[0]);
     asm volatile("s_nop 1");
   }
   int s = 0;
   for (; s + NST <= ns; s += NST)
-    w4_round<NST, DIAG, IDLE, NOP>(lds, run, NST, wave, acc, f, raw, std::make_integer_sequence<int, NST>{});
-  if (s < ns) w4_round<NST, DIAG, IDLE, NOP>(lds, run, ns - s, wave, acc, f, raw, std::make_integer_sequence<int, NST - 1>{});
+    w4_round<NST, DIAG, IDLE, NOP, OPT, DBG>(lds, run, NST, wave, f, raw, std::make_integer_sequence<int, NST>{});
+  if (s < ns)
+    w4_round<NST, DIAG, IDLE, NOP, OPT, DBG>(lds, run, ns - s, wave, f, raw, std::make_integer_sequence<int, NST - 1>{});
   // drain: the clamped DMAs still in flight write slots the next run's prologue re-uses, and the last stage's speculative
   // ds_reads (words of a stage beyond the run, never used) must have returned before their registers are re-used
   wait_vmcnt<0>();
@@ -269,9 +355,59 @@ __device__ __forceinline__ void w4_loop(StageBits* lds, W4Run& run, const int8_t
   raw_barrier();
 }
 
+// Epilogue of one wave: its 128 x 128 block is added into S32 with integer atomics (exact integers below 2^24 in the fp32
+// accumulators).  Element (mi, ni, r) of a lane is row i0 + 32 mi + (r & 3) + 8 (r >> 2) + 4 hi, column j0 + 32 ni + l31.  The row
+// base of each mi is wave-uniform (SGPR pair), a lane keeps ONE 32-bit byte offset that walks down the rows, the four column
+// tiles are immediate offsets: v_accvgpr_read + v_cvt + v_add + global_atomic_add per element.  (What bounds the epilogue is
+// not the instruction count but the atomics themselves, ~27 us per 256 x 256 tile whatever their width: 64-bit atomics on
+// column pairs changed nothing, profiles/r04h.)  MASKED: tiles on the diagonal, at the edge of the matrix or of a strip test
+// every element (symmetric job: j >= i and j < n; strip: i < n and jorg <= j < jend) and skip zeros.
+template <bool MASKED, int MI, int NI, int R>
+__device__ __forceinline__ void w4_store_elem(const int32_t* rowbase, uint32_t& voff, uint32_t ld4, int i0, int jj, int jorg, int n,
+                                              bool sym, int jend, int hi) {
+  const int v = w4_acc_to_int<16 * (4 * MI + NI) + R>();
+  bool ok = true;
+  if constexpr (MASKED) {
+    const int ii = i0 + MI * 32 + (R & 3) + 8 * (R >> 2) + 4 * hi;
+    ok = ii < n && jj < jend && jj >= (sym ? ii : jorg) && v != 0;
+  }
+  if (ok) asm volatile("global_atomic_add %0, %1, %2 offset:%3" ::"v"(voff), "v"(v), "s"(rowbase), "n"(NI * 128) : "memory");
+  voff += ((R & 3) == 3) ? 5u * ld4 : ld4;
+}
+template <bool MASKED, int MI, int NI, int... Rs>
+__device__ __forceinline__ void w4_store_tuple(const int32_t* rowbase, uint32_t voff, uint32_t ld4, int i0, int jj, int jorg, int n,
+                                               bool sym, int jend, int hi, std::integer_sequence<int, Rs...>) {
+  (w4_store_elem<MASKED, MI, NI, Rs>(rowbase, voff, ld4, i0, jj, jorg, n, sym, jend, hi), ...);
+}
+template <bool MASKED, int MI>
+__device__ __forceinline__ void w4_store_rows(int32_t* s32, int64_t ld, uint32_t voff0, int i0, int j0, int jorg, int n, bool sym,
+                                              int jend, int l31, int hi) {
+  const uint64_t a = (uint64_t)(uintptr_t)(s32 + (int64_t)(i0 + MI * 32) * ld + (j0 - jorg));
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), up = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  const int32_t* rowbase = reinterpret_cast<const int32_t*>(((uint64_t)up << 32) | lo);
+  const uint32_t ld4 = (uint32_t)ld * 4u;
+  constexpr std::make_integer_sequence<int, 16> rs{};
+  w4_store_tuple<MASKED, MI, 0>(rowbase, voff0, ld4, i0, j0 + l31, jorg, n, sym, jend, hi, rs);
+  w4_store_tuple<MASKED, MI, 1>(rowbase, voff0, ld4, i0, j0 + 32 + l31, jorg, n, sym, jend, hi, rs);
+  w4_store_tuple<MASKED, MI, 2>(rowbase, voff0, ld4, i0, j0 + 64 + l31, jorg, n, sym, jend, hi, rs);
+  w4_store_tuple<MASKED, MI, 3>(rowbase, voff0, ld4, i0, j0 + 96 + l31, jorg, n, sym, jend, hi, rs);
+}
+template <bool MASKED>
+__device__ __forceinline__ void w4_store(int32_t* s32, int64_t ld, int i0, int j0, int jorg, int n, bool sym, int jend, int l31,
+                                         int hi) {
+  const uint32_t voff0 = ((uint32_t)(4 * hi) * (uint32_t)ld + (uint32_t)l31) * 4u;
+  w4_store_rows<MASKED, 0>(s32, ld, voff0, i0, j0, jorg, n, sym, jend, l31, hi);
+  w4_store_rows<MASKED, 1>(s32, ld, voff0, i0, j0, jorg, n, sym, jend, l31, hi);
+  w4_store_rows<MASKED, 2>(s32, ld, voff0, i0, j0, jorg, n, sym, jend, l31, hi);
+  w4_store_rows<MASKED, 3>(s32, ld, voff0, i0, j0, jorg, n, sym, jend, l31, hi);
+}
+
 // Work decomposition and epilogue as gram_kbits_body (xcd_map 0 / 1 / 2 / 4); 256 x 256 workgroup tiles, a wave's block is
 // rows [128 wm, +128) x columns [128 wn, +128) of it.
-template <int NST, int NOP>
+#ifdef PCOA_EXPERIMENTS
+__device__ unsigned long long g_w4_clk[4];  // harness: shader-clock and 100-MHz ticks of block 0's life
+#endif
+template <int NST, int NOP, int OPT, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void gram_kbits_w4_kernel(const int8_t* __restrict__ p, int npad, int64_t nstages, int n,
                                                                int ntile, int ntri, int splitk, int64_t stages_per,
                                                                int32_t* __restrict__ s32, int xcd_map,
@@ -282,6 +418,9 @@ __global__ __launch_bounds__(256, 1) void gram_kbits_w4_kernel(const int8_t* __r
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int b = blockIdx.x;
+#ifdef PCOA_EXPERIMENTS
+  const unsigned long long clk0 = clock64(), rt0 = wall_clock64();
+#endif
 
   int64_t u, u_end;
   if (xcd_map == 4) {
@@ -316,9 +455,15 @@ __global__ __launch_bounds__(256, 1) void gram_kbits_w4_kernel(const int8_t* __r
 
   const int l31 = lane & 31, hi = lane >> 5;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)&lds[0];
-  W4Run run;
-  run.pitch = (int64_t)npad * 16;
-  run.addr_a = lds0 + (uint32_t)((wm * 128 + l31) * 16 + hi * 8);
+  W4Run<NST> run;
+  run.pitch = (DBG & 32) ? 0 : (int64_t)npad * 16;  // DBG & 32: every DMA re-reads the run's first block (always L2-warm)
+#pragma unroll
+  for (int q = 0; q < NST; ++q) {
+    run.addr_a[q] = lds0 + (uint32_t)(q * 8192 + (wm * 128 + l31) * 16 + hi * 8);
+    run.addr_b[q] = lds0 + (uint32_t)(q * 8192 + 4096 + (wn * 128 + l31) * 16 + hi * 8);
+    run.dst_i[q] = lds0 + (uint32_t)(q * 8192 + wave * 1024);
+    run.dst_j[q] = lds0 + (uint32_t)(q * 8192 + 4096 + wave * 1024);
+  }
 
   while (u < u_end) {  // workgroup-uniform
     const int tile = (int)(u / nstages);
@@ -341,53 +486,43 @@ __global__ __launch_bounds__(256, 1) void gram_kbits_w4_kernel(const int8_t* __r
       tile_coords<2>(tile, ntile, row_blk, col_blk);
     }
     const int col_i = row_blk * 256, col_j = col_blk * TJ;
-    const bool diag = row_blk == col_blk && strip.cols == 0;
-    const bool idle = diag && wm > wn;  // the block below the diagonal of a diagonal tile
-
-    f32x16 acc[4][4];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0;
+    // A diagonal tile runs the same code: panel J is panel I brought in a second time (10 of 55 tiles at N = 2504; the extra
+    // 4 KiB per stage come out of the L1).  The wave whose block lies below the diagonal keeps its share of the DMA and of the
+    // barriers and issues nothing else (the kernel is power-bound: MFMAs nobody needs cost clock).
+    const bool idle = row_blk == col_blk && strip.cols == 0 && wm > wn;
 
     run.off_i = (uint32_t)(col_i + wave * 64 + lane) * 16u;
     run.off_j = (uint32_t)(col_j + wave * 64 + lane) * 16u;
-    // a diagonal tile brings in panel I only and reads its B rows from it
-    run.addr_b = lds0 + (uint32_t)((diag ? 0 : 4096) + (wn * 128 + l31) * 16 + hi * 8);
-    const int8_t* first = p + st_begin * run.pitch;
-    run.rem = (int)(nstages - 1 - st_begin);
-    if (diag) {
-      if (idle) w4_loop<NST, true, true, NOP>(lds, run, first, ns, wave, acc);
-      else w4_loop<NST, true, false, NOP>(lds, run, first, ns, wave, acc);
+    const int8_t* first = p + ((DBG & 64) ? 0 : st_begin) * run.pitch;
+    run.rem = __builtin_amdgcn_readfirstlane((int)(nstages - 1 - ((DBG & 64) ? 0 : st_begin)));
+
+    if (idle) {
+      w4_loop<NST, false, true, NOP, OPT, DBG>(lds, run, first, ns, wave);
     } else {
-      w4_loop<NST, false, false, NOP>(lds, run, first, ns, wave, acc);
+      w4_zero_acc();
+      w4_loop<NST, false, false, NOP, OPT, DBG>(lds, run, first, ns, wave);
     }
 
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last asm MFMA -> read of D
     if (!idle) {
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          const int j = col_j + wn * 128 + ni * 32 + l31;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int i = col_i + wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const int v = (int)acc[mi][ni][r];  // exact integers below 2^24
-            if (strip.cols > 0) {
-              if (i < n && j >= strip.col0 && j < strip.col0 + strip.cols && v != 0)
-                atomicAdd(&s32[(int64_t)i * strip.cols + (j - strip.col0)], v);
-            } else if (j >= i && j < n && v != 0) {
-              atomicAdd(&s32[(int64_t)i * n + j], v);
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
+      const int i0 = col_i + wm * 128, j0 = col_j + wn * 128;
+      const bool sym = strip.cols == 0;
+      const int64_t ld = sym ? n : strip.cols;
+      const int jorg = sym ? 0 : strip.col0, jend = sym ? n : strip.col0 + strip.cols;
+      // inner: the whole tile inside the matrix and (symmetric job) above the diagonal / (strip) inside the strip's columns
+      const bool inner = sym ? (col_j + 256 <= n && col_i + 256 <= col_j) : (col_i + 256 <= n && col_j >= jorg && col_j + 256 <= jend);
+      if (inner) w4_store<false>(s32, ld, i0, j0, jorg, n, sym, jend, l31, hi);
+      else w4_store<true>(s32, ld, i0, j0, jorg, n, sym, jend, l31, hi);
     }
   }
+#ifdef PCOA_EXPERIMENTS
+  if (threadIdx.x == 0) {
+    const unsigned long long dc = clock64() - clk0, dr = wall_clock64() - rt0;
+    if (b == 8) { g_w4_clk[0] = dc; g_w4_clk[1] = dr; }
+    atomicMax(&g_w4_clk[2], dc);  // the slowest workgroup
+    atomicMax(&g_w4_clk[3], dr);
+  }
+#endif
 }
 
 #endif  // PCOA_KBITS_W4_KERNELS
@@ -446,19 +581,39 @@ hipError_t launch_gram_kbits_w4(const int8_t* p, int64_t nv, int32_t n, int32_t*
   }
   if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
   const dim3 grid((unsigned)nblocks), block(256);
-#define PCOA_LAUNCH_W4(NST_, NOP_)                                                                                      \
-  hipLaunchKernelGGL((gram_kbits_w4_kernel<NST_, NOP_>), grid, block, 0, stream, p, npad, nstages, n, ntile, ntri,        \
-                     (int)splitk, stages_per, s32, xcd_map, skip, strip)
+#define PCOA_LAUNCH_W4(NST_, NOP_, OPT_, DBG_)                                                                            \
+  hipLaunchKernelGGL((gram_kbits_w4_kernel<NST_, NOP_, OPT_, DBG_>), grid, block, 0, stream, p, npad, nstages, n, ntile,   \
+                     ntri, (int)splitk, stages_per, s32, xcd_map, skip, strip)
 #ifdef PCOA_EXPERIMENTS
   switch (g_w4_variant) {
-    case 1: PCOA_LAUNCH_W4(4, 1); break;
-    case 2: PCOA_LAUNCH_W4(4, 0); break;
-    case 3: PCOA_LAUNCH_W4(6, 2); break;
-    case 4: PCOA_LAUNCH_W4(2, 2); break;
-    default: PCOA_LAUNCH_W4(4, 2); break;
+    case 1: PCOA_LAUNCH_W4(4, 0, 0, 0); break;   // builtin DMA, pins behind the MFMA
+    case 2: PCOA_LAUNCH_W4(4, 0, 1, 0); break;   // asm DMA
+    case 3: PCOA_LAUNCH_W4(4, 0, 2, 0); break;   // pins in front of the MFMA
+    case 4: PCOA_LAUNCH_W4(4, 0, 3, 0); break;
+    case 5: PCOA_LAUNCH_W4(4, 0, 7, 0); break;   // + one DMA piece per k-step
+    case 6: PCOA_LAUNCH_W4(6, 0, 7, 0); break;
+    case 7: PCOA_LAUNCH_W4(4, 2, 7, 0); break;   // s_nop 1 in front of every MFMA
+    case 8: PCOA_LAUNCH_W4(4, 0, 13, 0); break;  // sched_barrier instead of pins
+    case 9: PCOA_LAUNCH_W4(4, 0, 21, 0); break;  // sched_barrier behind the MFMA, input pins one gap ahead, output pins
+    case 10: PCOA_LAUNCH_W4(4, 0, 45, 0); break; // sched_barrier instead of pins + one tie per k-step
+    case 11: PCOA_LAUNCH_W4(4, 0, 69, 0); break; // sched_barrier behind the MFMA, output pins only
+    // timing-only builds (wrong S): what is left when a part of the stage is taken out
+    case 101: PCOA_LAUNCH_W4(4, 0, 69, 1); break;   // no expansion VALU
+    case 102: PCOA_LAUNCH_W4(4, 0, 69, 2); break;   // no barrier
+    case 104: PCOA_LAUNCH_W4(4, 0, 69, 4); break;   // no ds_read
+    case 108: PCOA_LAUNCH_W4(4, 0, 69, 8); break;   // no DMA
+    case 112: PCOA_LAUNCH_W4(4, 0, 69, 12); break;  // no ds_read, no DMA
+    case 115: PCOA_LAUNCH_W4(4, 0, 69, 15); break;  // bare MFMAs
+    case 132: PCOA_LAUNCH_W4(4, 0, 69, 32); break;  // everything, but the operand stream is one block read over and over
+    case 133: PCOA_LAUNCH_W4(4, 0, 69, 33); break;  // the same without expansion VALU
+    case 164: PCOA_LAUNCH_W4(4, 0, 69, 64); break;  // everything, every run from block 0: the most L2 sharing there can be
+    case 139: PCOA_LAUNCH_W4(4, 0, 69, 39); break;  // the same without expansion, barrier, ds_read: MFMAs + L2-warm DMA
+    case 12: PCOA_LAUNCH_W4(6, 0, 69, 0); break;
+    case 13: PCOA_LAUNCH_W4(4, 0, 65, 0); break; // both DMA pieces in one gap
+    default: PCOA_LAUNCH_W4(4, 0, 69, 0); break;
   }
 #else
-  PCOA_LAUNCH_W4(4, 2);
+  PCOA_LAUNCH_W4(4, 0, 69, 0);
 #endif
 #undef PCOA_LAUNCH_W4
   return hipGetLastError();

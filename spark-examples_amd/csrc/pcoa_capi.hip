@@ -646,10 +646,18 @@ int fp4_launch(pcoa_ctx* c, int bi, bool overlapped, int side_kind = 1) {
       // k-bits: beside the pre-pass an even split over `pipe_gram_cus` workgroups, else the whole-chip form chosen in fp4_setup
       // (beside the short bitset transpose the even split wins: 1.07 vs 1.11 ms per step, profiles/r03zd)
       const int mode = !side ? c->kbits_mode : !c->coreside ? 4 : (side_kind == 3 ? c->kbits_mode : c->coreside_mode);
-      e = launch_gram_kbits(b.p, b.kb * 32, c->n, c->s32, cus, gs, mode, skip, strip_of(c));
+      // The one-wave-per-SIMD kernel (512 registers per wave, gram_kbits_w4.inl) wherever the contraction has its CUs to
+      // itself; beside the ring pre-pass the two-waves-per-SIMD kernel held to 224 registers, which leaves room for it.
+      const int w4 = debug_knobs().kbits_w4;
+      const bool use_w4 = w4 != 0 && (!(side && c->coreside) || w4 == 2);
+      auto launch = [&](int m) {
+        return use_w4 ? launch_gram_kbits_w4(b.p, b.kb * 32, c->n, c->s32, cus, gs, m, skip, strip_of(c))
+                      : launch_gram_kbits(b.p, b.kb * 32, c->n, c->s32, cus, gs, m, skip, strip_of(c));
+      };
+      e = launch(mode);
       if (e != hipSuccess && mode != 0) {
         (void)hipGetLastError();
-        e = launch_gram_kbits(b.p, b.kb * 32, c->n, c->s32, cus, gs, 0, skip, strip_of(c));
+        e = launch(0);
       } else if (e == hipSuccess) {
         if (mode == 2) c->lockstep_launches += 1;
         if (mode == 4) c->evensplit_launches += 1;
@@ -1160,6 +1168,7 @@ const DebugKnobs& debug_knobs() {
       if (!std::strcmp(v, "bits")) k.operand = 2;
     }
     if (const char* v = std::getenv("PCOA_KBITS_MODE")) k.kbits_mode = std::atoi(v);
+    if (const char* v = std::getenv("PCOA_KBITS_W4")) k.kbits_w4 = std::atoi(v);
     k.kbits_pipe_wgs = (int)num("PCOA_KBITS_PIPE_WGS");
     if (const char* v = std::getenv("PCOA_KBITS_CORESIDE")) k.kbits_coreside = std::atoi(v) != 0;
     k.kbits_ring_wgs = (int)num("PCOA_KBITS_RING_WGS");

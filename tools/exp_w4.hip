@@ -88,9 +88,10 @@ struct Case {
 int main(int argc, char** argv) {
   int n = 2504, reps = 10, num_cu = 256;
   int64_t v = 1 << 20;
-  bool small = true, big = true;
+  bool small = true, big = true, two_streams = false, hot = false;
   uint32_t thr = 0x14000000u;  // ~7.8 %
   std::vector<int> variants = {0, 1, 2, 3};
+  std::vector<int> modes = {4, 2, 0};
   for (int i = 1; i < argc; ++i) {
     if (!std::strcmp(argv[i], "--n") && i + 1 < argc) n = std::atoi(argv[++i]);
     if (!std::strcmp(argv[i], "--v") && i + 1 < argc) v = std::atoll(argv[++i]);
@@ -98,6 +99,13 @@ int main(int argc, char** argv) {
     if (!std::strcmp(argv[i], "--no-small")) small = false;
     if (!std::strcmp(argv[i], "--no-big")) big = false;
     if (!std::strcmp(argv[i], "--dense")) thr = 0x80000000u;
+    if (!std::strcmp(argv[i], "--two-streams")) two_streams = true;
+    if (!std::strcmp(argv[i], "--hot")) hot = true;
+    if (!std::strcmp(argv[i], "--density") && i + 1 < argc) thr = (uint32_t)(std::atof(argv[++i]) * 4294967296.0);
+    if (!std::strcmp(argv[i], "--modes") && i + 1 < argc) {
+      modes.clear();
+      for (char* t = std::strtok(argv[++i], ","); t; t = std::strtok(nullptr, ",")) modes.push_back(std::atoi(t));
+    }
     if (!std::strcmp(argv[i], "--variants") && i + 1 < argc) {
       variants.clear();
       for (char* t = std::strtok(argv[++i], ","); t; t = std::strtok(nullptr, ",")) variants.push_back(std::atoi(t));
@@ -141,7 +149,7 @@ int main(int argc, char** argv) {
     }
     for (int var : variants) {
       g_w4_variant = var;
-      for (int mode : {4, 2, 0}) {
+      for (int mode : modes) {
         if (mode == 2 && gram_lockstep_splitk(cn, num_cu) == 0) continue;
         if (mode == 4 && ntri > 4 * num_cu) continue;
         if (!timeit && mode == 0 && cv > (1 << 16)) continue;
@@ -149,11 +157,55 @@ int main(int argc, char** argv) {
         CK(launch_gram_kbits_w4(k1, cv, cn, s_new, num_cu, 0, mode));
         CK(hipDeviceSynchronize());
         const unsigned long long d = count_diff(s_ref, s_new, sbytes, cnt);
-        if (d) ++fails;
+        if (d && var < 100) ++fails;
         if (timeit) {
+          unsigned long long zero4[4] = {0, 0, 0, 0};
+          CK(hipMemcpyToSymbol(HIP_SYMBOL(g_w4_clk), zero4, sizeof(zero4)));
           const float t = time_ms(reps, [&] { CK(launch_gram_kbits_w4(k1, cv, cn, s_new, num_cu, 0, mode)); });
-          std::printf("n %d v %lld  w4 variant %d mode %d: %.4f ms   diff %llu %s\n", cn, (long long)cv, var, mode, t, d,
-                      d ? "MISMATCH" : "ok");
+          unsigned long long clk[4] = {0, 0, 0, 0};
+          CK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_w4_clk), sizeof(clk)));
+          if (hot) {  // each launch behind 8 GB of HBM traffic, timed alone: the state the library's serial order leaves the chip in
+            char* junk;
+            CK(hipMalloc(&junk, (size_t)4 << 30));
+            hipEvent_t ea, eb;
+            CK(hipEventCreate(&ea)); CK(hipEventCreate(&eb));
+            float tot = 0;
+            for (int r = 0; r < reps; ++r) {
+              CK(hipMemsetAsync(junk, r, (size_t)4 << 30, 0));
+              CK(hipMemsetAsync(junk, r + 1, (size_t)4 << 30, 0));
+              CK(hipEventRecord(ea, 0));
+              CK(launch_gram_kbits_w4(k1, cv, cn, s_new, num_cu, 0, mode));
+              CK(hipEventRecord(eb, 0));
+              CK(hipEventSynchronize(eb));
+              float ms1 = 0;
+              CK(hipEventElapsedTime(&ms1, ea, eb));
+              tot += ms1;
+            }
+            std::printf("n %d v %lld  w4 variant %d mode %d behind 8 GB of memset, one launch per event pair: %.4f ms\n", cn, (long long)cv, var, mode, tot / reps);
+            CK(hipFree(junk));
+          }
+          if (two_streams) {  // consecutive launches on alternating streams: the tail of one overlaps the head of the next
+            hipStream_t st[2];
+            CK(hipStreamCreateWithFlags(&st[0], hipStreamNonBlocking));
+            CK(hipStreamCreateWithFlags(&st[1], hipStreamNonBlocking));
+            hipEvent_t e0, e1, ej;
+            CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&ej));
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0, st[0]));
+            CK(hipStreamWaitEvent(st[1], e0, 0));
+            for (int r = 0; r < 2 * reps; ++r) CK(launch_gram_kbits_w4(k1, cv, cn, s_new, num_cu, st[r & 1], mode));
+            CK(hipEventRecord(ej, st[1]));
+            CK(hipStreamWaitEvent(st[0], ej, 0));
+            CK(hipEventRecord(e1, st[0]));
+            CK(hipEventSynchronize(e1));
+            float ms2 = 0;
+            CK(hipEventElapsedTime(&ms2, e0, e1));
+            std::printf("n %d v %lld  w4 variant %d mode %d on two streams: %.4f ms per launch\n", cn, (long long)cv, var, mode, ms2 / (2 * reps));
+            CK(hipStreamDestroy(st[0])); CK(hipStreamDestroy(st[1]));
+          }
+          std::printf("n %d v %lld  w4 variant %d mode %d: %.4f ms   diff %llu %s   block 8: %llu shader cycles in %.1f us = %.3f GHz; slowest block %llu cycles, %.1f us\n", cn,
+                      (long long)cv, var, mode, t, d, var >= 100 ? "(timing-only build)" : d ? "MISMATCH" : "ok", clk[0], clk[1] / 100.0,
+                      clk[1] ? clk[0] / (clk[1] * 10.0) : 0.0, clk[2], clk[3] / 100.0);
         } else {
           std::printf("n %d v %lld  w4 variant %d mode %d: diff %llu %s\n", cn, (long long)cv, var, mode, d, d ? "MISMATCH" : "ok");
         }
