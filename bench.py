@@ -18,6 +18,8 @@ The PCoA wall-clock (centring + eigensolve + D2H of N x 2, rank 0) is reported i
 Contract: one JSON line on stdout from rank 0.  Launched by the driver as
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes itself under torch.distributed.run
+with N ranks (dist.launch_plan); it exits with an error if fewer than N GPUs are visible or WORLD_SIZE != N.
 """
 import argparse
 import importlib
@@ -104,6 +106,17 @@ def main():
 
     import torch
     import torch.distributed as td
+
+    # --gpus N without a rendezvous in the environment: become the launcher of N ranks (or fail loudly) instead of
+    # running one rank and reporting n_gpus = 1
+    what, detail = pkg("dist").launch_plan(args.gpus, os.environ, torch.cuda.device_count(), [os.path.abspath(__file__)] + sys.argv[1:],
+                                           python=sys.executable)
+    if what == "error":
+        sys.exit("bench.py: " + detail)
+    if what == "spawn":
+        import subprocess
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(detail, env=env))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -532,6 +545,7 @@ def main():
                                      "note": "same cohort as carrier bitsets [V][ceil(N/32)] uint32 "
                                              "(pcoa_accumulate_bits, SURVEY 8d '1-bit-packed twin'); reported separately"}
             del bits
+            out["csr_boundary"] = csr_boundary(P, torch, dev, local_rank, n, x1, s_dense, steps, args.operand)
         if world == 1 and not args.no_extras and args.config2_variants > 0:
             # BASELINE configs[2] on ONE GPU: the whole 40 M-variant cohort as carrier bitsets (12.6 GB, resident), one job
             out["config2_one_gpu_bits"] = config2_one_gpu_bits(P, synth, torch, dev, local_rank, n, args.config2_variants,
@@ -658,6 +672,62 @@ def config2_one_gpu_bits(P, synth, torch, dev, local_rank, n, v, operand):
             "generation_s_outside_the_timed_region": t_gen,
             "note": "parity of this job (shard sum, oracle blocks, eigenpairs): tests/test_gpu_baseline_sizes.py::"
                     "test_config2_full_size_one_cohort_on_one_gpu_bitset_boundary"}
+
+
+def csr_boundary(P, torch, dev, local_rank, n, x1, s_dense_steps, steps, operand):
+    """The reference's own seam at scale: the configs[1] batch as the carrier lists an RDD[Seq[Int]]
+    partition holds (getCallsRdd, VariantsPca.scala:153-168) through pcoa_accumulate_calls_ex, whole job = H2D + scatter into
+    the operand + contraction + finalize.  One leg per place the arrays can live."""
+    v = int(x1.shape[0])
+    counts = torch.zeros(v, dtype=torch.int64, device=dev)
+    cols = []
+    for r0 in range(0, v, 1 << 17):
+        nzr = (x1[r0:r0 + (1 << 17)] != 0)
+        counts[r0:r0 + nzr.shape[0]] = nzr.sum(dim=1)
+        cols.append(nzr.nonzero()[:, 1].to(torch.int32))
+    idx_dev = torch.cat(cols)
+    del cols, nzr
+    offs_dev = torch.zeros(v + 1, dtype=torch.int64, device=dev)
+    offs_dev[1:] = torch.cumsum(counts, 0)
+    nnz = int(offs_dev[-1])
+    bytes_per_variant = (4.0 * nnz + 8.0 * (v + 1)) / v
+    pcie_bound = 63e9 / bytes_per_variant
+    idx_cpu, offs_cpu = idx_dev.cpu(), offs_dev.cpu()
+    idx_pin, offs_pin = idx_cpu.pin_memory(), offs_cpu.pin_memory()
+    half = v // 2 // 128 * 128
+    res = {"workload": "configs[1] batch 0 as carrier lists: %d variants, %d carriers (%.1f per variant), %.0f B per variant"
+                       % (v, nnz, nnz / float(v), bytes_per_variant),
+           "pcie_bound_variants_per_s": pcie_bound, "pcie_gbs_assumed": 63.0}
+    with P.PcoaEngine(n, device=local_rank, operand=operand) as e:
+        e.reserve(v, 0)
+        legs = [("pageable", idx_cpu, offs_cpu, False, 1), ("pinned", idx_pin, offs_pin, False, 1),
+                ("pinned_async_two_halves", idx_pin, offs_pin, True, 2), ("device", idx_dev, offs_dev, False, 1)]
+        for name, ti, to, asyn, parts in legs:
+            for timed in (False, True):
+                e.reset(); e.reset_timings(); e.sync()
+                t0 = time.perf_counter()
+                if parts == 1:
+                    e.accumulate_calls_tensors(ti, to, asynchronous=asyn)
+                else:   # what a host does that builds batch k+1 while batch k travels: two calls, no wait in between
+                    oh = to[half:] - to[half]
+                    oh = oh.pin_memory() if to.is_pinned() else oh
+                    t0 = time.perf_counter()
+                    e.accumulate_calls_tensors(ti[:int(to[half])], to[:half + 1], asynchronous=asyn)
+                    e.accumulate_calls_tensors(ti[int(to[half]):], oh, asynchronous=asyn)
+                t_call = time.perf_counter() - t0
+                e.finalize(); e.sync()
+                dt = time.perf_counter() - t0
+            tt = e.timings()
+            same = bool(np.array_equal(e.gram() * steps, s_dense_steps))
+            res[name] = {"variants_per_s": v / dt, "frac_of_pcie_bound": (v / dt) / pcie_bound, "seconds": dt,
+                         "seconds_until_the_calls_returned": t_call,
+                         "scatter_kernel_ms": 1e3 * tt["densify_seconds"], "contraction_ms": 1e3 * tt["gram_kernel_seconds"],
+                         "host_staging_copy_s": tt["csr_stage_seconds"], "host_wait_for_device_check_s": tt["csr_wait_seconds"],
+                         "chunks": int(tt["csr_fast_chunks"]), "same_gram_as_dense_input": same}
+    res["note"] = ("device-validated path (range + repeats checked by the scatter kernel; a call reaches S only after its check): "
+                   "pageable arrays are copied into pinned staging by host threads beside the H2D of the previous chunk; "
+                   "PCOA_CSR_LEGACY=1 gives the r03 path (host-serial validation, one staging buffer) for comparison")
+    return res
 
 
 def issued_fraction(n, bm, idle_diag=True):

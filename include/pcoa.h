@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define PCOA_VERSION_MAJOR 0
-#define PCOA_VERSION_MINOR 3
+#define PCOA_VERSION_MINOR 4
 
 typedef struct pcoa_ctx pcoa_ctx;
 
@@ -106,7 +106,13 @@ typedef struct pcoa_timings {
   int32_t pipeline_contraction_cus; /* CUs that contraction occupies (one workgroup each)                        */
   int64_t evensplit_launches;   /* contraction launches in the even-split form (k-bits operand: every workgroup an equal
                                    run of (tile, stage) units, one workgroup per CU)                                */
+  /* ---- r04 (read them with pcoa_get_timings_sized; pcoa_get_timings stops in front of them) ---- */
+  double csr_stage_seconds;     /* carrier lists: HOST seconds spent copying pageable arrays into pinned staging  */
+  double csr_wait_seconds;      /* carrier lists: HOST seconds spent waiting for the device's check of a call     */
+  int64_t csr_fast_chunks;      /* chunks (<= 8 M entries) scattered by the device-validated path                */
+  int64_t csr_redo_chunks;      /* of those: redone on the int8 kernel because a list repeated a callset           */
 } pcoa_timings;
+#define PCOA_TIMINGS_R03_BYTES 192  /* offsetof(pcoa_timings, csr_stage_seconds): what pcoa_get_timings writes */
 
 /* Synthetic genotype model (bench / tests only; not part of the reference).  Sample i belongs to
  * population p iff pop_offsets[p] <= i < pop_offsets[p+1].  Genotype X[v,i] = 1 iff
@@ -200,6 +206,28 @@ int pcoa_reserve(pcoa_ctx* ctx, int64_t variants_per_call, int32_t num_pc);
  * that call's remaining chunks (reported at the next synchronising call at the latest). */
 int pcoa_accumulate_calls(pcoa_ctx* ctx, const int32_t* sample_idx, const int64_t* row_offsets,
                           int64_t n_variants);
+
+/* The same boundary with the caller saying where the arrays live (r04).  flags = 0 is pcoa_accumulate_calls: pageable host
+ * arrays, consumed when the call returns.  What every form shares: the lists travel in chunks of <= 8 M entries through two
+ * staging slots (H2D of chunk k+1 beside the scatter of chunk k), the DEVICE checks them (range, repeats), and a call is
+ * only added to S once its check is clean -- PCOA_ERR_INDEX_RANGE leaves S as it was.
+ *   PCOA_CALLS_HOST_PINNED  the arrays are page-locked (hipHostMalloc / hipHostRegister): the DMA engine reads them directly
+ *                           (no copy into the library's pinned staging: ~10 GB/s per host thread against a 63 GB/s link).
+ *   PCOA_CALLS_ASYNC        the arrays stay valid AND unmodified until the next synchronising call (pcoa_sync,
+ *                           pcoa_gram_finalize, every read / compute / all-reduce / timing call): the call returns when
+ *                           the work is queued; an error in its lists is reported by the call that next validates -- a later
+ *                           accumulate call or that synchronising call -- and S is then unchanged by every call since the
+ *                           last synchronising call that returned PCOA_OK.  A Spark host that builds batch k+1 while batch k
+ *                           is on its way (VariantsPcaNative.scala) wants PINNED | ASYNC with two batch buffers.
+ *   PCOA_CALLS_DEVICE_PTR   both arrays are device pointers (e.g. the output of a device-side VCF / BGEN decoder), read in
+ *                           place; implies the lifetime rule of PCOA_CALLS_ASYNC, like every other device input.
+ * Replaces: the same mapPartitions body (VariantsPca.scala:184-189); the partition iterator of :184 is what makes the
+ * reference's boundary a stream of batches. */
+#define PCOA_CALLS_DEVICE_PTR 1u
+#define PCOA_CALLS_HOST_PINNED 2u
+#define PCOA_CALLS_ASYNC 4u
+int pcoa_accumulate_calls_ex(pcoa_ctx* ctx, const int32_t* sample_idx, const int64_t* row_offsets, int64_t n_variants,
+                             uint32_t flags);
 
 /* Dense boundary: a variants x samples tile, x[v*ld + i] = carrier multiplicity (0.0f / 1.0f for
  * well-formed input: extractCallInfo's hasVariation, VariantsPca.scala:56-60).  `x` is a host
@@ -310,6 +338,9 @@ int pcoa_compute(pcoa_ctx* ctx, int32_t num_pc, double* out_components, double* 
 /* Synchronises and fills *out.  Replaces: reportIoStats' role of printing what was processed
  * (VariantsPca.scala:48,281). */
 int pcoa_get_timings(pcoa_ctx* ctx, pcoa_timings* out);
+/* The struct grows at its end from release to release: pcoa_get_timings writes the r03 layout (PCOA_TIMINGS_R03_BYTES) and
+ * nothing behind it; pass sizeof(pcoa_timings) of the header you compiled against here to receive the newer fields too. */
+int pcoa_get_timings_sized(pcoa_ctx* ctx, pcoa_timings* out, size_t out_size);
 int pcoa_reset_timings(pcoa_ctx* ctx);
 
 /* ---- test hooks (not part of the reference-facing boundary) ---------------------------------------------------------------

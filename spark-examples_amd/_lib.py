@@ -28,6 +28,9 @@ PCOA_FLAG_EIG_HOUSEHOLDER = 0x20
 PCOA_FLAG_EIG_LANCZOS = 0x40
 PCOA_FLAG_NO_PIPELINE = 0x80
 PCOA_FLAG_OPERAND_FP4 = 0x100
+PCOA_CALLS_DEVICE_PTR = 1
+PCOA_CALLS_HOST_PINNED = 2
+PCOA_CALLS_ASYNC = 4
 
 
 class PcoaTimings(ctypes.Structure):
@@ -59,6 +62,10 @@ class PcoaTimings(ctypes.Structure):
         ("pipeline_pre_pass_cus", ctypes.c_int32),
         ("pipeline_contraction_cus", ctypes.c_int32),
         ("evensplit_launches", ctypes.c_int64),
+        ("csr_stage_seconds", ctypes.c_double),
+        ("csr_wait_seconds", ctypes.c_double),
+        ("csr_fast_chunks", ctypes.c_int64),
+        ("csr_redo_chunks", ctypes.c_int64),
     ]
 
 
@@ -97,6 +104,7 @@ _SIGNATURES = [
     ("pcoa_debug_free", ctypes.c_int, [_vp]),
     ("pcoa_debug_guard_mode", ctypes.c_int, []),
     ("pcoa_accumulate_calls", ctypes.c_int, [_vp, _vp, _vp, _i64]),
+    ("pcoa_accumulate_calls_ex", ctypes.c_int, [_vp, _vp, _vp, _i64, ctypes.c_uint32]),
     ("pcoa_accumulate_dense_f32", ctypes.c_int, [_vp, _vp, _i64, _i64, ctypes.c_int]),
     ("pcoa_accumulate_dense_u8", ctypes.c_int, [_vp, _vp, _i64, _i64, ctypes.c_int]),
     ("pcoa_accumulate_bits", ctypes.c_int, [_vp, _vp, _i64, _i64, ctypes.c_int]),
@@ -115,6 +123,7 @@ _SIGNATURES = [
     ("pcoa_center_read_f64", ctypes.c_int, [_vp, _vp, _vp, ctypes.POINTER(_i32), ctypes.POINTER(ctypes.c_double)]),
     ("pcoa_compute", ctypes.c_int, [_vp, _i32, _vp, _vp, ctypes.POINTER(_i32)]),
     ("pcoa_get_timings", ctypes.c_int, [_vp, ctypes.POINTER(PcoaTimings)]),
+    ("pcoa_get_timings_sized", ctypes.c_int, [_vp, ctypes.POINTER(PcoaTimings), ctypes.c_size_t]),
     ("pcoa_reset_timings", ctypes.c_int, [_vp]),
     ("pcoa_device_info", ctypes.c_int, [_vp, ctypes.c_char_p, _i32, ctypes.POINTER(_i32)]),
 ]

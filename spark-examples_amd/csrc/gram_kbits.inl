@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256) void transpose_bits_kbits_kernel(const uint32_
         make_uint4(out[q][0], out[q][1], out[q][2], out[q][3]);
 }
 
-// CSR carrier lists WITHOUT repeats (the host checks) -> k-bits: one wave per variant row, bit (row % 32) of word
+// CSR carrier lists -> k-bits (a list with a repeated callset raises flag bit 5, see below): one wave per variant row, bit (row % 32) of word
 // (row % 128) / 32 in sample c's 16-byte slot of block row / 128, through a 32-bit atomic OR.  Zero-filled beforehand.
 __global__ __launch_bounds__(256) void densify_csr_kbits_kernel(const int32_t* __restrict__ idx,
                                                                 const int64_t* __restrict__ offs, int64_t nv,
@@ -526,7 +526,10 @@ __global__ __launch_bounds__(256) void densify_csr_kbits_kernel(const int32_t* _
       atomicOr(flag, 1);
       continue;
     }
-    atomicOr(p + ((size_t)blk * npad + c) * 4 + (r >> 5), 1u << (r & 31));
+    // (a carrier list that names a callset twice finds its bit already set: flag bit 5 -- the host then redoes the chunk on
+    // the int8 kernel, which counts the repeat with multiplicity as the reference's double loop does, VariantsPca.scala:187)
+    const uint32_t bit = 1u << (r & 31);
+    if (atomicOr(p + ((size_t)blk * npad + c) * 4 + (r >> 5), bit) & bit) atomicOr(flag, 32);
   }
 }
 

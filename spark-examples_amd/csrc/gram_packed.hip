@@ -221,7 +221,8 @@ __global__ __launch_bounds__(256) void densify_csr_fp4_kernel(const int32_t* __r
       continue;
     }
     uint32_t* word = reinterpret_cast<uint32_t*>(p + ((size_t)kb * npad + c) * 16) + (t >> 3);
-    atomicOr(word, 2u << (4 * (t & 7)));
+    const uint32_t bit = 2u << (4 * (t & 7));
+    if (atomicOr(word, bit) & bit) atomicOr(flag, 32);  // a repeated callset: flag bit 5 (densify_csr_kbits_kernel)
   }
 }
 

@@ -9,6 +9,9 @@
 #include <rccl/rccl.h>   // types and prototypes only: the library is bound at run time (rccl_api below), not linked
 
 #include <algorithm>
+#include <chrono>
+#include <cstddef>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -235,6 +238,24 @@ struct pcoa_ctx {
   int64_t csr_idx_cap = 0;
   int64_t* csr_offs = nullptr;
   int64_t csr_offs_cap = 0;
+  // CSR boundary, fast path (calls_fast): two staging slots (device idx / offsets + a pinned host twin for pageable
+  // callers), a copy stream, a flag word of its own, and the chunks whose validation is still owed
+  struct CsrSlot {
+    int32_t* idx = nullptr; int64_t idx_cap = 0;      // device
+    int64_t* offs = nullptr; int64_t offs_cap = 0;    // device
+    int32_t* pin = nullptr; int64_t pin_cap = 0;      // pinned host (entries)
+    int64_t* pin_offs = nullptr; int64_t pin_offs_cap = 0;
+    hipEvent_t copied = nullptr, freed = nullptr;     // H2D of the slot done / densify that read the slot done
+    bool used = false;
+  };
+  CsrSlot cs[2];
+  hipStream_t csr_stream = nullptr;
+  int32_t* csr_flag = nullptr;        // device: bit 0 index out of range, bit 5 a carrier list repeats a callset
+  int32_t* csr_flag_host = nullptr;   // pinned
+  struct CsrPending { const int32_t* idx; const int64_t* offs; int64_t nv; int64_t kb; bool device; };
+  std::vector<CsrPending> csr_pending;  // committed provisionally into the ACTIVE operand buffer, not yet validated
+  double csr_stage_s = 0, csr_wait_s = 0;  // host seconds spent copying into pinned staging / waiting in validation
+  int64_t csr_fast_chunks = 0, csr_redo_chunks = 0;
   uint32_t* thr_dev = nullptr;
   int64_t thr_cap = 0;
   int32_t* sample_pop = nullptr;   // [n]
@@ -417,6 +438,7 @@ int ensure(pcoa_ctx* c, T** buf, int64_t* cap, int64_t need) {
 }
 
 int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+double wall_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // Rows of the fp32 staging tile: 256 MiB for ordinary N; for very wide matrices at least ~16k variants per
 // contraction launch (every launch pays one int32-atomic epilogue per output tile), capped at 8 GiB.
@@ -531,6 +553,7 @@ int fork_to(pcoa_ctx* c, hipStream_t side) {
 }
 
 int int8_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64_t ld);
+int csr_validate(pcoa_ctx* c);
 
 // Lazily creates what the FP4 path needs besides the operand memory: the buffer flags (device + pinned host), the
 // events, and -- where the shape fits -- the two side streams of the fp32 pipeline.
@@ -623,8 +646,12 @@ int fp4_setup(pcoa_ctx* c) {
 // side_kind: what will run beside it (the chunk that found the buffer full): 1 fp32 tile, 2 uint8 tile, 3 bitset tile.
 int fp4_launch(pcoa_ctx* c, int bi, bool overlapped, int side_kind = 1) {
   pcoa_ctx::Fp4Buf& b = c->fb[bi];
+  // carrier lists committed provisionally into this generation are validated (and rolled back, if need be) before the
+  // generation can reach S
+  int rc = (bi == c->fb_active && !c->csr_pending.empty()) ? csr_validate(c) : PCOA_OK;
+  if (rc != PCOA_OK) return rc;
   if (b.kb == 0) return PCOA_OK;
-  int rc = fold_if_needed(c, b.vars);
+  rc = fold_if_needed(c, b.vars);
   if (rc != PCOA_OK) return rc;
   const int64_t per_kb = fp4_kb_bytes(c);
   const int64_t kb_pad = round_up(b.kb, 24);
@@ -723,7 +750,7 @@ int fp4_resolve(pcoa_ctx* c, int bi, bool redo = true) {
 
 // Everything the FP4 path has queued anywhere has finished (and been verified) when this returns.
 int fp4_quiesce(pcoa_ctx* c) {
-  int rc = PCOA_OK;
+  int rc = c->csr_pending.empty() ? PCOA_OK : csr_validate(c);  // a synchronising call: the caller may release its arrays next
   for (int bi = 0; bi < 2 && rc == PCOA_OK; ++bi) rc = fp4_resolve(c, bi);
   if (rc != PCOA_OK) return rc;
   for (auto& b : c->fb)   // pre-passes of a generation still being filled on the masked stream
@@ -751,6 +778,12 @@ int fp4_sync_point(pcoa_ctx* c) {
 
 // S is being replaced or zeroed: what is buffered or in flight for the old S goes with it.
 int fp4_discard(pcoa_ctx* c) {
+  if (!c->csr_pending.empty()) {  // they go with the S they were meant for
+    for (auto& sl : c->cs)
+      if (sl.used) HIP_TRY(c, hipEventSynchronize(sl.freed));
+    c->csr_pending.clear();
+    if (c->csr_flag) HIP_TRY(c, hipMemsetAsync(c->csr_flag, 0, 16, c->stream));
+  }
   for (int bi = 0; bi < 2; ++bi) {
     pcoa_ctx::Fp4Buf& b = c->fb[bi];
     int rc = fp4_resolve(c, bi, false);
@@ -1169,6 +1202,7 @@ const DebugKnobs& debug_knobs() {
     }
     if (const char* v = std::getenv("PCOA_KBITS_MODE")) k.kbits_mode = std::atoi(v);
     if (const char* v = std::getenv("PCOA_KBITS_W4")) k.kbits_w4 = std::atoi(v);
+    if (const char* v = std::getenv("PCOA_CSR_LEGACY")) k.csr_legacy = std::atoi(v) != 0;
     k.kbits_pipe_wgs = (int)num("PCOA_KBITS_PIPE_WGS");
     if (const char* v = std::getenv("PCOA_KBITS_CORESIDE")) k.kbits_coreside = std::atoi(v) != 0;
     k.kbits_ring_wgs = (int)num("PCOA_KBITS_RING_WGS");
@@ -1287,6 +1321,17 @@ void pcoa_destroy(pcoa_ctx* c) {
     if (b.p) dev_free(b.p);
   }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  for (auto& sl : c->cs) {
+    if (sl.copied) (void)hipEventDestroy(sl.copied);
+    if (sl.freed) (void)hipEventDestroy(sl.freed);
+    if (sl.idx) dev_free(sl.idx);
+    if (sl.offs) dev_free(sl.offs);
+    if (sl.pin) (void)hipHostFree(sl.pin);
+    if (sl.pin_offs) (void)hipHostFree(sl.pin_offs);
+  }
+  if (c->csr_stream) (void)hipStreamDestroy(c->csr_stream);
+  if (c->csr_flag) dev_free(c->csr_flag);
+  if (c->csr_flag_host) (void)hipHostFree(c->csr_flag_host);
   if (c->fb_flags_host) (void)hipHostFree(c->fb_flags_host);
   if (c->hw) (void)hipHostFree(c->hw);
   if (c->ws.host_rec) (void)hipHostFree(c->ws.host_rec);
@@ -1384,6 +1429,7 @@ int pcoa_reset(pcoa_ctx* c) {
   HIP_TRY(c, hipMemsetAsync(c->err_flag, 0, 16, c->stream));
   c->variants_in_s32 = 0;
   c->dirty = false;
+  c->strip_centering_set = false;  // S changes: the row means of an earlier computePca no longer belong to it
   return PCOA_OK;
 }
 
@@ -1489,8 +1535,12 @@ int pcoa_accumulate_bits(pcoa_ctx* c, const uint32_t* bits, int64_t n_variants, 
   return PCOA_OK;
 }
 
-int pcoa_accumulate_calls(pcoa_ctx* c, const int32_t* sample_idx, const int64_t* row_offsets, int64_t n_variants) {
-  CHECK_CTX(c);
+}  // extern "C" (the helpers of the carrier-list boundary follow: templates need C++ linkage)
+namespace {
+// The r01-r03 form of the carrier-list boundary: one host pass over every entry (range check, repeats and their largest
+// multiplicity), then chunk by chunk onto whichever engine the ctx runs.  Since r04 it serves what calls_fast cannot: ctxs
+// on the fp32 / int8-only engines, and the chunks in which the device met a repeated callset (rare: nothing a VCF yields).
+int calls_legacy(pcoa_ctx* c, const int32_t* sample_idx, const int64_t* row_offsets, int64_t n_variants) {
   if (n_variants < 0 || !row_offsets) return fail(c, PCOA_ERR_INVALID_ARG, "row_offsets is NULL or n_variants < 0");
   if (n_variants == 0) return PCOA_OK;
   const int64_t nnz_total = row_offsets[n_variants] - row_offsets[0];
@@ -1601,6 +1651,245 @@ int pcoa_accumulate_calls(pcoa_ctx* c, const int32_t* sample_idx, const int64_t*
   return PCOA_OK;
 }
 
+
+// ---- carrier lists, fast path (r04) ------------------------------------------------------------------
+// What bounded the boundary the reference actually has (RDD[Seq[Int]] -> pcoa_accumulate_calls) was the HOST: a serial pass
+// over every carrier before the first byte moved, one device staging buffer (copy k+1 could not overlap densify k), pageable
+// memcpy, a stream synchronisation per call.  Here the device validates (densify_csr_*_kernel: an index outside [0, N)
+// raises bit 0 of csr_flag, a carrier list that names a callset twice -- the atomic OR finds the bit already set -- bit 5),
+// chunks of <= 8 M entries travel through two staging slots on a copy stream (pageable sources through pinned twins filled
+// by a few host threads), and the chunks are committed into the active operand buffer PROVISIONALLY: csr_validate reads
+// the flag before that generation can reach S (fp4_launch), at the end of a synchronous call, and at every synchronising
+// call; a bad chunk list is rolled out of the buffer again (S unchanged), a list with repeats is redone by calls_legacy on
+// the int8 kernel, which counts multiplicities as the reference's double loop does (VariantsPca.scala:187).
+constexpr int64_t kCsrChunkEntries = (int64_t)8 << 20;
+
+int csr_setup(pcoa_ctx* c) {
+  if (c->csr_flag) return PCOA_OK;
+  HIP_TRY(c, hipStreamCreateWithFlags(&c->csr_stream, hipStreamNonBlocking));
+  for (auto& sl : c->cs) {
+    HIP_TRY(c, hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&sl.freed, hipEventDisableTiming));
+  }
+  HIP_TRY(c, hipHostMalloc((void**)&c->csr_flag_host, 64, hipHostMallocDefault));
+  std::memset(c->csr_flag_host, 0, 64);
+  HIP_TRY(c, dev_alloc((void**)&c->csr_flag, 64, c->device));
+  HIP_TRY(c, hipMemsetAsync(c->csr_flag, 0, 64, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return PCOA_OK;
+}
+
+template <typename T>
+int ensure_slot_dev(pcoa_ctx* c, T** buf, int64_t* cap, int64_t need) {
+  if (need <= *cap) return PCOA_OK;
+  if (*buf) dev_free(*buf);  // (the caller has waited for the slot's last reader)
+  *buf = nullptr;
+  *cap = 0;
+  const int64_t newcap = std::max<int64_t>(need + need / 8, 1 << 16);
+  HIP_TRY(c, dev_alloc((void**)buf, sizeof(T) * (size_t)newcap, c->device));
+  *cap = newcap;
+  return PCOA_OK;
+}
+template <typename T>
+int ensure_slot_pin(pcoa_ctx* c, T** buf, int64_t* cap, int64_t need) {
+  if (need <= *cap) return PCOA_OK;
+  if (*buf) (void)hipHostFree(*buf);
+  *buf = nullptr;
+  *cap = 0;
+  const int64_t newcap = std::max<int64_t>(need + need / 8, 1 << 16);
+  HIP_TRY(c, hipHostMalloc((void**)buf, sizeof(T) * (size_t)newcap, hipHostMallocDefault));
+  *cap = newcap;
+  return PCOA_OK;
+}
+
+// src -> dst by a few host threads (a single memcpy into pinned memory runs at ~10 GB/s; the link takes 50)
+void parallel_copy(void* dst, const void* src, size_t bytes) {
+  const size_t kMin = (size_t)4 << 20;
+  unsigned nt = std::min<unsigned>(8, std::max<unsigned>(1, std::thread::hardware_concurrency() / 2));
+  if (bytes < 2 * kMin) nt = 1;
+  nt = (unsigned)std::min<size_t>(nt, (bytes + kMin - 1) / kMin);
+  if (nt <= 1) {
+    std::memcpy(dst, src, bytes);
+    return;
+  }
+  std::vector<std::thread> th;
+  const size_t per = (((bytes + nt - 1) / nt) + 63) & ~(size_t)63;  // nt * per >= bytes (a floor here once lost the last word)
+  for (unsigned t = 0; t < nt; ++t) {
+    const size_t b0 = std::min(bytes, per * t), b1 = std::min(bytes, per * (t + 1));
+    if (b1 > b0) th.emplace_back([=] { std::memcpy((char*)dst + b0, (const char*)src + b0, b1 - b0); });
+  }
+  for (auto& t : th) t.join();
+}
+
+// Validate the provisionally committed carrier-list chunks of the active operand buffer (see above).  Blocks until their
+// densify kernels are done.
+int csr_validate(pcoa_ctx* c) {
+  if (c->csr_pending.empty()) return PCOA_OK;
+  pcoa_ctx::Fp4Buf& b = c->fb[c->fb_active];
+  hipStream_t s = b.fill_stream ? b.fill_stream : c->stream;
+  const double t0 = wall_now();
+  HIP_TRY(c, hipMemcpyAsync(c->csr_flag_host, c->csr_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  c->csr_wait_s += wall_now() - t0;
+  const int32_t flag = c->csr_flag_host[0];
+  std::vector<pcoa_ctx::CsrPending> pend;
+  pend.swap(c->csr_pending);
+  if (flag == 0) return PCOA_OK;
+  // roll the chunks out of the buffer again: nothing of this generation has been contracted (fp4_launch validates first)
+  int64_t kb = 0, vars = 0;
+  for (const auto& q : pend) { kb += q.kb; vars += q.nv; }
+  b.kb -= kb;
+  b.vars -= vars;
+  HIP_TRY(c, hipMemsetAsync(c->csr_flag, 0, sizeof(int32_t), s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  if (flag & 1)
+    return fail(c, PCOA_ERR_INDEX_RANGE, "a callset index outside [0, N) in a carrier list; S is unchanged by the calls "
+                                         "since the last synchronising call that reported no error");
+  if (c->packed_mode == 3)
+    return fail(c, PCOA_ERR_INVALID_ARG,
+                "a carrier list repeats a callset (multiplicity > 1) and PCOA_FLAG_GRAM_FP4_MFMA was forced");
+  // repeats: the same chunks through the int8 kernel, which counts them with multiplicity
+  for (const auto& q : pend) {
+    c->csr_redo_chunks += 1;
+    std::vector<int32_t> hidx;
+    std::vector<int64_t> hoffs;
+    const int32_t* idx = q.idx;
+    const int64_t* offs = q.offs;
+    if (q.device) {
+      hoffs.resize((size_t)q.nv + 1);
+      HIP_TRY(c, hipMemcpy(hoffs.data(), q.offs, sizeof(int64_t) * (size_t)(q.nv + 1), hipMemcpyDeviceToHost));
+      const int64_t b0 = hoffs[0], nnz = hoffs[(size_t)q.nv] - b0;
+      hidx.resize((size_t)std::max<int64_t>(nnz, 1));
+      if (nnz > 0) HIP_TRY(c, hipMemcpy(hidx.data(), q.idx + b0, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost));
+      for (auto& o : hoffs) o -= b0;
+      idx = hidx.data();
+      offs = hoffs.data();
+    }
+    const int rc = calls_legacy(c, idx, offs, q.nv);
+    if (rc != PCOA_OK) return rc;
+  }
+  return PCOA_OK;
+}
+
+int calls_fast(pcoa_ctx* c, const int32_t* sample_idx, const int64_t* row_offsets, int64_t n_variants, uint32_t flags) {
+  const bool device = (flags & PCOA_CALLS_DEVICE_PTR) != 0;
+  const bool pinned = (flags & PCOA_CALLS_HOST_PINNED) != 0;
+  const bool async = device || (flags & PCOA_CALLS_ASYNC) != 0;
+  int rc = csr_setup(c);
+  if (rc != PCOA_OK) return rc;
+  if ((rc = fp4_setup(c)) != PCOA_OK) return rc;
+  // rows per chunk: what one operand buffer takes at most, and (host sources) <= kCsrChunkEntries entries
+  const int64_t rows_cap = std::max<int64_t>(128, std::min<int64_t>(fp4_target_kb(c) * 32, (int64_t)1 << 20));
+  int64_t v0 = 0;
+  int k = 0;
+  while (v0 < n_variants) {
+    int64_t rows = std::min(rows_cap, n_variants - v0);
+    int64_t b0 = 0, nnz = 0;
+    if (!device) {
+      b0 = row_offsets[v0];
+      if (row_offsets[v0 + rows] - b0 > kCsrChunkEntries) {  // largest row count that keeps the chunk under the cap (>= 1)
+        const int64_t* lo = row_offsets + v0 + 1;
+        const int64_t* up = std::upper_bound(lo, row_offsets + v0 + rows + 1, b0 + kCsrChunkEntries);
+        rows = std::max<int64_t>(1, (int64_t)(up - lo));
+      }
+      nnz = row_offsets[v0 + rows] - b0;
+      if (nnz == 0) {  // only empty rows: they add nothing (filtered at VariantsPca.scala:166)
+        v0 += rows;
+        continue;
+      }
+    }
+    // k-bits operand: chunks are whole blocks of 128 variants except the last of the call
+    if (c->op_fmt == 2 && v0 + rows < n_variants && rows >= 128) rows = rows / 128 * 128, nnz = device ? 0 : row_offsets[v0 + rows] - b0;
+    const int32_t* idx_dev = sample_idx;
+    const int64_t* offs_dev = row_offsets + v0;
+    int64_t offs_base = 0;
+    pcoa_ctx::CsrSlot& sl = c->cs[k & 1];
+    if (!device) {
+      if (sl.used) HIP_TRY(c, hipEventSynchronize(sl.freed));  // its last densify has read the slot (and its H2D is long done)
+      if ((rc = ensure_slot_dev(c, &sl.idx, &sl.idx_cap, nnz)) != PCOA_OK) return rc;
+      if ((rc = ensure_slot_dev(c, &sl.offs, &sl.offs_cap, rows + 1)) != PCOA_OK) return rc;
+      const int32_t* src = sample_idx + b0;
+      const int64_t* osrc = row_offsets + v0;
+      if (!pinned) {
+        const double t0 = wall_now();
+        if ((rc = ensure_slot_pin(c, &sl.pin, &sl.pin_cap, nnz)) != PCOA_OK) return rc;
+        if ((rc = ensure_slot_pin(c, &sl.pin_offs, &sl.pin_offs_cap, rows + 1)) != PCOA_OK) return rc;
+        parallel_copy(sl.pin, src, sizeof(int32_t) * (size_t)nnz);
+        std::memcpy(sl.pin_offs, osrc, sizeof(int64_t) * (size_t)(rows + 1));
+        src = sl.pin;
+        osrc = sl.pin_offs;
+        c->csr_stage_s += wall_now() - t0;
+      }
+      HIP_TRY(c, hipMemcpyAsync(sl.idx, src, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, c->csr_stream));
+      HIP_TRY(c, hipMemcpyAsync(sl.offs, osrc, sizeof(int64_t) * (size_t)(rows + 1), hipMemcpyHostToDevice, c->csr_stream));
+      HIP_TRY(c, hipEventRecord(sl.copied, c->csr_stream));
+      idx_dev = sl.idx;
+      offs_dev = sl.offs;
+      offs_base = b0;
+    }
+    const int64_t kb = kb_of(c, rows);
+    int8_t* dst = nullptr;
+    hipStream_t ps = nullptr;
+    if ((rc = fp4_reserve(c, kb, rows, 0, false, &dst, &ps, nullptr)) != PCOA_OK) return rc;
+    if (!device) HIP_TRY(c, hipStreamWaitEvent(ps, sl.copied, 0));
+    {
+      ScopedTimer t(c, T_DENSIFY, ps);
+      HIP_TRY(c, c->op_fmt == 2 ? launch_densify_csr_kbits(idx_dev, offs_dev, rows, offs_base, dst, c->n, c->csr_flag, ps, kb / 4)
+                                : launch_densify_csr_fp4(idx_dev, offs_dev, rows, offs_base, dst, c->n, c->csr_flag, ps, kb));
+    }
+    if (!device) {
+      HIP_TRY(c, hipEventRecord(sl.freed, ps));
+      sl.used = true;
+    }
+    fp4_commit(c, kb, rows);
+    c->csr_pending.push_back({device ? sample_idx : sample_idx, row_offsets + v0, rows, kb, device});
+    c->csr_fast_chunks += 1;
+    v0 += rows;
+    ++k;
+  }
+  if (!async) return csr_validate(c);  // the caller may release (or rewrite) its arrays once this returns
+  return PCOA_OK;
+}
+
+}  // namespace
+extern "C" {
+
+int pcoa_accumulate_calls_ex(pcoa_ctx* c, const int32_t* sample_idx, const int64_t* row_offsets, int64_t n_variants,
+                             uint32_t flags) {
+  CHECK_CTX(c);
+  if (n_variants < 0 || !row_offsets) return fail(c, PCOA_ERR_INVALID_ARG, "row_offsets is NULL or n_variants < 0");
+  if (flags & ~(uint32_t)(PCOA_CALLS_DEVICE_PTR | PCOA_CALLS_HOST_PINNED | PCOA_CALLS_ASYNC))
+    return fail(c, PCOA_ERR_INVALID_ARG, "unknown PCOA_CALLS_* flag");
+  if (n_variants == 0) return PCOA_OK;
+  const bool device = (flags & PCOA_CALLS_DEVICE_PTR) != 0;
+  if (!device) {
+    const int64_t nnz_total = row_offsets[n_variants] - row_offsets[0];
+    if (nnz_total < 0 || (nnz_total > 0 && !sample_idx))
+      return fail(c, PCOA_ERR_INVALID_ARG, "sample_idx is NULL or row_offsets decreasing");
+    for (int64_t v = 0; v < n_variants; ++v)  // (8 bytes per variant: not the pass over the entries)
+      if (row_offsets[v + 1] < row_offsets[v]) return fail(c, PCOA_ERR_INVALID_ARG, "row_offsets not monotone");
+  } else if (!sample_idx) {
+    return fail(c, PCOA_ERR_INVALID_ARG, "sample_idx is NULL");
+  }
+  // the engines with a binary-tile operand take the fast path; fp32-MFMA and int8-only ctxs the host-validated one
+  const bool fast = c->use_i8 && c->packed_mode != 2 && !debug_knobs().csr_legacy;
+  if (fast) return calls_fast(c, sample_idx, row_offsets, n_variants, flags);
+  if (!device) return calls_legacy(c, sample_idx, row_offsets, n_variants);
+  // device arrays on an engine without the fast path: through the host
+  std::vector<int64_t> hoffs((size_t)n_variants + 1);
+  HIP_TRY(c, hipMemcpy(hoffs.data(), row_offsets, sizeof(int64_t) * (size_t)(n_variants + 1), hipMemcpyDeviceToHost));
+  const int64_t b0 = hoffs[0], nnz = hoffs[(size_t)n_variants] - b0;
+  if (nnz < 0) return fail(c, PCOA_ERR_INVALID_ARG, "row_offsets decreasing");
+  std::vector<int32_t> hidx((size_t)std::max<int64_t>(nnz, 1));
+  if (nnz > 0) HIP_TRY(c, hipMemcpy(hidx.data(), sample_idx + b0, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost));
+  for (auto& o : hoffs) o -= b0;
+  return calls_legacy(c, hidx.data(), hoffs.data(), n_variants);
+}
+
+int pcoa_accumulate_calls(pcoa_ctx* c, const int32_t* sample_idx, const int64_t* row_offsets, int64_t n_variants) {
+  return pcoa_accumulate_calls_ex(c, sample_idx, row_offsets, n_variants, 0);
+}
+
 int pcoa_synth_fill_f32(pcoa_ctx* c, const pcoa_synth_params* p, int64_t first_variant, int64_t n_variants,
                         float* x_dev, int64_t ld) {
   CHECK_CTX(c);
@@ -1673,6 +1962,7 @@ int pcoa_gram_import_device_i64(pcoa_ctx* c, const int64_t* src_dev) {
   HIP_TRY(c, hipMemsetAsync(c->s32, 0, sizeof(int32_t) * nn, c->stream));
   c->variants_in_s32 = 0;
   c->dirty = false;
+  c->strip_centering_set = false;  // (also reached from pcoa_gram_load_i64: checkpoint resume replaces S)
   return PCOA_OK;
 }
 
@@ -2065,12 +2355,16 @@ int pcoa_strip_matvec_device(pcoa_ctx* c, const double* v_dev, double* y_dev) {
   return PCOA_OK;
 }
 
-int pcoa_get_timings(pcoa_ctx* c, pcoa_timings* out) {
+// The struct grows at its end from release to release; the caller says how many bytes ITS pcoa_timings has (a
+// shim built against an older header must not have its stack overwritten by a newer library).
+int pcoa_get_timings_sized(pcoa_ctx* c, pcoa_timings* out_user, size_t out_size) {
   CHECK_CTX(c);
-  if (!out) return fail(c, PCOA_ERR_INVALID_ARG, "out is NULL");
+  if (!out_user || out_size < sizeof(double)) return fail(c, PCOA_ERR_INVALID_ARG, "out is NULL or out_size too small");
   int rc0 = fp4_sync_point(c);
   if (rc0 != PCOA_OK) return rc0;
   drain_events(c, true);
+  pcoa_timings full;
+  pcoa_timings* out = &full;
   std::memset(out, 0, sizeof(*out));
   out->gram_kernel_seconds = c->tsec[T_GRAM];
   out->gram_kernel_launches = c->gram_launches;
@@ -2105,8 +2399,17 @@ int pcoa_get_timings(pcoa_ctx* c, pcoa_timings* out) {
   out->pack_seconds = c->tsec[T_PACK];
   out->pack_launches = c->pack_launches;
   out->pack_bytes = c->pack_bytes;
+  out->csr_stage_seconds = c->csr_stage_s;
+  out->csr_wait_seconds = c->csr_wait_s;
+  out->csr_fast_chunks = c->csr_fast_chunks;
+  out->csr_redo_chunks = c->csr_redo_chunks;
+  std::memcpy(out_user, out, std::min(out_size, sizeof(full)));
   return PCOA_OK;
 }
+
+static_assert(offsetof(pcoa_timings, csr_stage_seconds) == PCOA_TIMINGS_R03_BYTES, "the r03 prefix of pcoa_timings is frozen");
+// the r03 layout (ends behind evensplit_launches), whatever the struct has grown to since
+int pcoa_get_timings(pcoa_ctx* c, pcoa_timings* out) { return pcoa_get_timings_sized(c, out, PCOA_TIMINGS_R03_BYTES); }
 
 int pcoa_reset_timings(pcoa_ctx* c) {
   CHECK_CTX(c);
@@ -2114,6 +2417,8 @@ int pcoa_reset_timings(pcoa_ctx* c) {
   if (rc0 != PCOA_OK) return rc0;
   drain_events(c, true);
   for (double& t : c->tsec) t = 0;
+  c->csr_stage_s = c->csr_wait_s = 0;
+  c->csr_fast_chunks = c->csr_redo_chunks = 0;
   c->gram_launches = 0;
   c->gram_variants = 0;
   c->gram_flops = c->gram_bytes = 0;

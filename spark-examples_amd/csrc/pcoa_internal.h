@@ -35,6 +35,7 @@ struct DebugKnobs {
   int operand = 0;                 // PCOA_OPERAND = fp4 | bits -> 1 | 2: operand of the binary-tile contraction (0 = default)
   int kbits_mode = -1;             // PCOA_KBITS_MODE = 0 | 2 | 4: launch form of the k-bits contraction (whole chip)
   int kbits_pipe_wgs = 0;          // PCOA_KBITS_PIPE_WGS: workgroups of the k-bits contraction beside the fp32 pre-pass
+  int csr_legacy = 0;              // PCOA_CSR_LEGACY = 1: pcoa_accumulate_calls through the host-validated r03 path
   int kbits_w4 = -1;               // PCOA_KBITS_W4 = 0 | 1 | 2: one-wave-per-SIMD contraction (gram_kbits_w4.inl): 0 never, 1 wherever the kernel has its CUs to itself (default), 2 also beside the ring pre-pass
   int kbits_coreside = -1;         // PCOA_KBITS_CORESIDE = 0 | 1: fp32 pipeline with pre-pass and contraction on the SAME CUs (ring pre-pass)
   int kbits_ring_wgs = 0;          // PCOA_KBITS_RING_WGS: workgroups of the ring pre-pass beside a contraction (default 2 per CU)

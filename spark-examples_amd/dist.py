@@ -22,6 +22,31 @@ def shard_range(rank, world_size, n_variants):
     return start, start + base + (1 if rank < extra else 0)
 
 
+def launch_plan(gpus, env, device_count, argv, python="python"):
+    """What a script asked for `--gpus N` has to do (bench.py, tools/config5_strips.py).  Returns
+      ("run", None)        this process IS a rank (WORLD_SIZE set, e.g. under torch.distributed.run) or N == 1
+      ("spawn", command)   N > 1 and no rendezvous in the environment: re-execute under torch.distributed.run with one
+                           rank per GPU (rendezvous on 127.0.0.1: the container's host name may not resolve)
+      ("error", message)   the request cannot be honoured: fewer than N devices, or WORLD_SIZE disagrees with N.
+    A `--gpus 8` run that silently used one rank would report n_gpus = 1 (Missing 2)."""
+    gpus = int(gpus)
+    if gpus < 1:
+        return "error", "--gpus must be >= 1"
+    world = env.get("WORLD_SIZE")
+    if world is not None:
+        if int(world) != gpus:
+            return "error", "--gpus %d but WORLD_SIZE=%s: launch one rank per GPU" % (gpus, world)
+        return "run", None
+    if gpus == 1:
+        return "run", None
+    if device_count < gpus:
+        return "error", "--gpus %d but only %d GPU(s) are visible" % (gpus, device_count)
+    port = env.get("MASTER_PORT", "29531")
+    cmd = [python, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + list(argv)
+    return "spawn", cmd
+
+
 def allreduce_gram_tensor(t, group=None):
     """In-place sum of an int64 [N][N] tensor over the process group (CPU/gloo or GPU/RCCL)."""
     import torch.distributed as dist

@@ -136,6 +136,28 @@ class PcoaEngine(object):
             idx = np.zeros(1, dtype=np.int32)
         self._check(self._lib.pcoa_accumulate_calls(self._ctx, _ptr(idx), _ptr(offs), offs.size - 1))
 
+    def accumulate_calls_tensors(self, sample_idx, row_offsets, asynchronous=False):
+        """The same boundary for torch tensors (plumbing: memory handles only) -- pcoa_accumulate_calls_ex:
+        CUDA tensors are read in place (PCOA_CALLS_DEVICE_PTR), pinned CPU tensors by the DMA engine (PCOA_CALLS_HOST_PINNED),
+        other CPU tensors like numpy arrays.  asynchronous=True (PCOA_CALLS_ASYNC): return when the work is queued; the tensors
+        are kept alive (and must stay unmodified) until the next synchronising call."""
+        import torch
+        assert sample_idx.dtype == torch.int32 and row_offsets.dtype == torch.int64
+        assert sample_idx.dim() == 1 and row_offsets.dim() == 1 and sample_idx.is_contiguous() and row_offsets.is_contiguous()
+        assert sample_idx.device == row_offsets.device
+        flags = 0
+        if sample_idx.is_cuda:
+            flags |= L.PCOA_CALLS_DEVICE_PTR
+            torch.cuda.current_stream(sample_idx.device).synchronize()   # the engine runs on its own stream
+        elif sample_idx.is_pinned() and row_offsets.is_pinned():
+            flags |= L.PCOA_CALLS_HOST_PINNED
+        if asynchronous and not sample_idx.is_cuda:
+            flags |= L.PCOA_CALLS_ASYNC
+        if flags & (L.PCOA_CALLS_DEVICE_PTR | L.PCOA_CALLS_ASYNC):
+            self._keepalive.append((sample_idx, row_offsets))
+        self._check(self._lib.pcoa_accumulate_calls_ex(self._ctx, ctypes.c_void_p(sample_idx.data_ptr()),
+                                                       ctypes.c_void_p(row_offsets.data_ptr()), int(row_offsets.shape[0]) - 1, flags))
+
     def accumulate_callsets(self, callsets):
         """Convenience: list of per-variant index lists."""
         offs = np.zeros(len(callsets) + 1, dtype=np.int64)
@@ -340,7 +362,7 @@ class PcoaEngine(object):
     # ------------------------------------------------------------------ instrumentation
     def timings(self):
         t = L.PcoaTimings()
-        self._check(self._lib.pcoa_get_timings(self._ctx, ctypes.byref(t)))
+        self._check(self._lib.pcoa_get_timings_sized(self._ctx, ctypes.byref(t), ctypes.sizeof(t)))
         return dict((f[0], getattr(t, f[0])) for f in L.PcoaTimings._fields_ if f[0] != "reserved")
 
     def reset_timings(self):

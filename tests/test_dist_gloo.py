@@ -61,3 +61,17 @@ def test_single_process_allreduce_is_identity():
     assert np.array_equal(dist.allreduce_gram_numpy(s), s)
     t = torch.ones(2, 2, dtype=torch.int64)
     assert dist.allreduce_gram_tensor(t) is t
+
+
+def test_gpus_n_without_a_rendezvous_spawns_n_ranks_or_fails_loudly():
+    """bench.py --gpus N started the way the driver starts --gpus 1 must not run one rank and print n_gpus = 1."""
+    dist = load_pkg("dist")
+    assert dist.launch_plan(1, {}, 1, ["bench.py"]) == ("run", None)
+    assert dist.launch_plan(8, {"WORLD_SIZE": "8", "RANK": "3"}, 8, ["bench.py"]) == ("run", None)
+    what, cmd = dist.launch_plan(8, {}, 8, ["bench.py", "--gpus", "8", "--steps", "5"], python="py")
+    assert what == "spawn" and cmd[:3] == ["py", "-m", "torch.distributed.run"]
+    assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-5:] == ["bench.py", "--gpus", "8", "--steps", "5"]
+    assert dist.launch_plan(8, {}, 1, ["bench.py"])[0] == "error"          # fewer devices than ranks
+    assert dist.launch_plan(8, {"WORLD_SIZE": "2"}, 8, ["bench.py"])[0] == "error"   # the launcher disagrees with --gpus
+    assert dist.launch_plan(0, {}, 8, ["bench.py"])[0] == "error"

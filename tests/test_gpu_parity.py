@@ -367,6 +367,103 @@ def test_index_out_of_range_is_rejected_and_leaves_s_unchanged(P):
             eng.compute(6)  # MLlib: require(k > 0 && k <= n)
 
 
+def _csr_of(x):
+    """(sample_idx int32, row_offsets int64) of a dense 0/1 matrix [V][N]."""
+    rows, cols = np.nonzero(x)
+    offs = np.zeros(x.shape[0] + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rows, minlength=x.shape[0]), out=offs[1:])
+    return cols.astype(np.int32), offs
+
+
+@pytest.mark.parametrize("where", ["pageable", "pinned", "pinned_async", "device"])
+def test_carrier_lists_from_pageable_pinned_and_device_memory_give_the_oracle_matrix(P, O, where):
+    """pcoa_accumulate_calls_ex (r04): the device validates, the lists travel in chunks through two staging slots; the result is
+    the oracle's S whatever memory the arrays live in, across several calls, with an operand-buffer switch in between."""
+    import torch
+    rng = np.random.default_rng(77)
+    n, v = 300, 6000
+    x = (rng.random((v, n)) < 0.11).astype(np.float32)
+    x[17] = 0                      # an empty row (legal: the reference filters it, VariantsPca.scala:166)
+    want = O.similarity_from_dense(x, n)
+    with P.PcoaEngine(n) as eng:
+        for lo, hi in ((0, 1), (1, 2500), (2500, 2501), (2501, 6000)):
+            idx, offs = _csr_of(x[lo:hi])
+            ti, to = torch.from_numpy(idx), torch.from_numpy(offs)
+            if where == "device":
+                ti, to = ti.cuda(), to.cuda()
+            elif where != "pageable":
+                ti, to = ti.pin_memory(), to.pin_memory()
+            eng.accumulate_calls_tensors(ti, to, asynchronous=(where == "pinned_async"))
+        assert np.array_equal(eng.gram(), want)
+        tim = eng.timings()
+        assert tim["gram_kernel_kind"] == 3 and tim["csr_fast_chunks"] >= 4 and tim["csr_redo_chunks"] == 0
+
+
+def test_pageable_carrier_lists_whose_size_is_not_a_multiple_of_the_copy_split(P):
+    """Regression (r04): the threaded copy into pinned staging cut a chunk into floor(bytes / threads) pieces and lost the chunk's
+    last entry whenever that floor was already a multiple of 64.  Chunks of 8 * 2^20 * 4 + 4 bytes and neighbours, pageable
+    against device arrays (which are not staged)."""
+    import torch
+    n = 64
+    for nnz in (8 * (1 << 20) + 1, 8 * (1 << 20) + 17, 3 * (1 << 20) + 5):
+        v = nnz // 32 + 1
+        g = torch.Generator().manual_seed(nnz)
+        # rows of 32 distinct callsets each (the last one shorter): a random 32-subset of 64 per row
+        perm = torch.argsort(torch.rand((v, n), generator=g), dim=1)[:, :32].to(torch.int32)
+        perm, _ = torch.sort(perm, dim=1)
+        idx = perm.reshape(-1)[:nnz].contiguous()
+        offs = torch.clamp(torch.arange(v + 1, dtype=torch.int64) * 32, max=nnz)
+        with P.PcoaEngine(n) as a, P.PcoaEngine(n) as b:
+            a.accumulate_calls_tensors(idx, offs)
+            b.accumulate_calls_tensors(idx.cuda(), offs.cuda())
+            assert np.array_equal(a.gram(), b.gram())
+
+
+@pytest.mark.parametrize("where", ["pageable", "pinned_async", "device"])
+def test_the_device_side_check_of_carrier_lists_rejects_rolls_back_and_redoes(P, O, where):
+    """(a) an index outside [0, N): PCOA_ERR_INDEX_RANGE -- from the call itself when it is synchronous, from the next
+    synchronising call when the arrays were handed over asynchronously -- and S unchanged by the rejected lists;
+    (b) a list that names a callset twice: found by the scatter's atomic OR, the chunk redone on the int8 kernel with the
+    reference's multiplicities (VariantsPca.scala:187); the engine keeps working afterwards."""
+    import torch
+
+    def feed(eng, callsets):
+        offs = np.zeros(len(callsets) + 1, dtype=np.int64)
+        for i, c in enumerate(callsets):
+            offs[i + 1] = offs[i] + len(c)
+        idx = np.fromiter((j for c in callsets for j in c), dtype=np.int32, count=int(offs[-1]))
+        ti, to = torch.from_numpy(idx), torch.from_numpy(offs)
+        if where == "device":
+            ti, to = ti.cuda(), to.cuda()
+        elif where == "pinned_async":
+            ti, to = ti.pin_memory(), to.pin_memory()
+        eng.accumulate_calls_tensors(ti, to, asynchronous=(where == "pinned_async"))
+
+    n = 40
+    good = [[0, 1, 39], [2], [5, 6, 7, 8], [], [39]]
+    with P.PcoaEngine(n) as eng:
+        feed(eng, good)
+        before = eng.gram()
+        assert np.array_equal(before, O.similarity_matrix_python_loops(good, n))
+        for bad in ([[0, 40]], [[-1]], [[1], [2, 77], [3]]):
+            with pytest.raises(P.IndexRangeError):
+                feed(eng, bad)
+                eng.sync()          # asynchronous / device arrays: the check is reported here at the latest
+            assert np.array_equal(eng.gram(), before)
+        # repeats: multiplicity semantics of the reference's double loop
+        rep = [[0, 0, 1], [2], [1, 2, 2, 2], [3, 4]]
+        feed(eng, rep)
+        want = before + O.similarity_matrix_python_loops(rep, n)
+        assert np.array_equal(eng.gram(), want)
+        assert eng.timings()["csr_redo_chunks"] >= 1
+        feed(eng, good)
+        assert np.array_equal(eng.gram(), want + before)
+    with P.PcoaEngine(n, gram_kernel="fp4") as eng:   # the forced FP4 engine refuses a multiplicity
+        with pytest.raises(P.PcoaError):
+            feed(eng, [[0, 0, 1]])
+            eng.sync()
+
+
 def test_accumulation_is_additive_shard_invariant_and_resumable(P, O):
     rng = np.random.default_rng(11)
     n, v = 150, 900

@@ -111,6 +111,27 @@ def test_strip_creation_is_validated(P):
             e.strip_col_sums()
 
 
+def test_resident_centring_does_not_outlive_the_matrix_it_was_computed_for(P):
+    """pcoa.h: the row means of pcoa_strip_set_centering stay resident only until S changes.  pcoa_reset and
+    pcoa_gram_load_i64 (checkpoint resume) replace S as well: a later pcoa_strip_matvec_device must refuse (PCOA_ERR_STATE)
+    instead of multiplying the new S by the old row means."""
+    import torch
+    n = 300
+    with P.PcoaEngine(n, strip=(40, 120)) as e:
+        e.accumulate_callsets([[1, 50, 60], [50, 299], [41, 42, 43]])
+        v = torch.ones(n, dtype=torch.float64, device="cuda:0")
+        e.strip_set_centering(np.full(n, 0.25), 0.125)
+        assert e.strip_matvec_device(v).shape[0] == 120
+        e.load_gram(e.gram())
+        with pytest.raises(P.PcoaError):
+            e.strip_matvec_device(v)
+        e.strip_set_centering(np.full(n, 0.25), 0.125)
+        e.strip_matvec_device(v)
+        e.reset()
+        with pytest.raises(P.PcoaError):
+            e.strip_matvec_device(v)
+
+
 def test_strips_at_biobank_sample_count_match_the_single_engine(P):
     """N = 100,000 (BASELINE configs[3] sample count; 391 tile rows, many bands): two strip owners with a cut that is
     not tile-aligned against ONE engine holding all of S (40 GB) -- blocks on both sides of the diagonal and of the cut,
