@@ -255,6 +255,17 @@ int pcoa_accumulate_dense_u8(pcoa_ctx* ctx, const uint8_t* x, int64_t n_variants
 int pcoa_accumulate_bits(pcoa_ctx* ctx, const uint32_t* bits, int64_t n_variants, int64_t ld_words,
                          int is_device_ptr);
 
+/* PLINK 1 binary genotypes as they lie in a variant-major .bed file (r04): bed_rows[v * row_bytes + s / 4] holds sample s of
+ * variant v in bits 2 (s % 4): 00 homozygous A1, 01 missing, 10 heterozygous, 11 homozygous A2; row_bytes >= ceil(N / 4) (the
+ * file's own pitch is exactly that; the three magic bytes are the caller's to skip).  A sample is a carrier of the variant --
+ * hasVariation, VariantsPca.scala:56-60 -- iff its code is 10 or the homozygous NON-reference one: 00 when A2 is the reference
+ * allele (plink --keep-allele-order / plink2 --make-bed; ref_is_a1 = 0), 11 when A1 is (ref_is_a1 = 1); a missing call
+ * carries nothing.  The decode runs on the device (a host only reads the file: 626 B per variant at N = 2504), then the
+ * bitset path of pcoa_accumulate_bits.  Host or device pointer as there.
+ * Replaces: the same RDD[Seq[Int]] rows (getCallsRdd, VariantsPca.scala:153-168) for a cohort stored as a PLINK fileset. */
+int pcoa_accumulate_plink_bed(pcoa_ctx* ctx, const uint8_t* bed_rows, int64_t n_variants, int64_t row_bytes, int ref_is_a1,
+                              int is_device_ptr);
+
 /* Generates variants [first_variant, first_variant + n_variants) of the synthetic model directly
  * in HBM and accumulates them (no host tile).  params->thresholds covers exactly that range. */
 int pcoa_accumulate_synthetic(pcoa_ctx* ctx, const pcoa_synth_params* params, int64_t first_variant,
@@ -293,6 +304,19 @@ int pcoa_comm_runtime(char* path_out, int32_t path_cap, int32_t* version_out);
 int pcoa_comm_init(pcoa_ctx* ctx, const uint8_t id[128], int32_t rank, int32_t n_ranks,
                    void** comm_out);
 int pcoa_comm_destroy(void* nccl_comm);
+
+/* Page-locked host memory for input blocks a host fills and hands to the accumulate calls (hipHostMalloc): the DMA engine
+ * reads it at link speed, pageable memory goes through the runtime's staging copy at a third of that.  Process-wide, not tied
+ * to a ctx; at least one ctx (i.e. a HIP device) must exist.  (A JVM host passes such a block as a direct ByteBuffer.) */
+int pcoa_host_alloc_pinned(size_t bytes, void** out);
+int pcoa_host_free_pinned(void* p);
+
+/* dst.S += src.S for two engines of the SAME process (r04): what a host with one ctx per GPU -- k host threads, no
+ * collective runtime -- calls after the accumulation (host/variants_pca_driver --gpus k; a Spark executor with several GPUs).
+ * Both ctxs are synchronised; src's total crosses by hipMemcpyPeerAsync (xGMI on a node; the ctxs may also share a device) and
+ * is added into dst's int64 matrix; src is unchanged.  Integer sums: order and grouping of the reductions do not matter.
+ * Replaces: reduceByKey(_ + _, conf.numReducePartitions()) (VariantsPca.scala:190, GenomicsConf.scala:42-45) inside one JVM. */
+int pcoa_gram_reduce_from(pcoa_ctx* dst, pcoa_ctx* src);
 
 /* Host-driven reduction alternative (bench.py uses torch.distributed, whose "nccl" backend is RCCL):
  * export copies the finalized S as int64 [N][N] into a DEVICE buffer; import replaces S with the

@@ -156,6 +156,54 @@ hipError_t launch_fold_i32_to_i64(int32_t* s32, int64_t* s64, int64_t count, hip
   return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void add_i64_kernel(int64_t* __restrict__ dst, const int64_t* __restrict__ src, int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+
+hipError_t launch_add_i64(int64_t* dst, const int64_t* src, int64_t count, hipStream_t stream) {
+  hipLaunchKernelGGL(add_i64_kernel, dim3(grid_for(count, 256, 8192)), dim3(256), 0, stream, dst, src, count);
+  return hipGetLastError();
+}
+
+// PLINK 1 .bed rows (variant-major, 2 bits per genotype, sample s in bits 2 (s % 4) of byte s / 4: 00 hom A1, 01 missing,
+// 10 het, 11 hom A2) -> carrier bitsets (the pcoa_accumulate_bits layout).  hasVariation (VariantsPca.scala:56-60) with A2 the
+// reference allele = code 00 or 10; ref_a1: 11 or 10.  One thread = one output word = 32 samples = 8 bytes of the row.
+__global__ __launch_bounds__(256) void plink_bed_to_bits_kernel(const uint8_t* __restrict__ bed, int64_t row_bytes, int64_t nv,
+                                                                int32_t n, int64_t words, int ref_a1, uint32_t* __restrict__ bits) {
+  const int64_t total = nv * words;
+  for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = gid / words, w = gid - r * words;
+    const uint8_t* row = bed + r * row_bytes;
+    uint64_t x = 0;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const int64_t at = 8 * w + b;
+      if (at < row_bytes) x |= (uint64_t)row[at] << (8 * b);
+    }
+    const uint64_t E = 0x5555555555555555ull;
+    const uint64_t lo = x & E, hi = (x >> 1) & E;
+    uint64_t m = (hi & ~lo) | (ref_a1 ? (hi & lo) : (~hi & ~lo & E));  // carrier flags in the even bit positions
+    m = (m | (m >> 1)) & 0x3333333333333333ull;                            // ... squeezed into the low 32 bits
+    m = (m | (m >> 2)) & 0x0f0f0f0f0f0f0f0full;
+    m = (m | (m >> 4)) & 0x00ff00ff00ff00ffull;
+    m = (m | (m >> 8)) & 0x0000ffff0000ffffull;
+    m = (m | (m >> 16)) & 0x00000000ffffffffull;
+    const int64_t first = 32 * w;
+    uint32_t keep = 0xffffffffu;
+    if (first >= n) keep = 0u;
+    else if (first + 32 > n) keep = (1u << (n - (int32_t)first)) - 1u;
+    bits[gid] = (uint32_t)m & keep;
+  }
+}
+
+hipError_t launch_plink_bed_to_bits(const uint8_t* bed, int64_t row_bytes, int64_t nv, int32_t n, int64_t words, int ref_a1,
+                                    uint32_t* bits, hipStream_t stream) {
+  if (nv <= 0) return hipSuccess;
+  hipLaunchKernelGGL(plink_bed_to_bits_kernel, dim3(grid_for(nv * words, 256, 16384)), dim3(256), 0, stream, bed, row_bytes, nv, n,
+                     words, ref_a1, bits);
+  return hipGetLastError();
+}
+
 hipError_t launch_export_i64(const int32_t* s32, const int64_t* s64_or_null, int64_t* dst, int64_t count,
                              hipStream_t stream) {
   hipLaunchKernelGGL(export_kernel, dim3(grid_for(count, 256, 8192)), dim3(256), 0, stream, s32, s64_or_null,

@@ -256,6 +256,8 @@ struct pcoa_ctx {
   std::vector<CsrPending> csr_pending;  // committed provisionally into the ACTIVE operand buffer, not yet validated
   double csr_stage_s = 0, csr_wait_s = 0;  // host seconds spent copying into pinned staging / waiting in validation
   int64_t csr_fast_chunks = 0, csr_redo_chunks = 0;
+  uint8_t* bed_raw = nullptr;      // raw PLINK .bed rows of one chunk (pcoa_accumulate_plink_bed, host input)
+  int64_t bed_raw_cap = 0;
   uint32_t* thr_dev = nullptr;
   int64_t thr_cap = 0;
   int32_t* sample_pop = nullptr;   // [n]
@@ -1335,7 +1337,7 @@ void pcoa_destroy(pcoa_ctx* c) {
   if (c->fb_flags_host) (void)hipHostFree(c->fb_flags_host);
   if (c->hw) (void)hipHostFree(c->hw);
   if (c->ws.host_rec) (void)hipHostFree(c->ws.host_rec);
-  void* bufs[] = {c->s32, c->s64, c->zeros, c->err_flag, c->tile, c->csr_idx, c->csr_offs, c->thr_dev,
+  void* bufs[] = {c->s32, c->s64, c->zeros, c->err_flag, c->tile, c->csr_idx, c->csr_offs, c->thr_dev, c->bed_raw,
                   c->sample_pop, c->xfer, c->coll, c->fb_flags, c->strip_ws, c->strip_means, c->pack_buf, c->lanczos_ws, c->ws.a, c->ws.d, c->ws.e, c->ws.tau, c->ws.q, c->ws.w, c->ws.lam,
                   c->ws.z, c->ws.wy, c->ws.scratch, c->ws.iscratch, c->row_sums, c->colmean, c->stats, c->nz,
                   c->out_dev};
@@ -1532,6 +1534,42 @@ int pcoa_accumulate_bits(pcoa_ctx* c, const uint32_t* bits, int64_t n_variants, 
     if (rc != PCOA_OK) return rc;
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return PCOA_OK;
+}
+
+// PLINK 1 .bed rows as they lie in the file (r04): decoded on the device.  The host's share of a whole-genome fileset is
+// then reading it; 626 B per variant cross PCIe at N = 2504 (a 100 M variants/s link bound) instead of carrier lists or
+// host-built bitsets.  Chunks of <= 2^17 rows: raw rows -> plink_bed_to_bits_kernel -> the bitset transpose -> operand.
+int pcoa_accumulate_plink_bed(pcoa_ctx* c, const uint8_t* bed_rows, int64_t n_variants, int64_t row_bytes, int ref_is_a1,
+                              int is_device_ptr) {
+  CHECK_CTX(c);
+  if (n_variants < 0 || (n_variants > 0 && !bed_rows)) return fail(c, PCOA_ERR_INVALID_ARG, "bed_rows is NULL or n_variants < 0");
+  if (row_bytes < ((int64_t)c->n + 3) / 4) return fail(c, PCOA_ERR_INVALID_ARG, "row_bytes must be >= ceil(n_samples / 4)");
+  if (!c->use_i8)
+    return fail(c, PCOA_ERR_INVALID_ARG, "the PLINK boundary needs a packed-operand engine (not PCOA_FLAG_GRAM_F32_MFMA)");
+  if (n_variants == 0) return PCOA_OK;
+  const int64_t words = ((int64_t)c->n + 31) / 32;
+  const int64_t rows_cap = std::min<int64_t>(n_variants, (int64_t)1 << 17);
+  int rc = ensure(c, &c->tile, &c->tile_elems, rows_cap * words);
+  if (rc != PCOA_OK) return rc;
+  if (!is_device_ptr && (rc = ensure(c, &c->bed_raw, &c->bed_raw_cap, rows_cap * row_bytes)) != PCOA_OK) return rc;
+  uint32_t* bits = reinterpret_cast<uint32_t*>(c->tile);
+  for (int64_t v0 = 0; v0 < n_variants; v0 += rows_cap) {
+    const int64_t rows = std::min(rows_cap, n_variants - v0);
+    const uint8_t* src = bed_rows + v0 * row_bytes;
+    if (!is_device_ptr) {
+      HIP_TRY(c, hipMemcpyAsync(c->bed_raw, src, (size_t)(rows * row_bytes), hipMemcpyHostToDevice, c->stream));
+      src = c->bed_raw;
+    }
+    {
+      ScopedTimer t(c, T_DENSIFY);
+      HIP_TRY(c, launch_plink_bed_to_bits(src, row_bytes, rows, c->n, words, ref_is_a1 ? 1 : 0, bits, c->stream));
+    }
+    if ((rc = gram_device_bits(c, bits, rows, words, false)) != PCOA_OK) return rc;
+  }
+  // host rows are consumed, and the shared staging buffers are free for the next call, once the stream has drained; a
+  // device input (read by the decode kernel only) follows the lifetime rule of every device input
+  if (!is_device_ptr) HIP_TRY(c, hipStreamSynchronize(c->stream));
   return PCOA_OK;
 }
 
@@ -1948,6 +1986,62 @@ int pcoa_gram_export_device_i64(pcoa_ctx* c, int64_t* dst_dev) {
   if (rc != PCOA_OK) return rc;
   if ((rc = check_device_flags(c)) != PCOA_OK) return rc;  // never hand out an S that an input check has invalidated
   HIP_TRY(c, launch_export_i64(c->s32, c->s64, dst_dev, (int64_t)s_count(c), c->stream));
+  return PCOA_OK;
+}
+
+// Page-locked host memory for a host's input blocks (the compiled host streams .bed blocks through two of them: a copy from
+// pageable memory crosses the link at ~14 GB/s, from pinned memory at ~50).  Not tied to a ctx.
+int pcoa_host_alloc_pinned(size_t bytes, void** out) {
+  if (!out || bytes == 0) return PCOA_ERR_INVALID_ARG;
+  *out = nullptr;
+  return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? PCOA_OK : PCOA_ERR_HIP;
+}
+int pcoa_host_free_pinned(void* p) {
+  if (!p) return PCOA_OK;
+  return hipHostFree(p) == hipSuccess ? PCOA_OK : PCOA_ERR_HIP;
+}
+
+// dst.S += src.S for two engines of ONE process (r04): the reduction step of a host that runs one ctx per GPU from its own
+// threads (host/variants_pca_driver --gpus k), without a collective runtime.  src's total leaves as int64 (export), crosses to
+// dst's device by hipMemcpyPeerAsync (xGMI between the GPUs of a node; a plain read when both ctxs sit on one device) and is
+// added into dst's int64 matrix.  Integer sums: the result does not depend on the order in which partials are reduced.
+int pcoa_gram_reduce_from(pcoa_ctx* dst, pcoa_ctx* src) {
+  CHECK_CTX(dst);
+  if (!src) return fail(dst, PCOA_ERR_INVALID_ARG, "src ctx is NULL");
+  if (src == dst) return fail(dst, PCOA_ERR_INVALID_ARG, "src and dst are the same ctx");
+  if (src->n != dst->n || src->s_cols != dst->s_cols || src->strip_col0 != dst->strip_col0 || src->is_strip != dst->is_strip)
+    return fail(dst, PCOA_ERR_INVALID_ARG, "reduce_from: the two engines hold different matrices (n / strip)");
+  const size_t nn = s_count(dst);
+  // src: everything contracted, mirrored, checked, exported as int64 on its own device
+  {
+    pcoa_ctx* c = src;
+    CHECK_CTX(c);
+    if (!c->xfer) HIP_TRY(c, dev_alloc((void**)&c->xfer, sizeof(int64_t) * nn, c->device));
+    int rc = pcoa_gram_export_device_i64(c, c->xfer);
+    if (rc != PCOA_OK) {
+      dst->last_error = "reduce_from: src: " + src->last_error;
+      return rc;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  pcoa_ctx* c = dst;
+  CHECK_CTX(c);
+  int rc = finalize_impl(c);
+  if (rc != PCOA_OK) return rc;
+  if ((rc = check_device_flags(c)) != PCOA_OK) return rc;
+  {
+    ScopedTimer t(c, T_FINALIZE);
+    if ((rc = fold_now(c)) != PCOA_OK) return rc;  // dst's total in its int64 matrix (symmetric), S32 = 0
+  }
+  const int64_t* from = src->xfer;
+  if (src->device != c->device) {
+    if (!c->xfer) HIP_TRY(c, dev_alloc((void**)&c->xfer, sizeof(int64_t) * nn, c->device));
+    HIP_TRY(c, hipMemcpyPeerAsync(c->xfer, c->device, src->xfer, src->device, sizeof(int64_t) * nn, c->stream));
+    from = c->xfer;
+  }
+  HIP_TRY(c, launch_add_i64(c->s64, from, (int64_t)nn, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->strip_centering_set = false;
   return PCOA_OK;
 }
 

@@ -133,6 +133,9 @@ hipError_t launch_symmetrize_i32(int32_t* s32, int32_t n, hipStream_t stream);
 hipError_t launch_fold_i32_to_i64(int32_t* s32, int64_t* s64, int64_t count, hipStream_t stream);
 hipError_t launch_export_i64(const int32_t* s32, const int64_t* s64_or_null, int64_t* dst, int64_t count,
                              hipStream_t stream);
+hipError_t launch_plink_bed_to_bits(const uint8_t* bed, int64_t row_bytes, int64_t nv, int32_t n, int64_t words, int ref_a1,
+                                    uint32_t* bits, hipStream_t stream);
+hipError_t launch_add_i64(int64_t* dst, const int64_t* src, int64_t count, hipStream_t stream);
 hipError_t launch_synth_fill_f32(uint64_t seed, const uint32_t* thresholds_dev, const int32_t* sample_pop_dev,
                                  int32_t n_pops, int64_t first_variant, int64_t nv, int32_t n, float* x_dev,
                                  int64_t ld, hipStream_t stream);

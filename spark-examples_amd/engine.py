@@ -224,6 +224,22 @@ class PcoaEngine(object):
         ldv = a.shape[1] if ld_words is None else int(ld_words)
         self._check(self._lib.pcoa_accumulate_bits(self._ctx, _ptr(a), nv, ldv, 0))
 
+    def accumulate_plink_bed(self, rows, ref_is_a1=False):
+        """Raw variant-major PLINK .bed rows, numpy uint8 [V][row_bytes] (host) or a torch uint8 CUDA tensor: decoded on the
+        device (pcoa_accumulate_plink_bed)."""
+        if hasattr(rows, "data_ptr") and getattr(rows, "is_cuda", False):
+            import torch  # plumbing only
+            assert rows.dtype == torch.uint8 and rows.dim() == 2 and rows.stride(1) == 1
+            self._keepalive.append(rows)
+            torch.cuda.current_stream(rows.device).synchronize()
+            self._check(self._lib.pcoa_accumulate_plink_bed(self._ctx, ctypes.c_void_p(rows.data_ptr()), int(rows.shape[0]),
+                                                            int(rows.stride(0)), int(bool(ref_is_a1)), 1))
+            return
+        a = np.ascontiguousarray(rows, dtype=np.uint8)
+        if a.ndim != 2:
+            raise ValueError("rows must be [variants][row_bytes]")
+        self._check(self._lib.pcoa_accumulate_plink_bed(self._ctx, _ptr(a), a.shape[0], a.shape[1], int(bool(ref_is_a1)), 0))
+
     def accumulate_dense_device_ptr(self, ptr, n_variants, ld):
         self._check(self._lib.pcoa_accumulate_dense_f32(self._ctx, ctypes.c_void_p(int(ptr)), int(n_variants),
                                                         int(ld), 1))
@@ -272,6 +288,10 @@ class PcoaEngine(object):
         if a.shape != (self.n, self.cols):
             raise ValueError("expected an %d x %d matrix" % (self.n, self.cols))
         self._check(self._lib.pcoa_gram_load_i64(self._ctx, _ptr(a)))
+
+    def reduce_from(self, other):
+        """self.S += other.S (two engines of this process; pcoa_gram_reduce_from: peer copy + int64 add, no collective)."""
+        self._check(self._lib.pcoa_gram_reduce_from(self._ctx, other._ctx))
 
     def export_device(self, dst_ptr):
         self._check(self._lib.pcoa_gram_export_device_i64(self._ctx, ctypes.c_void_p(int(dst_ptr))))

@@ -38,6 +38,12 @@
 #include <spawn.h>
 #include <sys/wait.h>
 #include <unistd.h>
+#include <fcntl.h>
+#include <functional>
+#include <future>
+#include <mutex>
+#include <condition_variable>
+#include <sys/resource.h>
 
 extern char** environ;
 
@@ -59,6 +65,13 @@ struct Conf {  // PcaConf / GenomicsConf (GenomicsConf.scala:31-101), same flag 
   int num_pc = 2, num_reduce_partitions = 10, gpu = 0;
   long bases_per_partition = 1000000;
   std::string client_secrets, spark_master;
+  // r04: the variant-sharded job of BASELINE configs[2] from the command line (VariantsPca.scala:190: partitions + reduceByKey)
+  int gpus = 1;                       // --gpus k: k host threads, one engine per device, variants dealt by contiguous ranges
+  std::vector<int> gpu_map;           // --gpu-map a,b,..: device ordinal of each engine (default: --gpu, --gpu + 1, ..)
+  std::string reduce = "auto";        // --reduce auto|rccl|peer: all-reduce over RCCL / peer copies + int64 adds
+  std::string plink_decode = "device";  // --plink-decode device|host: where the 2-bit codes become carrier bits
+  long stream_rows = 65536;           // --stream-rows: variants per block of the streaming PLINK reader
+  bool no_stream = false;             // --no-stream: PLINK through the in-memory path of r03 (carrier lists)
 };
 
 [[noreturn]] void die(const std::string& m) {
@@ -91,6 +104,17 @@ Conf parse(int argc, char** argv) {
     else if (a == "--client-secrets") c.client_secrets = one(i);
     else if (a == "--spark-master") c.spark_master = one(i);
     else if (a == "--gpu") c.gpu = std::atoi(one(i).c_str());
+    else if (a == "--gpus") c.gpus = std::atoi(one(i).c_str());
+    else if (a == "--gpu-map") {
+      std::stringstream ss(one(i));
+      std::string tok;
+      c.gpu_map.clear();
+      while (std::getline(ss, tok, ',')) c.gpu_map.push_back(std::atoi(tok.c_str()));
+    }
+    else if (a == "--reduce") c.reduce = one(i);
+    else if (a == "--plink-decode") c.plink_decode = one(i);
+    else if (a == "--stream-rows") c.stream_rows = std::atol(one(i).c_str());
+    else if (a == "--no-stream") c.no_stream = true;
     else if (a == "--parse-only") c.parse_only = true;
     else if (a == "--dump-similarity") c.dump_similarity = one(i);
     else if (a == "--ingest-threads") c.ingest_threads = std::atoi(one(i).c_str());
@@ -100,6 +124,13 @@ Conf parse(int argc, char** argv) {
     }
     else die("unknown flag " + a);
   }
+  if (c.gpus < 1) die("--gpus must be >= 1");
+  if (c.gpu_map.empty())
+    for (int g = 0; g < c.gpus; ++g) c.gpu_map.push_back(c.gpu + g);
+  if ((int)c.gpu_map.size() != c.gpus) die("--gpu-map must name exactly --gpus devices");
+  if (c.reduce != "auto" && c.reduce != "rccl" && c.reduce != "peer") die("--reduce takes auto, rccl or peer");
+  if (c.plink_decode != "device" && c.plink_decode != "host") die("--plink-decode takes device or host");
+  if (c.stream_rows < 1) die("--stream-rows must be >= 1");
   return c;
 }
 
@@ -453,10 +484,17 @@ std::string plink_chrom_name(const std::string& chrom) {
   return chrom;
 }
 
-Dataset load_plink(const std::string& path, const std::string& stem, const std::vector<Region>& regions, int32_t index_base,
-                   bool ref_a1) {
-  const std::string prefix = path.substr(0, path.size() - 4);
-  Dataset d;
+struct PlinkMeta {
+  std::string prefix;
+  std::vector<std::string> ids, names;
+  std::vector<char> keep;  // per .bim line: inside --references and on a contig the reference keeps
+  size_t n = 0, bpv = 0;   // samples; bytes per variant row of the .bed
+};
+
+PlinkMeta read_plink_meta(const std::string& path, const std::string& stem, const std::vector<Region>& regions) {
+  PlinkMeta m;
+  m.prefix = path.substr(0, path.size() - 4);
+  const std::string& prefix = m.prefix;
   {
     std::ifstream fam(prefix + ".fam");
     if (!fam) die("cannot open " + prefix + ".fam");
@@ -465,13 +503,12 @@ Dataset load_plink(const std::string& path, const std::string& stem, const std::
       std::istringstream is(line);
       std::string fid, iid;
       if (!(is >> fid >> iid)) continue;
-      d.names.push_back(iid);
-      d.ids.push_back(stem + "-" + std::to_string(d.ids.size()));
+      m.names.push_back(iid);
+      m.ids.push_back(stem + "-" + std::to_string(m.ids.size()));
     }
   }
-  const size_t n = d.ids.size();
-  if (n == 0) die("no samples in " + prefix + ".fam");
-  std::vector<char> keep;
+  m.n = m.ids.size();
+  if (m.n == 0) die("no samples in " + prefix + ".fam");
   {
     std::ifstream bim(prefix + ".bim");
     if (!bim) die("cannot open " + prefix + ".bim");
@@ -488,21 +525,40 @@ Dataset load_plink(const std::string& path, const std::string& stem, const std::
         for (const auto& r : regions)
           if (r.contig == contig && r.start <= bp - 1 && bp - 1 < r.end) { ok = true; break; }
       }
-      keep.push_back(ok ? 1 : 0);
+      m.keep.push_back(ok ? 1 : 0);
     }
   }
-  std::ifstream bed(prefix + ".bed", std::ios::binary);
+  m.bpv = (m.n + 3) / 4;
+  // the .bed must be exactly 3 + variants * bpv bytes
+  std::ifstream bed(prefix + ".bed", std::ios::binary | std::ios::ate);
   if (!bed) die("cannot open " + prefix + ".bed");
+  const std::streamoff size = bed.tellg();
+  bed.seekg(0);
   unsigned char magic[3] = {0, 0, 0};
   bed.read(reinterpret_cast<char*>(magic), 3);
   if (!bed || magic[0] != 0x6c || magic[1] != 0x1b) die(prefix + ".bed: not a PLINK 1 binary file");
   if (magic[2] != 1) die(prefix + ".bed is sample-major; only the variant-major layout is read");
-  const size_t bpv = (n + 3) / 4;
+  const std::streamoff want = 3 + (std::streamoff)(m.keep.size() * m.bpv);
+  if (size < want) die(prefix + ".bed is shorter than its .bim / .fam say");
+  if (size > want) die(prefix + ".bed is longer than its .bim / .fam say");
+  return m;
+}
+
+// the in-memory form (r03; --no-stream, --parse-only): carrier lists of every kept variant
+Dataset load_plink(const std::string& path, const std::string& stem, const std::vector<Region>& regions, int32_t index_base,
+                   bool ref_a1) {
+  PlinkMeta m = read_plink_meta(path, stem, regions);
+  Dataset d;
+  d.ids = m.ids;
+  d.names = m.names;
+  const size_t n = m.n, bpv = m.bpv;
+  std::ifstream bed(m.prefix + ".bed", std::ios::binary);
+  bed.seekg(3);
   std::vector<unsigned char> row(bpv);
-  for (size_t v = 0; v < keep.size(); ++v) {
+  for (size_t v = 0; v < m.keep.size(); ++v) {
     bed.read(reinterpret_cast<char*>(row.data()), (std::streamsize)bpv);
-    if ((size_t)bed.gcount() != bpv) die(prefix + ".bed is shorter than its .bim / .fam say");
-    if (!keep[v]) continue;
+    if ((size_t)bed.gcount() != bpv) die(m.prefix + ".bed is shorter than its .bim / .fam say");
+    if (!m.keep[v]) continue;
     Variant var;
     for (size_t s = 0; s < n; ++s) {
       const unsigned code = (row[s >> 2] >> (2 * (s & 3))) & 3u;
@@ -510,8 +566,188 @@ Dataset load_plink(const std::string& path, const std::string& stem, const std::
     }
     d.variants.push_back(std::move(var));
   }
-  if (bed.peek() != std::ifstream::traits_type::eof()) die(prefix + ".bed is longer than its .bim / .fam say");
   return d;
+}
+
+// ---- r04: one engine per GPU ---------------------------------------------------------------------------------------------
+// Contiguous, balanced ranges: the first (total mod k) shards get one unit more (dist.shard_range of the Python host; the
+// reference's partitions, VariantsPca.scala:184).
+void shard_range(int g, int k, int64_t total, int64_t* b, int64_t* e) {
+  const int64_t base = total / k, extra = total % k;
+  *b = g * base + std::min<int64_t>(g, extra);
+  *e = *b + base + (g < extra ? 1 : 0);
+}
+
+// 2-bit PLINK codes of one row -> carrier bitset words (host decode, --plink-decode host): 8 bytes = 32 samples = one word
+void bed_row_to_bits(const unsigned char* row, size_t bpv, size_t n, bool ref_a1, uint32_t* out, size_t words) {
+  const uint64_t E = 0x5555555555555555ull;
+  for (size_t w = 0; w < words; ++w) {
+    uint64_t x = 0;
+    const size_t at = 8 * w, have = at < bpv ? std::min<size_t>(8, bpv - at) : 0;
+    std::memcpy(&x, row + at, have);  // little-endian host
+    const uint64_t lo = x & E, hi = (x >> 1) & E;
+    uint64_t m = (hi & ~lo) | (ref_a1 ? (hi & lo) : (~hi & ~lo & E));
+    m = (m | (m >> 1)) & 0x3333333333333333ull;
+    m = (m | (m >> 2)) & 0x0f0f0f0f0f0f0f0full;
+    m = (m | (m >> 4)) & 0x00ff00ff00ff00ffull;
+    m = (m | (m >> 8)) & 0x0000ffff0000ffffull;
+    m = (m | (m >> 16)) & 0x00000000ffffffffull;
+    uint32_t keep = 0xffffffffu;
+    if (32 * w >= n) keep = 0;
+    else if (32 * w + 32 > n) keep = (1u << (n - 32 * w)) - 1u;
+    out[w] = (uint32_t)m & keep;
+  }
+}
+
+struct StreamStats {
+  std::mutex mu;
+  int64_t variants = 0;
+  double read_s = 0, feed_s = 0;
+};
+
+// Shard g of a PLINK fileset, streamed: blocks of --stream-rows variants are read (pread, own descriptor) one block ahead of
+// the engine, rows outside --references squeezed out, and handed over as they lie in the file (device decode) or as bitsets
+// decoded here.  Never more than two blocks in memory per engine (VariantsRDD.compute is an iterator, rdd/VariantsRDD.scala:
+// 205-235; the reference never holds a data set either).
+void stream_plink_shard(const Conf& conf, const PlinkMeta& m, int g, int k, pcoa_ctx* ctx, StreamStats* st,
+                        unsigned char* const (&buf)[2]) {
+  int64_t r0, r1;
+  shard_range(g, k, (int64_t)m.keep.size(), &r0, &r1);
+  const int fd = ::open((m.prefix + ".bed").c_str(), O_RDONLY);
+  if (fd < 0) die("cannot open " + m.prefix + ".bed");
+  const int64_t block = conf.stream_rows;
+  const size_t bpv = m.bpv, words = (m.n + 31) / 32;
+  const bool ref_a1 = conf.plink_ref_allele == "a1";
+  // buf: two page-locked blocks of --stream-rows rows (pcoa_host_alloc_pinned): the engine's DMA reads them at link speed
+  const unsigned read_threads = std::max(1u, std::min(4u, std::thread::hardware_concurrency() / (2u * (unsigned)k)));
+  std::vector<uint32_t> bits;
+  if (conf.plink_decode == "host") bits.resize((size_t)block * words);
+  auto read_block = [&](int64_t b0, int which) -> int64_t {  // returns kept rows, compacted to the front of buf[which]
+    const int64_t rows = std::min(block, r1 - b0);
+    const size_t want = (size_t)rows * bpv;
+    auto read_range = [&](size_t lo, size_t hi) {  // (one pread stream copies out of the page cache at ~6 GB/s: a few side by side)
+      while (lo < hi) {
+        const ssize_t r = ::pread(fd, buf[which] + lo, hi - lo, (off_t)(3 + (size_t)b0 * bpv + lo));
+        if (r <= 0) die(m.prefix + ".bed: read error");
+        lo += (size_t)r;
+      }
+    };
+    if (read_threads <= 1 || want < ((size_t)8 << 20)) {
+      read_range(0, want);
+    } else {
+      std::vector<std::thread> rt;
+      const size_t per = (want + read_threads - 1) / read_threads;
+      for (unsigned t = 0; t < read_threads; ++t) {
+        const size_t lo = std::min(want, per * t), hi = std::min(want, per * (t + 1));
+        if (hi > lo) rt.emplace_back(read_range, lo, hi);
+      }
+      for (auto& x : rt) x.join();
+    }
+    int64_t kept = 0;
+    for (int64_t r = 0; r < rows; ++r) {
+      if (!m.keep[(size_t)(b0 + r)]) continue;
+      if (kept != r) std::memmove(buf[which] + (size_t)kept * bpv, buf[which] + (size_t)r * bpv, bpv);
+      ++kept;
+    }
+    return kept;
+  };
+  double read_s = 0, feed_s = 0;
+  int64_t total = 0;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto secs = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
+  int which = 0;
+  std::future<int64_t> next;
+  auto t0 = now();
+  int64_t kept = r0 < r1 ? read_block(r0, 0) : 0;
+  read_s += secs(t0, now());
+  for (int64_t b0 = r0; b0 < r1; b0 += block) {
+    const int64_t b1 = b0 + block;
+    if (b1 < r1) next = std::async(std::launch::async, read_block, b1, which ^ 1);  // the next block is read beside this one's feed
+    auto t1 = now();
+    if (kept > 0) {
+      if (conf.plink_decode == "host") {
+        const unsigned nt = std::max(1u, std::min<unsigned>(conf.ingest_threads > 0 ? (unsigned)conf.ingest_threads : std::thread::hardware_concurrency(), 16u) / (unsigned)k);
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t)
+          th.emplace_back([&, t] {
+            for (int64_t r = t; r < kept; r += nt)
+              bed_row_to_bits(buf[which] + (size_t)r * bpv, bpv, m.n, ref_a1, bits.data() + (size_t)r * words, words);
+          });
+        for (auto& x : th) x.join();
+        check(ctx, pcoa_accumulate_bits(ctx, bits.data(), kept, (int64_t)words, 0), "getSimilarityMatrix");
+      } else {
+        check(ctx, pcoa_accumulate_plink_bed(ctx, buf[which], kept, (int64_t)bpv, ref_a1 ? 1 : 0, 0), "getSimilarityMatrix");
+      }
+      total += kept;
+    }
+    feed_s += secs(t1, now());
+    if (b1 < r1) {
+      auto t2 = now();
+      kept = next.get();
+      read_s += secs(t2, now());  // (only what the feed did not hide)
+      which ^= 1;
+    }
+  }
+  ::close(fd);
+  std::lock_guard<std::mutex> lk(st->mu);
+  st->variants += total;
+  st->read_s = std::max(st->read_s, read_s);
+  st->feed_s = std::max(st->feed_s, feed_s);
+}
+
+// k engines, fed by k host threads, reduced into engine 0 (VariantsPca.scala:190: reduceByKey).  RCCL where every engine has
+// a device of its own and the collective runtime binds; else peer copies + int64 adds (pcoa_gram_reduce_from), which also work
+// with several engines on ONE device (--gpu-map 0,0: the way this path is tested on a single-GPU box).
+pcoa_ctx* run_engines(const Conf& conf, int32_t n, const std::function<void(int, int, pcoa_ctx*)>& feed, std::string* how,
+                      double* feed_seconds, const std::function<void()>& prepare) {
+  const int k = conf.gpus;
+  std::vector<pcoa_ctx*> ctx((size_t)k, nullptr);
+  for (int g = 0; g < k; ++g)
+    if (pcoa_create(&ctx[(size_t)g], n, conf.gpu_map[(size_t)g], PCOA_FLAG_DEFAULT) != PCOA_OK)
+      die("pcoa_create on device " + std::to_string(conf.gpu_map[(size_t)g]) + ": " + pcoa_last_error(nullptr));
+  // operand buffers and the computePca workspace now, not inside the first accumulate calls (pcoa_reserve: the warm-up a Spark
+  // executor runs once per GPU)
+  for (int g = 0; g < k; ++g) check(ctx[(size_t)g], pcoa_reserve(ctx[(size_t)g], (int64_t)1 << 20, g == 0 ? conf.num_pc : 0), "pcoa_reserve");
+  bool distinct = true;
+  for (int a = 0; a < k; ++a)
+    for (int b = a + 1; b < k; ++b) distinct = distinct && conf.gpu_map[(size_t)a] != conf.gpu_map[(size_t)b];
+  bool use_rccl = k > 1 && (conf.reduce == "rccl" || (conf.reduce == "auto" && distinct));
+  if (use_rccl && !distinct) die("--reduce rccl needs a device of its own for every engine");
+  uint8_t uid[128] = {0};
+  if (use_rccl && pcoa_comm_unique_id(uid) != PCOA_OK) {
+    if (conf.reduce == "rccl") die("pcoa_comm_unique_id failed: no collective runtime");
+    use_rccl = false;  // auto: no RCCL to bind -> peer reduction
+  }
+  std::vector<int> rccl_rc((size_t)k, PCOA_OK);
+  std::vector<std::thread> th;
+  prepare();  // (what the feed needs once a HIP device is up: the pinned blocks of the streaming reader)
+  const auto t_feed = std::chrono::steady_clock::now();  // engines exist: from here to the reduced S is the job
+  for (int g = 0; g < k; ++g)
+    th.emplace_back([&, g] {
+      feed(g, k, ctx[(size_t)g]);
+      if (use_rccl) {  // every rank reaches the collective from its own thread
+        void* comm = nullptr;
+        int rc = pcoa_comm_init(ctx[(size_t)g], uid, g, k, &comm);
+        if (rc == PCOA_OK) rc = pcoa_gram_allreduce_rccl(ctx[(size_t)g], comm);
+        if (comm) (void)pcoa_comm_destroy(comm);
+        rccl_rc[(size_t)g] = rc;
+      }
+    });
+  for (auto& t : th) t.join();
+  if (use_rccl) {
+    for (int g = 0; g < k; ++g)
+      if (rccl_rc[(size_t)g] != PCOA_OK) die(std::string("all-reduce over RCCL: ") + pcoa_last_error(ctx[(size_t)g]));
+    *how = "RCCL all-reduce over " + std::to_string(k) + " engines";
+  } else if (k > 1) {
+    for (int g = 1; g < k; ++g) check(ctx[0], pcoa_gram_reduce_from(ctx[0], ctx[(size_t)g]), "reduce");
+    *how = "peer reduction of " + std::to_string(k) + " engines into engine 0";
+  } else {
+    *how = "one engine";
+  }
+  check(ctx[0], pcoa_gram_finalize(ctx[0]), "getSimilarityMatrix");
+  *feed_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_feed).count();
+  for (int g = 1; g < k; ++g) pcoa_destroy(ctx[(size_t)g]);
+  return ctx[0];
 }
 
 int main(int argc, char** argv) {
@@ -524,8 +760,20 @@ int main(int argc, char** argv) {
   std::vector<Dataset> data;
   std::vector<std::string> ids, names;
   std::set<std::string> used_stems;
+  // A single PLINK fileset is STREAMED (r04): only the .fam and the .bim are read up front; the .bed goes through
+  // stream_plink_shard block by block, each engine its own contiguous range of variants.
+  const bool stream_plink = conf.input_path.size() == 1 && is_plink_path(conf.input_path[0]) && !conf.no_stream &&
+                            !conf.parse_only && !conf.has_maf;
+  PlinkMeta plink;
+  if (stream_plink) {
+    std::vector<Region> regions;
+    if (!conf.all_references && !conf.references.empty()) regions = parse_references(conf.references[0]);
+    plink = read_plink_meta(conf.input_path[0], set_id_of(conf.input_path[0], 0, used_stems), regions);
+    ids = plink.ids;
+    names = plink.names;
+  }
   if (conf.input_path.size() > 1) std::printf("Running PCA on %zu datasets.\n", conf.input_path.size());
-  for (size_t k = 0; k < conf.input_path.size(); ++k) {
+  for (size_t k = 0; k < conf.input_path.size() && !stream_plink; ++k) {
     std::vector<Region> regions;
     if (!conf.all_references && !conf.references.empty())
       regions = parse_references(conf.references[std::min(k, conf.references.size() - 1)]);
@@ -607,9 +855,7 @@ int main(int argc, char** argv) {
   }
   if (sample_idx.empty()) sample_idx.push_back(0);
 
-  // getSimilarityMatrix (:182-191) and computePca (:198-231) on the GPU
-  pcoa_ctx* ctx = nullptr;
-  if (pcoa_create(&ctx, n, conf.gpu, PCOA_FLAG_DEFAULT) != PCOA_OK) die(std::string("pcoa_create: ") + pcoa_last_error(nullptr));
+  // getSimilarityMatrix (:182-191) and computePca (:198-231) on the GPU(s)
   // The RDD[Seq[Int]] rows go over as carrier BITSETS (pcoa_accumulate_bits) when every row is a SET: 316 B per variant
   // at N = 2504 instead of 4 B per carrier, straight onto the MX-FP4 kernel.  A row can only repeat a callset when
   // mergeDatasets groups a key that occurs twice inside one VCF (the group size still equals the number of sets when
@@ -626,16 +872,28 @@ int main(int argc, char** argv) {
         last[cidx] = (int64_t)r;
       }
   }
-  if (any_repeat) {
-    check(ctx, pcoa_accumulate_calls(ctx, sample_idx.data(), row_offsets.data(), (int64_t)row_offsets.size() - 1),
-          "getSimilarityMatrix");
-  } else {
-    const int64_t n_rows = (int64_t)row_offsets.size() - 1;
+  StreamStats stream_stats;
+  std::vector<unsigned char*> blocks;  // page-locked blocks of the streaming reader, two per engine (filled by `prepare`)
+  // engine g of k takes the contiguous range shard_range(g, k, rows) -- the reference's partitions (:184)
+  std::function<void(int, int, pcoa_ctx*)> feed = [&](int g, int k, pcoa_ctx* ctx) {
+    if (stream_plink) {
+      unsigned char* const two[2] = {blocks[(size_t)(2 * g)], blocks[(size_t)(2 * g + 1)]};
+      stream_plink_shard(conf, plink, g, k, ctx, &stream_stats, two);
+      return;
+    }
+    int64_t ra, rb;
+    shard_range(g, k, (int64_t)row_offsets.size() - 1, &ra, &rb);
+    if (rb <= ra) return;
+    if (any_repeat) {
+      std::vector<int64_t> offs(row_offsets.begin() + ra, row_offsets.begin() + rb + 1);
+      check(ctx, pcoa_accumulate_calls(ctx, sample_idx.data(), offs.data(), rb - ra), "getSimilarityMatrix");
+      return;
+    }
     const int64_t words = ((int64_t)n + 31) / 32;
-    const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(n_rows, ((int64_t)64 << 20) / words));
+    const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(rb - ra, ((int64_t)64 << 20) / words));
     std::vector<uint32_t> bits((size_t)(batch * words));
-    for (int64_t r0 = 0; r0 < n_rows; r0 += batch) {
-      const int64_t rows = std::min(batch, n_rows - r0);
+    for (int64_t r0 = ra; r0 < rb; r0 += batch) {
+      const int64_t rows = std::min(batch, rb - r0);
       std::fill(bits.begin(), bits.begin() + (size_t)(rows * words), 0u);
       for (int64_t r = 0; r < rows; ++r)
         for (int64_t q = row_offsets[(size_t)(r0 + r)]; q < row_offsets[(size_t)(r0 + r + 1)]; ++q) {
@@ -644,8 +902,32 @@ int main(int argc, char** argv) {
         }
       check(ctx, pcoa_accumulate_bits(ctx, bits.data(), rows, words, 0), "getSimilarityMatrix");
     }
-  }
+  };
+  std::string how;
+  double feed_s = 0;
+  auto prepare = [&] {
+    if (!stream_plink) return;
+    for (int q = 0; q < 2 * conf.gpus; ++q) {
+      void* b = nullptr;
+      if (pcoa_host_alloc_pinned((size_t)conf.stream_rows * plink.bpv, &b) != PCOA_OK) die("pcoa_host_alloc_pinned failed");
+      blocks.push_back(static_cast<unsigned char*>(b));
+    }
+  };
+  pcoa_ctx* ctx = run_engines(conf, n, feed, &how, &feed_s, prepare);
+  for (unsigned char* b : blocks) (void)pcoa_host_free_pinned(b);
   check(ctx, pcoa_gram_finalize(ctx), "getSimilarityMatrix");
+  {
+    struct rusage ru;
+    getrusage(RUSAGE_SELF, &ru);
+    if (stream_plink)
+      std::fprintf(stderr, "Streamed %lld variants x %d samples from %s.bed in %.3f s = %.1f M variants/s (ingest -> reduced S, engines "
+                   "already created; %s; slowest shard: read not hidden %.3f s, decode + accumulate %.3f s; %s decode); peak RSS %.0f MB\n", (long long)stream_stats.variants, n,
+                   plink.prefix.c_str(), feed_s, stream_stats.variants / feed_s / 1e6, how.c_str(), stream_stats.read_s,
+                   stream_stats.feed_s, conf.plink_decode.c_str(), ru.ru_maxrss / 1024.0);
+    else
+      std::fprintf(stderr, "getSimilarityMatrix: %zu variants in %.3f s (%s); peak RSS %.0f MB\n", row_offsets.size() - 1, feed_s,
+                   how.c_str(), ru.ru_maxrss / 1024.0);
+  }
   if (!conf.dump_similarity.empty()) {  // all N^2 entries, as matrix.iterator emits them (:189)
     std::vector<int64_t> sim((size_t)n * (size_t)n);
     check(ctx, pcoa_gram_read_i64(ctx, sim.data()), "dump-similarity");
