@@ -255,7 +255,7 @@ def main():
                 "pipeline_contraction_cus": int(tim["pipeline_contraction_cus"]),
                 "what": "fp32 tiles at this N: the pre-pass of operand buffer k+1 runs beside the contraction of buffer k "
                         "(one workgroup per CU on pipeline_contraction_cus CUs, placed first; the pre-pass cannot share a CU "
-                        "with it and takes the rest) -- DESIGN.md 4.1; PCOA_PIPELINE=0 disables it"}
+                        "with it and takes the rest) -- DESIGN_HISTORY.md 4.1; PCOA_PIPELINE=0 disables it"}
         # k-bits operand: the two kernels SHARE the CUs (persistent ring pre-pass, 40 VGPRs, beside a contraction held to 224)
         cores = bool(tim["pipeline_pre_pass_cus"] + tim["pipeline_contraction_cus"] > cus and tim["pipeline_launches"] > 0)
         info["co_resident"] = cores
@@ -263,7 +263,7 @@ def main():
             info["what"] = ("fp32 tiles at this N, k-bits operand: the pre-pass of operand buffer k+1 (pack_kbits_ring_kernel: "
                             "persistent, LDS-DMA ring, two workgroups of 4 waves per CU, 40 VGPRs) runs on the SAME CUs as the "
                             "contraction of buffer k (gram_kbits_kernel held to 224 VGPRs per wave, one workgroup on each of "
-                            "pipeline_contraction_cus CUs, placed first) -- DESIGN.md 4.1, profiles/r03s..u_coreside.txt; "
+                            "pipeline_contraction_cus CUs, placed first) -- DESIGN_HISTORY.md 4.1, profiles/r03s..u_coreside.txt; "
                             "PCOA_KBITS_CORESIDE=0 gives the disjoint-CU form back, PCOA_PIPELINE=0 the serial order")
         kern_s = tim["gram_kernel_seconds"] / launches           # average Gram-kernel launch duration (HIP events)
         vpl = tim["gram_variants"] / launches                    # variants per contraction launch

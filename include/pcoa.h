@@ -99,7 +99,7 @@ typedef struct pcoa_timings {
   int64_t fp4_fallbacks;        /* chunks the auto mode re-ran on the int8 kernel (non-binary values) */
   int64_t lockstep_launches;    /* contraction launches in the lock-step form (all tiles of a k-stream resident)  */
   int64_t pipeline_launches;    /* of those: launched on the contraction stream beside the next buffer's pre-pass
-                                   (fp32 pipeline)                                                  */
+                                   (fp32 pipeline, DESIGN_HISTORY.md 4.1)                                                  */
   int32_t pipeline_pre_pass_cus;    /* CUs the pre-pass runs on while such a contraction does (0 = pipeline unavailable).  k-bits
                                        operand: all of them -- the ring pre-pass SHARES every CU with the contraction --, so
                                        pipeline_pre_pass_cus + pipeline_contraction_cus > the CU count means "co-resident" */
@@ -374,6 +374,10 @@ int pcoa_reset_timings(pcoa_ctx* ctx);
  * of touching a neighbouring allocation.  The GPU test suite runs its fuzz and parity sweeps in that mode with the
  * input tiles allocated here (tests/test_gpu_guard.py).  pcoa_debug_guard_mode returns the mode in effect (0 = off). */
 int pcoa_debug_alloc(int32_t device_ordinal, size_t bytes, void** out);
+/* One y = B x of the centred matrix of the current S (host vectors of N doubles) with either form of the eigensolver's mat-vec:
+ * 0 = one wave per row over all N^2 entries, 1 = upper-triangular 1024 x 1024 tiles, each entry read once and used for y_i and
+ * y_j (the form pcoa_compute takes from N = 16,384; needs N % 4 == 0). */
+int pcoa_debug_centred_matvec(pcoa_ctx* ctx, const double* x, double* y, int upper_triangle_form);
 int pcoa_debug_free(void* p);
 int pcoa_debug_guard_mode(void);
 

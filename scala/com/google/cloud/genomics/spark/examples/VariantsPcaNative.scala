@@ -38,9 +38,12 @@ object VariantsPcaNative {
   def getSimilarityMatrix(sc: SparkContext, callsets: RDD[Seq[Int]], size: Int, nGpus: Int): Array[Long] = {
     val uid = sc.broadcast(NativePcoa.commUniqueId()) // rank 0's RCCL id, shipped by Spark
     require(uid.value != null, "pcoa_comm_unique_id failed")
-    require(nGpus == 1 || sc.defaultParallelism >= nGpus,
-      s"$nGpus GPU tasks meet in one RCCL collective but only ${sc.defaultParallelism} task slots exist: they would wait for each other forever")
-    callsets.repartition(nGpus).mapPartitionsWithIndex { (rank, callsInPartition) =>
+    val slots = concurrentTaskSlots(sc)
+    require(nGpus == 1 || slots >= nGpus,
+      s"$nGpus GPU tasks meet in one RCCL collective but only $slots tasks can run at the same time: they would wait for each other forever")
+    // exactly one partition per GPU: coalesce (no shuffle) when there are enough partitions, a shuffle only when there are too few
+    val perGpu = if (callsets.getNumPartitions >= nGpus) callsets.coalesce(nGpus) else callsets.repartition(nGpus)
+    perGpu.mapPartitionsWithIndex { (rank, callsInPartition) =>
       val ctx = NativePcoa.create(size, rank, NativePcoa.FlagDefault)
       try {
       callsInPartition.grouped(BatchRecords).foreach { batch =>
@@ -71,6 +74,26 @@ object VariantsPcaNative {
       }
       Iterator((rank, ctx))
     }.collect().sortBy(_._1).map(_._2)
+  }
+
+  /**
+   * Tasks that can run AT THE SAME TIME: cores of the executors registered now (local[k]: k) over spark.task.cpus.
+   * sc.defaultParallelism is not that number: spark.default.parallelism overrides it, and on a cluster it counts cores that
+   * may belong to executors still starting (ADVICE r03).  (On Spark >= 2.4 a barrier stage -- callsets.barrier().mapPartitions
+   * -- gives the gang scheduling this collective needs without the check; the reference builds against 1.6.1.)
+   */
+  def concurrentTaskSlots(sc: SparkContext): Int = {
+    val cpusPerTask = math.max(1, sc.getConf.getInt("spark.task.cpus", 1))
+    val localK = "local\\[(\\d+)(?:,\\s*\\d+)?\\]".r
+    val cores = sc.master match {
+      case "local" => 1
+      case m if m.startsWith("local[*") => Runtime.getRuntime.availableProcessors
+      case localK(k) => k.toInt
+      case _ =>
+        val executors = math.max(1, sc.getExecutorMemoryStatus.size - 1) // the driver's block manager is one entry
+        executors * math.max(1, sc.getConf.getInt("spark.executor.cores", 1))
+    }
+    cores / cpusPerTask
   }
 
   /**

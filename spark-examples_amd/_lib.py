@@ -105,6 +105,7 @@ _SIGNATURES = [
     ("pcoa_debug_guard_mode", ctypes.c_int, []),
     ("pcoa_accumulate_calls", ctypes.c_int, [_vp, _vp, _vp, _i64]),
     ("pcoa_gram_reduce_from", ctypes.c_int, [_vp, _vp]),
+    ("pcoa_debug_centred_matvec", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int]),
     ("pcoa_host_alloc_pinned", ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]),
     ("pcoa_host_free_pinned", ctypes.c_int, [_vp]),
     ("pcoa_accumulate_plink_bed", ctypes.c_int, [_vp, _vp, _i64, _i64, ctypes.c_int, ctypes.c_int]),

@@ -22,7 +22,7 @@
 // K4 deviates from the "implicit QR" wording of BASELINE.json on purpose: implicit QL/QR is a
 // serial chain of O(N^2) dependent rotations (one lane busy), whereas Sturm counts for 256 shifts
 // at once fill a workgroup and only the k wanted eigenvalues are ever computed.  Same eigenvalues
-// to machine precision; see DESIGN.md.
+// to machine precision; see DESIGN_HISTORY.md 4.4.
 //
 // Bounds: K3 is HBM/L2-bandwidth- and launch-latency-bound (BLAS-2), K4/K5 are latency-bound;
 // the eigensolver is reported as wall-clock, not against a roofline.

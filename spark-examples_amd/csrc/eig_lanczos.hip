@@ -181,6 +181,134 @@ __global__ __launch_bounds__(256) void symv_centered_kernel(const int32_t* __res
   if (lane == 0) y[i] = acc;
 }
 
+// ---- large N: y = B x reading only the UPPER TRIANGLE of S (r04) ----------------------------------------
+// symv_centered_kernel reads all N^2 entries per mat-vec -- 40 GB at N = 100,000, 250 GB at N = 250,000 -- and with one wave
+// per row streams them at ~3 TB/s.  S is symmetric: an entry S(i, j), j > i, serves y_i += B(i,j) x_j AND y_j += B(j,i) x_i.
+// One workgroup per upper-triangular tile of 1024 x 1024 entries (4 MiB of S): wave w walks the rows w, w + 4, ..; a lane owns
+// 16 columns (four 16-byte loads per row, the next row's loads in flight while this row is used), accumulates its share of
+// the row's dot product (wave-reduced at the end of the row) and, per column, the transposed products.  Both B(i,j) and
+// B(j,i) are evaluated from the integer S in the reference's operation order -- ((S - rowMean) - colMean) + mean, no fused
+// multiply-add in the centring (VariantsPca.scala:216-221) -- so the entries are the ones symv_centered_kernel and the
+// materialised B hold, bit for bit; only the ORDER of the additions differs (results agree to ~1e-15 relative, tested to
+// 1e-13).  No floating-point atomics: a tile writes its 1024 row sums and 1024 column sums into its own slots of `part`,
+// and symv_sym_gather_kernel adds, for every y_i, the slots of its block row and block column in a fixed order.
+constexpr int SYT = 1024;
+
+__device__ __forceinline__ int64_t sym_tile_index(int bi, int bj, int nb) {  // bi <= bj
+  return (int64_t)bi * nb - (int64_t)bi * (bi - 1) / 2 + (bj - bi);
+}
+
+template <bool DIAG>
+__global__ __launch_bounds__(256) void symv_sym_tiles_kernel(const int32_t* __restrict__ s32, int n, int nb,
+                                                             const double* __restrict__ cm, const double* __restrict__ stats,
+                                                             const double* __restrict__ x, double* __restrict__ part) {
+  __shared__ double colred[4][SYT];  // 32 KiB
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // DIAG: blockIdx.x = diagonal tile; else: blockIdx.x enumerates the strictly upper tiles row by row
+  int bi, bj;
+  if (DIAG) {
+    bi = bj = blockIdx.x;
+  } else {
+    int t = blockIdx.x;
+    bi = 0;
+    while (t >= nb - 1 - bi) {
+      t -= nb - 1 - bi;
+      ++bi;
+    }
+    bj = bi + 1 + t;
+  }
+  const int i0 = bi * SYT, j0 = bj * SYT;
+  const double mmean = stats[1];
+  // the lane's 16 columns: j0 + 256 q + 4 lane + {0..3}
+  double xj[16], mj[16], cacc[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = j0 + 256 * q + 4 * lane + e;
+      xj[4 * q + e] = j < n ? x[j] : 0.0;
+      mj[4 * q + e] = j < n ? cm[j] : 0.0;
+      cacc[4 * q + e] = 0.0;
+    }
+  const int rows = min(SYT, n - i0);
+  double* prow = part + sym_tile_index(bi, bj, nb) * (2 * SYT);
+  auto load_row = [&](int r, int4 (&v)[4]) {
+    const int32_t* rowp = s32 + (int64_t)(i0 + r) * n + j0 + 4 * lane;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = j0 + 256 * q + 4 * lane;
+      v[q] = (j < n) ? *reinterpret_cast<const int4*>(rowp + 256 * q) : make_int4(0, 0, 0, 0);   // n % 4 == 0: whole or none
+    }
+  };
+  int4 cur[4], nxt[4];
+  if (wave < rows) load_row(wave, cur);
+  for (int r = wave; r < rows; r += 4) {
+    if (r + 4 < rows) load_row(r + 4, nxt);
+    const int i = i0 + r;
+    const double xi = x[i], mi = cm[i];
+    double racc = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int sv[4] = {cur[q].x, cur[q].y, cur[q].z, cur[q].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int j = j0 + 256 * q + 4 * lane + e;
+        const double d = (double)sv[e];
+        double bij, bji;
+        {
+#pragma clang fp contract(off)
+          bij = d - mi;
+          bij = bij - mj[4 * q + e];
+          bij = bij + mmean;
+          bji = d - mj[4 * q + e];
+          bji = bji - mi;
+          bji = bji + mmean;
+        }
+        if (DIAG) {  // the tile's own upper triangle: the diagonal counts once (in the row sums)
+          if (j >= i && j < n) racc += bij * xj[4 * q + e];
+          if (j > i && j < n) cacc[4 * q + e] += bji * xi;
+        } else {
+          // (columns >= n of the last block column: x and S were read as 0 but the centred entry is not 0 -> mask)
+          if (j < n) {
+            racc += bij * xj[4 * q + e];
+            cacc[4 * q + e] += bji * xi;
+          }
+        }
+      }
+    }
+    racc = wave_sum(racc);
+    if (lane == 0) prow[r] = racc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+  }
+  for (int r = rows + (int)threadIdx.x; r < SYT; r += 256) prow[r] = 0.0;   // rows beyond N in the last block row
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) colred[wave][256 * q + 4 * lane + e] = cacc[4 * q + e];
+  __syncthreads();
+  for (int cidx = threadIdx.x; cidx < SYT; cidx += 256)
+    prow[SYT + cidx] = ((colred[0][cidx] + colred[1][cidx]) + colred[2][cidx]) + colred[3][cidx];
+}
+
+// y_i = sum over the tiles of block row bi (their row sums, left to right) + over the tiles of block column bi above the
+// diagonal (their column sums, top to bottom): a fixed order
+__global__ __launch_bounds__(256) void symv_sym_gather_kernel(const double* __restrict__ part, int n, int nb, double* __restrict__ y) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int bi = i / SYT, r = i - bi * SYT;
+  double acc = 0.0;
+  for (int bj = bi; bj < nb; ++bj) acc += part[sym_tile_index(bi, bj, nb) * (2 * SYT) + r];
+  for (int bk = 0; bk <= bi; ++bk) acc += part[sym_tile_index(bk, bi, nb) * (2 * SYT) + SYT + r];  // (the diagonal tile's too)
+  y[i] = acc;
+}
+
+// doubles of workspace the symmetric form needs (0: not used at this N)
+size_t symv_sym_workspace_doubles_impl(int n) {
+  const int64_t nb = (n + SYT - 1) / SYT;
+  return (size_t)(nb * (nb + 1) / 2) * (size_t)(2 * SYT);
+}
+
 void launch_symv(const EigWorkspace& ws, int n, const double* x, double* y, hipStream_t stream) {
   const unsigned rows4 = (unsigned)((n + 3) / 4);
   if (ws.a) {
@@ -188,6 +316,14 @@ void launch_symv(const EigWorkspace& ws, int n, const double* x, double* y, hipS
   } else if (ws.s64) {
     hipLaunchKernelGGL(symv_centered_kernel<true>, dim3(rows4), dim3(256), 0, stream, ws.s32, ws.s64, n, ws.colmean,
                        ws.stats, x, y);
+  } else if (ws.sym_part && (n & 3) == 0) {
+    const int nb = (n + SYT - 1) / SYT;
+    if (nb > 1)
+      hipLaunchKernelGGL(symv_sym_tiles_kernel<false>, dim3((unsigned)((int64_t)nb * (nb - 1) / 2)), dim3(256), 0, stream, ws.s32, n,
+                         nb, ws.colmean, ws.stats, x, ws.sym_part);
+    hipLaunchKernelGGL(symv_sym_tiles_kernel<true>, dim3((unsigned)nb), dim3(256), 0, stream, ws.s32, n, nb, ws.colmean, ws.stats, x,
+                       ws.sym_part);
+    hipLaunchKernelGGL(symv_sym_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ws.sym_part, n, nb, y);
   } else {
     hipLaunchKernelGGL(symv_centered_kernel<false>, dim3(rows4), dim3(256), 0, stream, ws.s32, ws.s64, n, ws.colmean,
                        ws.stats, x, y);
@@ -343,6 +479,9 @@ __global__ __launch_bounds__(1024) void residual_kernel(const double* __restrict
 }
 
 }  // namespace
+
+size_t symv_sym_workspace_doubles(int32_t n) { return symv_sym_workspace_doubles_impl(n); }
+void launch_centred_matvec(const EigWorkspace& ws, int32_t n, const double* x, double* y, hipStream_t stream) { launch_symv(ws, n, x, y, stream); }
 
 size_t lanczos_workspace_doubles(int32_t n, int32_t k, int32_t mmax) {
   // V[(mmax+1)][n], w[n], bu[k][n], alpha[mmax], beta[mmax], h1[mmax+1], h2[mmax+1], the check record

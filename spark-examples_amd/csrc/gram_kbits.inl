@@ -2,7 +2,7 @@
 // in registers, on the way into the matrix cores.  Included twice by gram_packed.hip (kernels inside its anonymous
 // namespace, launchers inside namespace pcoa); not a translation unit of its own.
 //
-// Why: the FP4 operand costs 1.28 GB written by the pre-pass and 4.3 GB re-read by
+// Why (DESIGN_HISTORY.md 4.1): the FP4 operand costs 1.28 GB written by the pre-pass and 4.3 GB re-read by
 // the contraction per 10^6 variants at N = 2504, and that L2-hit stream is what slows the fp32 pre-pass beside it.  A
 // genotype indicator is one bit; as bits the operand is 0.33 GB written and ~1.1 GB re-read.
 //
@@ -798,7 +798,7 @@ __device__ __forceinline__ void ppb_loop(StageBits* lds, const int8_t* __restric
 // The body is a device function wrapped by the kernel below it, which is held to 224 VGPRs per wave (the compiler takes all
 // 256 a 2-waves-per-SIMD kernel may have when left alone, and needs 196): two contraction waves then leave a SIMD 64 of its
 // 512 registers -- room for the waves of the persistent ring pre-pass (pack_kbits_ring_kernel), which shares the CU with
-// this kernel in the fp32 pipeline (profiles/r03s .. r03u_coreside.txt).
+// this kernel in the fp32 pipeline (DESIGN_HISTORY.md 4.1, profiles/r03s .. r03u_coreside.txt).
 #define PCOA_KBITS_CONTRACTION __device__ __forceinline__ void gram_kbits_body
 template <int NST, int LEFT, int ENC>
 PCOA_KBITS_CONTRACTION(const int8_t* __restrict__ p, int npad, int64_t nstages, int n,
@@ -1020,6 +1020,7 @@ hipError_t launch_pack_kbits_ring(const float* x, int64_t ld, int64_t nv, int32_
 #undef PCOA_RINGK2
 #else
   if ((ring / 100) % 10) PCOA_RINGK(8, 2, 0);
+  else if (ring / 1000) PCOA_RINGK(8, 0, 3);
   else PCOA_RINGK(8, 0, 0);
 #endif
 #undef PCOA_RINGK

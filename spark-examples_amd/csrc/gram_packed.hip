@@ -29,7 +29,7 @@
 //   PCOA_GRAM_I8_CFG=43 selects the in-phase ring, 143 the
 //   ping-pong schedule without the two MFMAs issued behind the phase barrier.
 //
-// Measured at N = 2504 per 10^6 variants: FP4 1.13-1.16 ms (6 PFLOP/s issued), int8 2.14 ms; DESIGN.md 4.1 / 4.2.
+// Measured at N = 2504 per 10^6 variants: FP4 1.13-1.16 ms (6 PFLOP/s issued), int8 2.14 ms; DESIGN_HISTORY.md 4.1 / 4.2.
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -1340,7 +1340,7 @@ hipError_t launch_gram_i8_packed(const int8_t* p, int64_t nv, int32_t n, int32_t
 }
 
 // Lock-step launch of the FP4 / int8 contraction (gram_packed_kernel with xcd_map = 2): ntri * splitk <= #CUs
-// persistent workgroups, splitk in {1, 2, 4, 8} k-streams, each on 8 / splitk XCDs.
+// persistent workgroups, splitk in {1, 2, 4, 8} k-streams, each on 8 / splitk XCDs (DESIGN_HISTORY.md 4.1).
 int gram_lockstep_splitk(int32_t n, int cus) {
   const int ntile = (int)(gram_packed_npad(n) / TJ);
   const int64_t ntri = (int64_t)ntile * (ntile + 1) / 2;
@@ -1394,7 +1394,7 @@ hipError_t launch_gram_packed(const int8_t* p, int fmt, int64_t nv, int32_t n, i
                               hipStream_t stream, int* splitk_out, const int32_t* skip, GramStrip strip) {
   if (nv <= 0) return hipSuccess;
   // Shipped schedule: ping-pong, 4 k-blocks per stage, 3-stage ring, two MFMAs behind the phase barrier ("243").  The
-  // other schedules of DESIGN.md 4.1 / 4.2 (PCOA_GRAM_I8_CFG = 43 | 44 | 143 | 144 | 443) only exist in a library built
+  // other schedules of DESIGN_HISTORY.md 4.1 / 4.2 (PCOA_GRAM_I8_CFG = 43 | 44 | 143 | 144 | 443) only exist in a library built
   // with -DPCOA_EXPERIMENTS.
   int cfg = 243;
 #ifdef PCOA_EXPERIMENTS

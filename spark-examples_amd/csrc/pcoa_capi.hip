@@ -145,8 +145,13 @@ struct RcclApi {
   ncclResult_t (*GetVersion)(int*) = nullptr;
 };
 
+// the collective runtime itself, not a plugin of it: the BASENAME starts with "librccl.so" (librccl-net.so and friends carry
+// "librccl" in their names too)
 int find_mapped_rccl(struct dl_phdr_info* info, size_t, void* data) {
-  if (info->dlpi_name && std::strstr(info->dlpi_name, "librccl")) {
+  if (!info->dlpi_name) return 0;
+  const char* base = std::strrchr(info->dlpi_name, '/');
+  base = base ? base + 1 : info->dlpi_name;
+  if (std::strncmp(base, "librccl.so", 10) == 0) {
     *static_cast<std::string*>(data) = info->dlpi_name;
     return 1;
   }
@@ -159,36 +164,49 @@ const RcclApi& rccl_api() {
   std::call_once(once, [] {
     std::string mapped;
     dl_iterate_phdr(find_mapped_rccl, &mapped);
-    if (!mapped.empty()) api.handle = dlopen(mapped.c_str(), RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
-    for (const char* name : {"librccl.so.1", "librccl.so"})
-      if (!api.handle) api.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-    if (!api.handle) {
-      const char* why = dlerror();
-      api.error = std::string("RCCL not found (no librccl mapped in this process, dlopen(librccl.so.1) failed: ") +
-                  (why ? why : "?") + ")";
-      return;
-    }
-    bool ok = true;
-    auto bind = [&](auto& fn, const char* sym) {
-      fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(api.handle, sym));
-      if (!fn) {
-        ok = false;
-        api.error = std::string("RCCL symbol missing: ") + sym;
+    // candidates in order: the image already mapped in this process, then the RUNPATH's; a candidate whose symbols do not
+    // bind is dropped and the next one tried
+    std::vector<std::pair<std::string, int>> cands;
+    if (!mapped.empty()) cands.push_back({mapped, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD});
+    cands.push_back({"librccl.so.1", RTLD_NOW | RTLD_GLOBAL});
+    cands.push_back({"librccl.so", RTLD_NOW | RTLD_GLOBAL});
+    std::string errors;
+    for (const auto& cand : cands) {
+      void* h = dlopen(cand.first.c_str(), cand.second);
+      if (!h) {
+        const char* why = dlerror();
+        errors += " [" + cand.first + ": " + (why ? why : "not loaded") + "]";
+        continue;
       }
-    };
-    bind(api.GetUniqueId, "ncclGetUniqueId");
-    bind(api.CommInitRank, "ncclCommInitRank");
-    bind(api.CommDestroy, "ncclCommDestroy");
-    bind(api.AllReduce, "ncclAllReduce");
-    bind(api.GetErrorString, "ncclGetErrorString");
-    bind(api.GetVersion, "ncclGetVersion");
-    if (!ok) {
-      api.handle = nullptr;
+      RcclApi t;
+      t.handle = h;
+      bool ok = true;
+      std::string missing;
+      auto bind = [&](auto& fn, const char* sym) {
+        fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(h, sym));
+        if (!fn) {
+          ok = false;
+          missing = sym;
+        }
+      };
+      bind(t.GetUniqueId, "ncclGetUniqueId");
+      bind(t.CommInitRank, "ncclCommInitRank");
+      bind(t.CommDestroy, "ncclCommDestroy");
+      bind(t.AllReduce, "ncclAllReduce");
+      bind(t.GetErrorString, "ncclGetErrorString");
+      bind(t.GetVersion, "ncclGetVersion");
+      if (!ok) {
+        errors += " [" + cand.first + ": symbol missing: " + missing + "]";
+        continue;
+      }
+      api = t;
+      Dl_info di;
+      if (dladdr(reinterpret_cast<void*>(api.AllReduce), &di) && di.dli_fname) api.path = di.dli_fname;
+      else api.path = cand.first;
       return;
     }
-    Dl_info di;
-    if (dladdr(reinterpret_cast<void*>(api.AllReduce), &di) && di.dli_fname) api.path = di.dli_fname;
-    else api.path = mapped;
+    api.handle = nullptr;
+    api.error = "RCCL not found:" + errors;
   });
   return api;
 }
@@ -277,7 +295,7 @@ struct pcoa_ctx {
   // holds); a buffer is contracted when it is full or when S is needed (finalize / read / all-reduce / compute), so one
   // launch carries up to the buffer's capacity whatever the size of the calls.  Two buffers exist where the fp32
   // pipeline applies (fb_count == 2): the pre-pass of the next buffer then runs beside the contraction of the last one
-  // on disjoint CU sets.  Auto mode: the pre-passes of a buffer generation raise the buffer's device
+  // on disjoint CU sets (DESIGN_HISTORY.md 4.1).  Auto mode: the pre-passes of a buffer generation raise the buffer's device
   // flag on a value other than 0 / 1, the contraction reads the same word and does nothing if it is set, and the host
   // learns it when it next needs the buffer (fp4_resolve) and redoes the generation's chunks on the int8 kernel -- no
   // host synchronisation per call.
@@ -322,6 +340,8 @@ struct pcoa_ctx {
   double* out_dev = nullptr;       // [kmax][n]
   int32_t kmax = 0;
   double* lanczos_ws = nullptr;    // Krylov basis + scalars of the Lanczos fast path (lazy)
+  double* sym_part = nullptr;      // tile sums of the symmetric mat-vec (large N, lazy)
+  int64_t sym_part_cap = 0;
   int64_t lanczos_cap = 0;         // doubles
   int32_t eig_method = 0;          // of the last pcoa_compute: 1 = Lanczos, 2 = Householder
   int32_t lanczos_steps = 0;
@@ -521,7 +541,8 @@ hipError_t launch_pack_operand(const pcoa_ctx* c, const void* x, int is_u8, int6
                                hipStream_t s, int64_t kb, int ring_wgs = 0) {
   // ring_wgs > 0: the persistent ring pre-pass of the co-resident fp32 pipeline (fp32 tile, k-bits operand, ring_ok checked)
   if (ring_wgs > 0 && c->op_fmt == 2 && !is_u8)
-    return launch_pack_kbits_ring(static_cast<const float*>(x), ld, nv, c->n, dst, flag, s, kb / 4, ring_wgs, 8);
+    return launch_pack_kbits_ring(static_cast<const float*>(x), ld, nv, c->n, dst, flag, s, kb / 4, ring_wgs,
+                                  8 + 1000 * std::max(0, debug_knobs().kbits_ring_prio));
   if (ring_wgs > 0 && c->op_fmt == 2 && is_u8)
     return launch_pack_kbits_ring_u8(static_cast<const uint8_t*>(x), ld, nv, c->n, dst, flag, s, kb / 4, ring_wgs, 8);
   return c->op_fmt == 2 ? launch_pack_kbits(x, is_u8, ld, nv, c->n, dst, flag, s, kb / 4)
@@ -630,6 +651,12 @@ int fp4_setup(pcoa_ctx* c) {
         c->coreside_mode = (ls > 0 && gram_lockstep_workgroups(c->n, ls) * 5 >= c->num_cu * 4 && k.kbits_mode != 4) ? 2 : c->kbits_mode;
         if (k.kbits_mode == 2 && ls > 0) c->coreside_mode = 2;
         c->pipe_gram_cus = c->num_cu;
+        // (harness knob: the co-resident contraction as an even split over fewer workgroups -- the CUs it leaves run
+        // pre-pass waves only)
+        if (k.kbits_pipe_wgs >= 8 && k.kbits_pipe_wgs <= c->num_cu) {
+          c->pipe_gram_cus = k.kbits_pipe_wgs / 8 * 8;
+          c->coreside_mode = 4;
+        }
         c->ring_wgs = (k.kbits_ring_wgs > 0) ? k.kbits_ring_wgs : 2 * c->num_cu;
       }
     } else {
@@ -1205,9 +1232,11 @@ const DebugKnobs& debug_knobs() {
     if (const char* v = std::getenv("PCOA_KBITS_MODE")) k.kbits_mode = std::atoi(v);
     if (const char* v = std::getenv("PCOA_KBITS_W4")) k.kbits_w4 = std::atoi(v);
     if (const char* v = std::getenv("PCOA_CSR_LEGACY")) k.csr_legacy = std::atoi(v) != 0;
+    if (const char* v = std::getenv("PCOA_SYMV_SYM_MIN_N")) k.symv_sym_min_n = std::atoi(v);
     k.kbits_pipe_wgs = (int)num("PCOA_KBITS_PIPE_WGS");
     if (const char* v = std::getenv("PCOA_KBITS_CORESIDE")) k.kbits_coreside = std::atoi(v) != 0;
     k.kbits_ring_wgs = (int)num("PCOA_KBITS_RING_WGS");
+    k.kbits_ring_prio = (int)num("PCOA_KBITS_RING_PRIO");
     k.kbits_coreside_max_npad = (int)num("PCOA_KBITS_CORESIDE_MAX_NPAD");
     k.gram_cfg = (int)num("PCOA_GRAM_I8_CFG");
     k.gram_splitk = (int)num("PCOA_GRAM_I8_SPLITK");
@@ -1338,7 +1367,7 @@ void pcoa_destroy(pcoa_ctx* c) {
   if (c->hw) (void)hipHostFree(c->hw);
   if (c->ws.host_rec) (void)hipHostFree(c->ws.host_rec);
   void* bufs[] = {c->s32, c->s64, c->zeros, c->err_flag, c->tile, c->csr_idx, c->csr_offs, c->thr_dev, c->bed_raw,
-                  c->sample_pop, c->xfer, c->coll, c->fb_flags, c->strip_ws, c->strip_means, c->pack_buf, c->lanczos_ws, c->ws.a, c->ws.d, c->ws.e, c->ws.tau, c->ws.q, c->ws.w, c->ws.lam,
+                  c->sample_pop, c->xfer, c->coll, c->fb_flags, c->strip_ws, c->strip_means, c->pack_buf, c->lanczos_ws, c->sym_part, c->ws.a, c->ws.d, c->ws.e, c->ws.tau, c->ws.q, c->ws.w, c->ws.lam,
                   c->ws.z, c->ws.wy, c->ws.scratch, c->ws.iscratch, c->row_sums, c->colmean, c->stats, c->nz,
                   c->out_dev};
   for (void* b : bufs)
@@ -1991,6 +2020,41 @@ int pcoa_gram_export_device_i64(pcoa_ctx* c, int64_t* dst_dev) {
 
 // Page-locked host memory for a host's input blocks (the compiled host streams .bed blocks through two of them: a copy from
 // pageable memory crosses the link at ~14 GB/s, from pinned memory at ~50).  Not tied to a ctx.
+// Test hook: one y = B x of the centred matrix of the CURRENT S with either form of the mat-vec (0 = one wave per row over all
+// N^2 entries, 1 = upper-triangular tiles); x, y host arrays of N doubles.  N % 4 == 0 and no int64 part for form 1.
+int pcoa_debug_centred_matvec(pcoa_ctx* c, const double* x, double* y, int upper_triangle_form) {
+  CHECK_CTX(c);
+  if (!x || !y) return fail(c, PCOA_ERR_INVALID_ARG, "x or y is NULL");
+  if (c->is_strip) return fail(c, PCOA_ERR_STATE, "not available on a strip owner");
+  int rc = finalize_impl(c);
+  if (rc != PCOA_OK) return rc;
+  if ((rc = check_device_flags(c)) != PCOA_OK) return rc;
+  if ((rc = ensure_workspace(c, 1)) != PCOA_OK) return rc;
+  const int32_t n = c->n;
+  HIP_TRY(c, launch_center(c->s32, c->s64, n, c->row_sums, c->stats, c->nz, nullptr, c->stream));
+  HIP_TRY(c, launch_col_means(c->row_sums, n, c->colmean, c->stream));
+  EigWorkspace wl = c->ws;
+  wl.a = nullptr;
+  wl.s32 = c->s32;
+  wl.s64 = c->s64;
+  wl.colmean = c->colmean;
+  wl.stats = c->stats;
+  wl.sym_part = nullptr;
+  if (upper_triangle_form) {
+    if (c->s64 || (n & 3)) return fail(c, PCOA_ERR_STATE, "the upper-triangle form needs N % 4 == 0 and no int64 part");
+    if ((rc = ensure(c, &c->sym_part, &c->sym_part_cap, (int64_t)symv_sym_workspace_doubles(n))) != PCOA_OK) return rc;
+    wl.sym_part = c->sym_part;
+  }
+  double* xd = c->ws.q;   // two N-vectors of the eigensolver workspace
+  double* yd = c->ws.w;
+  HIP_TRY(c, hipMemcpyAsync(xd, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  launch_centred_matvec(wl, n, xd, yd, c->stream);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(y, yd, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return PCOA_OK;
+}
+
 int pcoa_host_alloc_pinned(size_t bytes, void** out) {
   if (!out || bytes == 0) return PCOA_ERR_INVALID_ARG;
   *out = nullptr;
@@ -2287,6 +2351,13 @@ int pcoa_compute(pcoa_ctx* c, int32_t num_pc, double* out_components, double* ou
       ScopedTimer t(c, T_LANCZOS);
       EigWorkspace wl = c->ws;
       if (!b_ready) wl.a = nullptr;  // implicit form
+      // large N: the mat-vec reads only the upper triangle of S (half the bytes; symv_sym_tiles_kernel)
+      const int sym_min = debug_knobs().symv_sym_min_n > 0 ? debug_knobs().symv_sym_min_n : 16384;
+      wl.sym_part = nullptr;
+      if (!wl.a && !wl.s64 && n >= sym_min && (n & 3) == 0) {
+        if ((rc = ensure(c, &c->sym_part, &c->sym_part_cap, (int64_t)symv_sym_workspace_doubles(n))) != PCOA_OK) return rc;
+        wl.sym_part = c->sym_part;
+      }
       HIP_TRY(c, lanczos_topk(wl, c->lanczos_ws, n, num_pc, mmax, 1e-11, sel.data(), &conv, &steps, c->stream));
     }
     c->lanczos_steps = steps;

@@ -18,7 +18,7 @@ constexpr int kNumXcd = 8;    // MI355X: block b is dispatched to XCD b % 8 (spe
 
 // ---- debug / experiment knobs -------------------------------------------------------------------
 // Every environment variable the library looks at, read ONCE (first use) into this struct; nothing else calls getenv.
-// None is needed for normal use; DESIGN.md "Environment hooks" documents them.
+// None is needed for normal use; DESIGN_HISTORY.md "Environment hooks" documents them.
 struct DebugKnobs {
   int gram_kernel = -1;            // PCOA_GRAM_KERNEL = auto | fp4 | i8 | f32  -> 0 | 3 | 2 | 1 (overrides the create flags)
   int64_t pack_chunk = 0;          // PCOA_DEBUG_PACK_CHUNK: variants per pre-pass launch (tests: multi-chunk paths)
@@ -35,9 +35,11 @@ struct DebugKnobs {
   int operand = 0;                 // PCOA_OPERAND = fp4 | bits -> 1 | 2: operand of the binary-tile contraction (0 = default)
   int kbits_mode = -1;             // PCOA_KBITS_MODE = 0 | 2 | 4: launch form of the k-bits contraction (whole chip)
   int kbits_pipe_wgs = 0;          // PCOA_KBITS_PIPE_WGS: workgroups of the k-bits contraction beside the fp32 pre-pass
+  int symv_sym_min_n = 0;          // PCOA_SYMV_SYM_MIN_N: smallest N whose Lanczos mat-vec reads only the upper triangle of S (default 16384)
   int csr_legacy = 0;              // PCOA_CSR_LEGACY = 1: pcoa_accumulate_calls through the host-validated r03 path
   int kbits_w4 = -1;               // PCOA_KBITS_W4 = 0 | 1 | 2: one-wave-per-SIMD contraction (gram_kbits_w4.inl): 0 never, 1 wherever the kernel has its CUs to itself (default), 2 also beside the ring pre-pass
   int kbits_coreside = -1;         // PCOA_KBITS_CORESIDE = 0 | 1: fp32 pipeline with pre-pass and contraction on the SAME CUs (ring pre-pass)
+  int kbits_ring_prio = 0;         // PCOA_KBITS_RING_PRIO = 1: the ring pre-pass's waves at s_setprio 3 (harness knob)
   int kbits_ring_wgs = 0;          // PCOA_KBITS_RING_WGS: workgroups of the ring pre-pass beside a contraction (default 2 per CU)
   int kbits_coreside_max_npad = 0; // PCOA_KBITS_CORESIDE_MAX_NPAD: largest padded sample count the co-resident pipeline is used for
 };
@@ -181,7 +183,12 @@ struct EigWorkspace {
   const int64_t* s64;     // [n][n] or nullptr
   const double* colmean;  // [n] rowSums(j) / N
   const double* stats;    // stats[1] = matrixMean
+  // large N: workspace of the symmetric mat-vec that reads only the upper triangle of S (symv_sym_workspace_doubles(n)
+  // doubles: 1024 row sums + 1024 column sums per upper-triangular 1024 x 1024 tile), or nullptr: one wave per row
+  double* sym_part = nullptr;
 };
+size_t symv_sym_workspace_doubles(int32_t n);
+void launch_centred_matvec(const EigWorkspace& ws, int32_t n, const double* x, double* y, hipStream_t stream);  // one y = B x (test hook)
 hipError_t launch_tridiagonalize(const EigWorkspace& ws, int32_t n, hipStream_t stream);
 // eigenvalues with ascending indices idx[0..count) of T -> lam_out[0..count) (device)
 hipError_t launch_bisect(const EigWorkspace& ws, int32_t n, const int32_t* idx_host, int32_t count,

@@ -289,6 +289,13 @@ class PcoaEngine(object):
             raise ValueError("expected an %d x %d matrix" % (self.n, self.cols))
         self._check(self._lib.pcoa_gram_load_i64(self._ctx, _ptr(a)))
 
+    def debug_centred_matvec(self, x, upper_triangle_form):
+        """One y = B x of the centred matrix of the current S (test hook of the two mat-vec forms of the eigensolver)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.zeros(self.n, dtype=np.float64)
+        self._check(self._lib.pcoa_debug_centred_matvec(self._ctx, _ptr(x), _ptr(y), int(upper_triangle_form)))
+        return y
+
     def reduce_from(self, other):
         """self.S += other.S (two engines of this process; pcoa_gram_reduce_from: peer copy + int64 add, no collective)."""
         self._check(self._lib.pcoa_gram_reduce_from(self._ctx, other._ctx))
@@ -353,6 +360,8 @@ class PcoaEngine(object):
         """(B v)[col0:col0+cols] for a float64 torch tensor v on this engine's GPU; returns a device tensor (no PCIe traffic)."""
         import torch  # plumbing only: device memory handles
         assert v_dev.is_cuda and v_dev.dtype == torch.float64 and v_dev.dim() == 1 and v_dev.shape[0] == self.n
+        if v_dev.device.index != self.device:   # the ctx dereferences the pointer on ITS device (ADVICE r03)
+            raise ValueError("v lives on cuda:%d, this strip owner on cuda:%d" % (v_dev.device.index, self.device))
         v_dev = v_dev.contiguous()
         y = torch.empty(self.cols, dtype=torch.float64, device=v_dev.device)
         torch.cuda.current_stream(v_dev.device).synchronize()   # the engine runs on its own stream

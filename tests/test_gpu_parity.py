@@ -464,6 +464,33 @@ def test_the_device_side_check_of_carrier_lists_rejects_rolls_back_and_redoes(P,
             eng.sync()
 
 
+@pytest.mark.parametrize("n", [1024, 2504, 3076, 4100])
+def test_upper_triangle_form_of_the_centred_matvec_agrees_with_the_row_form_and_the_oracle(P, O, n):
+    """r04: from N = 16,384 the Lanczos mat-vec reads only the upper-triangular 1024 x 1024 tiles of S (each entry serves y_i and
+    y_j).  Same entries of B (reference operation order), another order of the additions: the two forms agree to 1e-13 of
+    ||B|| ||x||, and with the oracle's materialised B.  Shapes: one tile, a ragged last tile in both directions, N % 1024 small."""
+    rng = np.random.default_rng(n)
+    v = 700
+    x8 = (rng.random((v, n)) < rng.uniform(0.02, 0.4, size=(v, 1))).astype(np.uint8)
+    with P.PcoaEngine(n) as eng:
+        eng.accumulate_dense_u8(x8)
+        s = eng.gram()
+        b = O.center_matrix(s)[0]
+        scale = np.abs(b).sum(axis=1).max()
+        for seed in range(3):
+            xv = np.random.default_rng(seed).standard_normal(n)
+            y_row = eng.debug_centred_matvec(xv, 0)
+            y_tri = eng.debug_centred_matvec(xv, 1)
+            want = b @ xv
+            assert np.abs(y_row - want).max() <= 1e-12 * scale * np.abs(xv).max()
+            assert np.abs(y_tri - y_row).max() <= 1e-13 * scale * np.abs(xv).max()
+        # a unit vector picks out one row / column of B exactly (the entries themselves are bit-identical in both forms)
+        for k in (0, n // 2 + 1, n - 1):
+            e = np.zeros(n)
+            e[k] = 1.0
+            assert np.array_equal(eng.debug_centred_matvec(e, 1), b[:, k]) and np.array_equal(eng.debug_centred_matvec(e, 0), b[:, k])
+
+
 def test_accumulation_is_additive_shard_invariant_and_resumable(P, O):
     rng = np.random.default_rng(11)
     n, v = 150, 900

@@ -1,6 +1,6 @@
 """The register / LDS budget the co-resident pipeline rests on, read from the built library (CPU, no GPU needed).
 
-DESIGN.md 4.0: a contraction workgroup (2 waves per SIMD) and the ring pre-pass share a CU only if
+DESIGN_HISTORY.md 4.0: a contraction workgroup (2 waves per SIMD) and the ring pre-pass share a CU only if
 2 * vgpr(gram_kbits_kernel) + waves * vgpr(ring) <= 512 per SIMD (allocation granule 8) and the LDS adds up to <= 160 KiB.
 A compiler or source change that pushes the contraction back to 256 VGPRs would silently turn the pipeline into the serial
 order -- nothing fails, it just gets slower.  This test reads `.vgpr_count` / `.group_segment_fixed_size` of the kernels from

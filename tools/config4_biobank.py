@@ -72,6 +72,16 @@ def main():
     comps, lam, nz = eng.compute(2)
     t_pcoa = time.perf_counter() - t1
     tim2 = eng.timings()
+    # the two forms of the eigensolver's mat-vec on this S (pcoa_debug_centred_matvec; the vector crosses PCIe, 0.8 MB at N = 10^5)
+    xv = np.random.default_rng(1).standard_normal(n)
+    mv = {}
+    for form in (0, 1):
+        eng.debug_centred_matvec(xv, form)
+        tm = time.perf_counter()
+        for _ in range(3):
+            yv = eng.debug_centred_matvec(xv, form)
+        mv[form] = ((time.perf_counter() - tm) / 3.0, yv)
+    mv_diff = float(np.abs(mv[0][1] - mv[1][1]).max() / np.abs(mv[0][1]).max())
     out = {
         "workload": "biobank scale (configs[3] = 100,000 x 10^6; configs[4] sample count = 250,000): synthetic %d samples x %d variants, 1x MI355X (Gram + eig on one GPU)" % (n, v),
         "device": name, "cu_count": cus,
@@ -81,6 +91,8 @@ def main():
         "variants_per_s_kernels": v / (tim["gram_kernel_seconds"] + tim["pack_seconds"]),
         "algorithmic_pops": 2.0 * v * n * n / tim["gram_kernel_seconds"] / 1e15,
         "pcoa_wall_s": t_pcoa, "pcoa_method": tim2["eig_method"], "lanczos_steps": tim2["lanczos_steps"],
+        "matvec_row_form_s": mv[0][0], "matvec_upper_triangle_form_s": mv[1][0], "matvec_forms_max_rel_diff": mv_diff,
+        "matvec_note": "row form reads 4 N^2 bytes, upper-triangle form 2 N^2 + tile sums; both include centring, H2D / D2H of the vector",
         "eigenvalues": [float(x) for x in lam], "nonzero_rows": int(nz),
         "unit_norm": [float(np.linalg.norm(comps[:, c])) for c in range(2)],
         "orthogonality": float(abs(comps[:, 0] @ comps[:, 1])),

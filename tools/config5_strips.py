@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE configs[4] layout ("Gram tiled across HBM"): one strip owner per rank, every rank sees every variant,
-computePca as a Lanczos iteration over the strips (spark-examples_amd/strips.py).
+computePca as a Lanczos iteration over the strips (spark-examples_amd/strips.py; DESIGN_HISTORY.md 4.5).
 
   torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/config5_strips.py --samples 250000 --variants 10000000
 

@@ -1,4 +1,4 @@
-// exp_overlap.hip -- A/B harness for the fp32 boundary of the Gram path.
+// exp_overlap.hip -- A/B harness for the fp32 boundary of the Gram path (DESIGN_HISTORY.md 4.1).
 //
 // Measures, on one MI355X and on the kernels of spark-examples_amd/csrc/gram_packed.hip themselves (the file is
 // included, so the anonymous-namespace kernels are visible):

@@ -32,8 +32,8 @@ for n, d in sorted(res.items()):
     print(n)
     for c, v in sorted(d.items()): print("   %-28s %.4g" % (c, v))
     if "TCC_HIT_sum" in d: print("   L2 hit rate %.3f" % (d["TCC_HIT_sum"] / max(1, d["TCC_HIT_sum"] + d["TCC_MISS_sum"])))
-    if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "GRBM_GUI_ACTIVE" in d: print("   MFMA busy / SIMD / GUI_ACTIVE %.3f" % (d["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / d["GRBM_GUI_ACTIVE"]))
-    if "SQ_INSTS_VALU" in d and "SQ_INSTS_MFMA" in d: print("   VALU : MFMA %.2f" % (d["SQ_INSTS_VALU"] / d["SQ_INSTS_MFMA"]))
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "GRBM_GUI_ACTIVE" in d: print("   MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs) = %.3f" % (d["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (d["GRBM_GUI_ACTIVE"] / 8)))
+    if "SQ_INSTS_VALU" in d and "SQ_INSTS_MFMA" in d: print("   SQ_INSTS_VALU : SQ_INSTS_MFMA %.2f (SQ_INSTS_VALU counts the MFMAs too: %.2f other VALU per MFMA)" % (d["SQ_INSTS_VALU"] / d["SQ_INSTS_MFMA"], d["SQ_INSTS_VALU"] / d["SQ_INSTS_MFMA"] - 1))
     if "TCC_EA0_RDREQ_LEVEL_sum" in d and "TCC_EA0_RDREQ_sum" in d: print("   mean EA read latency %.0f TCC cycles" % (d["TCC_EA0_RDREQ_LEVEL_sum"] / max(1, d["TCC_EA0_RDREQ_sum"])))
 json.dump(res, open("$OUT/pmc_summary.json", "w"), indent=1)
 PY
