@@ -145,6 +145,17 @@ int pcoa_create(pcoa_ctx** out, int32_t n_samples, int32_t device_ordinal, uint3
 int pcoa_create_strip(pcoa_ctx** out, int32_t n_samples, int32_t col0, int32_t cols, int32_t device_ordinal,
                       uint32_t flags);
 
+/* computePca's eigensolver for a matrix the engine does not hold (r04): the engine's Lanczos iteration (Krylov basis and
+ * re-orthogonalisation on the GPU, Ritz pairs by bisection + inverse iteration, a pair accepted only after its TRUE residual
+ * passes) with the product y = B v supplied by the caller: fn(user, v_dev, y_dev) must leave B v in y_dev -- both are device
+ * vectors of N doubles on the ctx's GPU -- with its own work complete when it returns, and return 0.  out_components:
+ * [num_pc][N] unit, sign-normalised columns (as pcoa_compute); PCOA_ERR_NOT_CONVERGED if no verified pair is reached (there
+ * is no dense fallback here).  Any ctx will do (a strip owner's: spark-examples_amd/strips.py runs computePca over strips
+ * through this, every product one all-gather of an N-vector).  Replaces: the same MLlib call (VariantsPca.scala:224-227). */
+typedef int (*pcoa_matvec_fn)(void* user, const double* v_dev, double* y_dev);
+int pcoa_lanczos_with_matvec(pcoa_ctx* ctx, int32_t num_pc, pcoa_matvec_fn fn, void* user, double* out_components,
+                             double* out_eigenvalues, int32_t* steps_out);
+
 /* Returns 1 for a strip owner (and its column range), 0 for an ordinary ctx. */
 int pcoa_strip_info(const pcoa_ctx* ctx, int32_t* col0_out, int32_t* cols_out);
 

@@ -68,6 +68,22 @@ JNIEXPORT jint JNICALL FN(accumulateCalls)(JNIEnv* env, jobject, jlong ctx, jobj
                                static_cast<int64_t>(n_variants));
 }
 
+// pcoa_accumulate_calls_ex: the same batch with the caller saying where the buffers live and whether it will wait
+// (PCOA_CALLS_HOST_PINNED | PCOA_CALLS_ASYNC for a host that builds batch k+1 while batch k travels)
+JNIEXPORT jint JNICALL FN(accumulateCallsEx)(JNIEnv* env, jobject, jlong ctx, jobject sample_idx, jobject row_offsets,
+                                             jlong n_variants, jint flags) {
+  return pcoa_accumulate_calls_ex(ctx_of(ctx), direct<const int32_t>(env, sample_idx), direct<const int64_t>(env, row_offsets),
+                                  static_cast<int64_t>(n_variants), static_cast<uint32_t>(flags));
+}
+
+// pcoa_sync: the synchronising call after which asynchronously handed-over buffers may be reused
+JNIEXPORT jint JNICALL FN(sync)(JNIEnv*, jobject, jlong ctx) { return pcoa_sync(ctx_of(ctx)); }
+
+// pcoa_gram_reduce_from: dst.S += src.S, two engines of this JVM
+JNIEXPORT jint JNICALL FN(gramReduceFrom)(JNIEnv*, jobject, jlong dst, jlong src) {
+  return pcoa_gram_reduce_from(ctx_of(dst), ctx_of(src));
+}
+
 // pcoa_accumulate_bits: one carrier bitset per record (java.util.BitSet.toLongArray() written little-endian)
 JNIEXPORT jint JNICALL FN(accumulateBits)(JNIEnv* env, jobject, jlong ctx, jobject bits, jlong n_variants, jlong ld_words) {
   return pcoa_accumulate_bits(ctx_of(ctx), direct<const uint32_t>(env, bits), static_cast<int64_t>(n_variants),

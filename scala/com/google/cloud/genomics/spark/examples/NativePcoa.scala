@@ -27,11 +27,19 @@ object NativePcoa {
   val FlagDefault = 0
   val FlagEigHouseholder = 0x20
 
+  /** flags of accumulateCallsEx (pcoa.h: PCOA_CALLS_*) */
+  val CallsDevicePtr = 1
+  val CallsPinned = 2
+  val CallsAsync = 4
+
   @native def create(nSamples: Int, device: Int, flags: Int): Long // pcoa_create; throws IllegalStateException
   @native def destroy(ctx: Long): Unit // pcoa_destroy
   @native def lastError(ctx: Long): String // pcoa_last_error
   @native def reset(ctx: Long): Int // pcoa_reset
   @native def accumulateCalls(ctx: Long, sampleIdx: ByteBuffer, rowOffsets: ByteBuffer, nVariants: Long): Int // pcoa_accumulate_calls
+  @native def accumulateCallsEx(ctx: Long, sampleIdx: ByteBuffer, rowOffsets: ByteBuffer, nVariants: Long, flags: Int): Int // pcoa_accumulate_calls_ex
+  @native def sync(ctx: Long): Int // pcoa_sync
+  @native def gramReduceFrom(dst: Long, src: Long): Int // pcoa_gram_reduce_from (two engines of this JVM)
   @native def accumulateBits(ctx: Long, bits: ByteBuffer, nVariants: Long, ldWords: Long): Int // pcoa_accumulate_bits
   @native def gramFinalize(ctx: Long): Int // pcoa_gram_finalize
   @native def commUniqueId(): Array[Byte] // pcoa_comm_unique_id (128 bytes; null on failure)

@@ -28,6 +28,7 @@ PCOA_FLAG_EIG_HOUSEHOLDER = 0x20
 PCOA_FLAG_EIG_LANCZOS = 0x40
 PCOA_FLAG_NO_PIPELINE = 0x80
 PCOA_FLAG_OPERAND_FP4 = 0x100
+MATVEC_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
 PCOA_CALLS_DEVICE_PTR = 1
 PCOA_CALLS_HOST_PINNED = 2
 PCOA_CALLS_ASYNC = 4
@@ -105,6 +106,7 @@ _SIGNATURES = [
     ("pcoa_debug_guard_mode", ctypes.c_int, []),
     ("pcoa_accumulate_calls", ctypes.c_int, [_vp, _vp, _vp, _i64]),
     ("pcoa_gram_reduce_from", ctypes.c_int, [_vp, _vp]),
+    ("pcoa_lanczos_with_matvec", ctypes.c_int, [_vp, ctypes.c_int32, _vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_int32)]),
     ("pcoa_debug_centred_matvec", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int]),
     ("pcoa_host_alloc_pinned", ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]),
     ("pcoa_host_free_pinned", ctypes.c_int, [_vp]),

@@ -495,7 +495,18 @@ size_t lanczos_workspace_doubles(int32_t n, int32_t k, int32_t mmax) {
 // B (unnormalised Ritz vectors; the caller normalises) and lam_sel_host[0..k) their eigenvalues
 // (ordered by decreasing magnitude).  B (ws.a, or the implicit form when ws.a is null) is not modified.
 hipError_t lanczos_topk(const EigWorkspace& ws, double* lz, int32_t n, int32_t k, int32_t mmax, double tol,
-                        double* lam_sel_host, int* converged, int* steps_out, hipStream_t stream) {
+                        double* lam_sel_host, int* converged, int* steps_out, hipStream_t stream, const LanczosMatvec* mv) {
+  // mv: y = B v supplied by the caller (strip owners: B is tiled over GPUs and the product needs an all-gather the
+  // engine knows nothing about); the stream is drained around the call
+  auto matvec = [&](const double* v, double* y) -> hipError_t {
+    if (!mv) {
+      launch_symv(ws, n, v, y, stream);
+      return hipSuccess;
+    }
+    hipError_t e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    return (*mv)(v, y) == 0 ? hipSuccess : hipErrorUnknown;
+  };
   *converged = 0;
   if (steps_out) *steps_out = 0;
   if (mmax > n) mmax = n;
@@ -531,7 +542,10 @@ hipError_t lanczos_topk(const EigWorkspace& ws, double* lz, int32_t n, int32_t k
   for (int j = 0; j < mmax; ++j) {
     const double* vj = V + (size_t)j * n;
     const int cnt = j + 1;
-    launch_symv(ws, n, vj, w, stream);
+    {
+      const hipError_t em = matvec(vj, w);
+      if (em != hipSuccess) return em;
+    }
     // CGS2 in three launches: dots of pass 1 (one workgroup per basis vector), then per 256-entry slice of w the update
     // of pass 1 fused with the slice's share of the dots of pass 2, then the update of pass 2 fused with the slice's
     // share of ||w||^2.  (All of it in ONE workgroup was measured slower: 30 vs 24 us per step -- a single CU cannot
@@ -567,8 +581,10 @@ hipError_t lanczos_topk(const EigWorkspace& ws, double* lz, int32_t n, int32_t k
     // ws.z <- u (ritz_kernel read y from ws.z, so it wrote to bu first)
     if ((e = hipMemcpyAsync(ws.z, bu, sizeof(double) * (size_t)k * n, hipMemcpyDeviceToDevice, stream)) != hipSuccess)
       return e;
-    for (int t = 0; t < k; ++t)
-      launch_symv(ws, n, ws.z + (size_t)t * n, bu + (size_t)t * n, stream);
+    for (int t = 0; t < k; ++t) {
+      const hipError_t em = matvec(ws.z + (size_t)t * n, bu + (size_t)t * n);
+      if (em != hipSuccess) return em;
+    }
     hipLaunchKernelGGL(residual_kernel, dim3((unsigned)k), dim3(1024), 0, stream, bu, ws.z, n, ws.lam, rec_res);
     const size_t rec_count = (size_t)nc + 1 + 2 * (size_t)k;
     double* hrec = ws.host_rec;

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -205,8 +206,11 @@ hipError_t launch_backtransform(const EigWorkspace& ws, int32_t n, int32_t k, in
 
 // ---- Lanczos fast path (eig_lanczos.hip) ------------------------------------------------------
 size_t lanczos_workspace_doubles(int32_t n, int32_t k, int32_t mmax);
+// mv (optional): the caller's y = B v on device vectors (return 0); nullptr = the engine's own mat-vec on ws
+typedef std::function<int(const double*, double*)> LanczosMatvec;
 hipError_t lanczos_topk(const EigWorkspace& ws, double* lz, int32_t n, int32_t k, int32_t mmax, double tol,
-                        double* lam_sel_host, int* converged, int* steps_out, hipStream_t stream);
+                        double* lam_sel_host, int* converged, int* steps_out, hipStream_t stream,
+                        const LanczosMatvec* mv = nullptr);
 
 }  // namespace pcoa
 

@@ -289,6 +289,48 @@ class PcoaEngine(object):
             raise ValueError("expected an %d x %d matrix" % (self.n, self.cols))
         self._check(self._lib.pcoa_gram_load_i64(self._ctx, _ptr(a)))
 
+    def lanczos(self, matvec, num_pc, max_steps=512, tol=1e-11, first_check=12, trace=None):
+        """Top-k eigenpairs of the symmetric operator `matvec` (float64 CUDA tensor of N entries on this engine's GPU -> the
+        same) by the ENGINE's Lanczos iteration (pcoa_lanczos_with_matvec): Krylov basis, re-orthogonalisation, the Ritz
+        problem and the true-residual acceptance run in the library's kernels; this method only wraps the callback's device
+        pointers as tensors.  Returns (components [N][k] sign-normalised unit columns, eigenvalues [k]).  (max_steps / tol /
+        first_check are the stand-in's knobs; the engine uses its own: 512, 1e-11, 12.)"""
+        import torch  # plumbing only: a tensor view of a device pointer
+        n, k = self.n, int(num_pc)
+        dev = torch.device("cuda", self.device)
+
+        class _Ptr(object):   # __cuda_array_interface__: N float64 at a raw device address
+            def __init__(self, addr):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(addr), False), "version": 2}
+
+        failure = []
+
+        def call(_user, v_ptr, y_ptr):
+            try:
+                v = torch.as_tensor(_Ptr(v_ptr), device=dev)
+                y = torch.as_tensor(_Ptr(y_ptr), device=dev)
+                y.copy_(matvec(v))
+                torch.cuda.current_stream(dev).synchronize()   # the engine reads y on its own stream next
+                return 0
+            except BaseException as exc:   # never unwind through the C frames
+                failure.append(exc)
+                return 1
+
+        cb = L.MATVEC_FN(call)
+        comps = np.zeros((k, n), dtype=np.float64)
+        lam = np.zeros(k, dtype=np.float64)
+        steps = ctypes.c_int32(0)
+        rc = self._lib.pcoa_lanczos_with_matvec(self._ctx, k, cb, None, _ptr(comps), _ptr(lam), ctypes.byref(steps))
+        if failure:
+            raise failure[0]
+        if trace is not None:
+            trace.append((int(steps.value), lam.copy(), None))
+        if rc == L.PCOA_ERR_NOT_CONVERGED:
+            raise RuntimeError("Lanczos over strips did not reach a verified residual in %d steps (tiny spectral gaps?); there "
+                               "is no dense fallback for a matrix tiled across GPUs" % int(steps.value))
+        self._check(rc)
+        return np.ascontiguousarray(comps.T), lam
+
     def debug_centred_matvec(self, x, upper_triangle_form):
         """One y = B x of the centred matrix of the current S (test hook of the two mat-vec forms of the eigensolver)."""
         x = np.ascontiguousarray(x, dtype=np.float64)

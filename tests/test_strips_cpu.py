@@ -1,6 +1,6 @@
 """CPU tests of the strip-owner computePca (spark-examples_amd/strips.py): the host-driven Lanczos over
-column strips of S, with numpy stand-ins for the GPU strip owners (the same interface: .n, .strip, .strip_col_sums(),
-.strip_matvec()), single-process and over two gloo ranks."""
+column strips of S, with numpy stand-ins for the GPU strip owners (tests/strip_standins.py: the same interface, .lanczos included),
+single-process and over two gloo ranks."""
 import os
 import socket
 import sys
@@ -9,37 +9,7 @@ import numpy as np
 import pytest
 
 from conftest import ROOT, align_sign, load_oracle, load_pkg, planted_callsets
-
-
-class HostStrip(object):
-    """numpy stand-in for PcoaEngine(strip=(col0, cols)): holds S[:, col0:col0+cols] and evaluates the rows of B in the
-    reference's operation order, as csrc/center.hip: strip_band_kernel does."""
-
-    def __init__(self, s_full, col0, cols):
-        self.n = s_full.shape[0]
-        self.strip = (col0, cols)
-        self.s = np.ascontiguousarray(s_full[:, col0:col0 + cols]).astype(np.float64)
-
-    @classmethod
-    def empty(cls, n, col0, cols):
-        return cls(np.zeros((n, n), dtype=np.int64), col0, cols)
-
-    def accumulate_bits(self, bits):
-        """carrier bitsets [v][ceil(n/32)] uint32 (pcoa_accumulate_bits): S[:, strip] += X^T X[:, strip]"""
-        bits = np.asarray(bits)
-        assert bits.dtype == np.uint32 and bits.ndim == 2 and bits.shape[1] == (self.n + 31) // 32
-        x = ((bits[:, :, None] >> np.arange(32, dtype=np.uint32)[None, None, :]) & 1).reshape(bits.shape[0], -1)[:, :self.n]
-        x = x.astype(np.float64)
-        col0, cols = self.strip
-        self.s += x.T @ x[:, col0:col0 + cols]
-
-    def strip_col_sums(self):
-        return self.s.sum(axis=0)
-
-    def strip_matvec(self, v, means, matrix_mean):
-        col0, cols = self.strip
-        b = ((self.s - means[col0:col0 + cols][None, :]) - means[:, None]) + matrix_mean   # B(j, i) at [i, jj]
-        return b.T @ v
+from strip_standins import HostStrip
 
 
 def _cohort(seed, n, v):

@@ -26,30 +26,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-class NumpyStrip(object):
-    """CPU stand-in for PcoaEngine(strip=...): the interface strips.py needs, in numpy (tests / --standin only)."""
-
-    def __init__(self, n, col0, cols):
-        self.n, self.strip = n, (col0, cols)
-        self.s = np.zeros((n, cols), dtype=np.float64)
-
-    def accumulate_bits(self, bits):
-        bits = np.asarray(bits)
-        x = ((bits[:, :, None] >> np.arange(32, dtype=np.uint32)[None, None, :]) & 1).reshape(bits.shape[0], -1)[:, :self.n]
-        x = x.astype(np.float64)
-        c0, w = self.strip
-        self.s += x.T @ x[:, c0:c0 + w]
-
-    def strip_col_sums(self):
-        return self.s.sum(axis=0)
-
-    def strip_matvec(self, v, means, matrix_mean):
-        c0, w = self.strip
-        b = ((self.s - means[c0:c0 + w][None, :]) - means[:, None]) + matrix_mean
-        return b.T @ v
-
-    def close(self):
-        pass
+def NumpyStrip(n, col0, cols):
+    """CPU stand-in for PcoaEngine(strip=...) (tests / --standin only): tests/strip_standins.py"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from strip_standins import HostStrip
+    return HostStrip.empty(n, col0, cols)
 
 
 def device_bitsets(owner, seed, offs, thr, first, n, dev):
