@@ -74,6 +74,31 @@ def cpu_baseline(x_dev, n, budget_s=20.0):
             "blas_note": "best-effort numpy/OpenBLAS sgemm X^T X on %d variants" % nb}, s_ref, sample
 
 
+def pmc_for(key):
+    """HBM traffic per 10^6 variants from rocprofv3 --pmc passes.  k-bits kernels: profiles/gram_pmc_live.json, written by
+    `tools/gpu_round.sh <tag> pmclive` from the tree it ran on and named by that tree's source hash; a file of another
+    tree is REFUSED (traffic: null).  The older kernels (f32 / i8 / fp4 operand) keep their static record."""
+    P = pkg("_lib")
+    here = P.source_hash()
+    live = os.path.join(ROOT, "profiles", "gram_pmc_live.json")
+    if key.startswith("kbits"):
+        try:
+            rec = json.load(open(live))
+        except Exception:  # noqa: BLE001
+            return {}, "no profiles/gram_pmc_live.json for this tree (source hash %s): run tools/gpu_round.sh <tag> pmclive" % here
+        if rec.get("source_hash") != here:
+            return {}, ("REFUSED: profiles/gram_pmc_live.json was measured on source hash %s, this tree is %s "
+                        "(tools/gpu_round.sh <tag> pmclive makes a new one)" % (rec.get("source_hash"), here))
+        return rec.get(key, {}), ("profiles/gram_pmc_live.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                                  "(--no-extras) on THIS source tree (hash %s, %s), per 10^6 variants, scaled to this run's "
+                                  "launch size" % (here, rec.get("made", "?")))
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "gram_pmc_latest.json")))
+        return rec.get(key, {}), "profiles/gram_pmc_latest.json (static record of an earlier round; NOT measured on this tree)"
+    except Exception:  # noqa: BLE001
+        return {}, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,6 +110,9 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--cohort", type=int, default=8000000, help="--scaling strong: variants of the fixed cohort")
     ap.add_argument("--samples", type=int, default=N_SAMPLES)
+    ap.add_argument("--ld", type=int, default=0,
+                    help="row pitch of the resident fp32 tile in floats (0 = packed: ld = samples).  pcoa.h: a pitch that is a "
+                         "multiple of 32 floats starts every row on a 128-byte line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pcoa-reps", type=int, default=3)
     ap.add_argument("--no-extras", action="store_true",
@@ -152,11 +180,15 @@ def main():
         first, resident = rank * nb * v, nb * v
         batch_of = lambda i: ((i % nb) * v, (i % nb) * v + v)      # noqa: E731
         variants_per_job = world * v * steps_n
-    x = torch.empty((resident, n), dtype=torch.float32, device=dev)
+    ld = args.ld if args.ld >= n else n
+    x_store = torch.empty((resident, ld), dtype=torch.float32, device=dev)
+    if ld > n:
+        x_store[:, n:].fill_(float("nan"))        # pitch padding is never read as data: NaN would fail the 0/1 check
+    x = x_store[:, :n]
     step_rows = 1 << 18
     for v0 in range(0, resident, step_rows):
         v1 = min(resident, v0 + step_rows)
-        eng.synth_fill(SEED, offs, synth.thresholds(SEED, first + v0, v1 - v0), first + v0, x[v0:v1].data_ptr(), n)
+        eng.synth_fill(SEED, offs, synth.thresholds(SEED, first + v0, v1 - v0), first + v0, x[v0:v1].data_ptr(), ld)
     eng.sync()
 
     scratch = None
@@ -269,16 +301,7 @@ def main():
         vpl = tim["gram_variants"] / launches                    # variants per contraction launch
         flops_per_launch = 2.0 * vpl * n * n                     # algorithmic 2*V*N^2
         achieved = flops_per_launch / kern_s / 1e12 if kern_s > 0 else 0.0
-        pmc, pmc_src = {}, None
-        pmc_path = os.path.join(ROOT, "profiles", "gram_pmc_latest.json")
-        if os.path.exists(pmc_path):
-            try:
-                pmc = json.load(open(pmc_path)).get(
-                    "kbits" if int(tim["operand_bits"]) == 1 else {1: "f32", 2: "i8", 3: "fp4"}[tim["gram_kernel_kind"]], {})
-                pmc_src = "profiles/gram_pmc_latest.json (static: rocprofv3 --pmc passes of an earlier run of this command, " \
-                          "scaled to this run's launch size; NOT measured in this run)"
-            except Exception:
-                pmc = {}
+        pmc, pmc_src = pmc_for("kbits" if kbits else {1: "f32", 2: "i8", 3: "fp4"}[tim["gram_kernel_kind"]])
         kind = tim["gram_kernel_kind"]          # what actually ran: 1 fp32, 2 int8, 3 MX-FP4
         pipe = bool(info.get("pipeline"))
         gram_cus = info.get("pipeline_contraction_cus", cus) if pipe else cus
@@ -384,7 +407,7 @@ def main():
                                         if args.scaling == "weak" else
                                         "STRONG scaling: fixed cohort of %d variants sharded over %d ranks, K steps = one pass"
                                         % (args.cohort, world))),
-                       "n_samples": n, "variants_per_step_per_gpu": v if args.scaling == "weak" else resident // steps,
+                       "n_samples": n, "row_pitch_floats": ld, "variants_per_step_per_gpu": v if args.scaling == "weak" else resident // steps,
                        "resident_variants_per_gpu": resident, "seed": SEED,
                        "parallelism": "variant-sharded x%d" % world,
                        "allreduce": allreduce_mode,
@@ -410,6 +433,10 @@ def main():
             "pcoa_paths_max_vector_diff": agree,
             "eigenvalues": [float(t) for t in lam], "nonzero_rows": int(nz),
             "device": dev_name, "cu_count": cus,
+            # what tools/pmc_live.py needs to turn per-process counter totals into per-variant traffic
+            "pmc_manifest": {"source_hash": pkg("_lib").source_hash(), "no_extras": bool(args.no_extras),
+                             "fp32_variants_through_the_engine": int((args.warmup + args.steps) * v) if args.scaling == "weak" else None,
+                             "pipeline": bool(info["pipeline"])},
         }
         if not args.no_extras and info["pipeline"]:
             # the two kernels STANDALONE (each alone on the whole chip, strictly serial on one stream): what their own
@@ -443,6 +470,10 @@ def main():
                                 "achieved": 2.0 * gv * n * n / gs / 1e12 * issued_fraction(n, 256),
                                 "frac": 2.0 * gv * n * n / gs / 1e12 * issued_fraction(n, 256) / PEAK_FP4_MFMA_TFLOPS,
                                 "convention": "issued matrix-core work", "variants_per_launch": gv}}
+            pmc_alone, pmc_alone_src = pmc_for("kbits_standalone")
+            for k2, fld, per in (("pre_pass", "pack_hbm_bytes_per_mvariants", vs), ("contraction", "gram_hbm_bytes_per_mvariants", gv)):
+                out["roofline_standalone"][k2]["traffic"] = pmc_alone[fld] * per / 1e6 if fld in pmc_alone else None
+                out["roofline_standalone"][k2]["traffic_source"] = pmc_alone_src
             # the same two figures next to the co-running ones, where a reader of `roofline` looks first
             for obj in (out.get("roofline"), out.get("roofline_other")):
                 if not isinstance(obj, dict):

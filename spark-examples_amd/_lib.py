@@ -139,6 +139,22 @@ EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
 _lib = None
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources the library is built from (csrc/* and include/pcoa.h).
+    A measurement file made from one tree (profiles/gram_pmc_live.json) names the tree by this hash; .git does not
+    travel to the GPU box and the commit that adds such a file moves HEAD, so a commit id cannot be used for it."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(_HERE, "csrc")
+    files = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".inl", ".h"))]
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "pcoa.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def load():
     """Loads libpcoa_hip.so and binds every entry point; raises ImportError if it is absent."""
     global _lib

@@ -185,7 +185,48 @@ def ring_case(seed, idx):
         return int(tim["pipeline_launches"])
 
 
+def aln_case(seed, idx):
+    """fp32 SUB-tiles through the co-resident pipeline's ring pre-pass: every residue of the pitch mod 32 floats (rows on and off
+    the 128-byte lines), sub-tiles that start at row 0..3 of an allocation (every offset of the first row inside its line),
+    sample counts that fill the padded range to within a few samples, NaN in the pitch padding and in the rows before the
+    sub-tile."""
+    rng = np.random.default_rng(seed)
+    n = [2504, 2504, 2532, 2536, 1284, 3000][idx % 6]
+    ld = (n + 7) // 8 * 8 + 8 * int(rng.integers(0, 5))
+    r0 = int(rng.integers(0, 4))
+    calls = [int(rng.choice([2049, 4097, 4500, 6000])) for _ in range(int(rng.integers(3, 6)))]
+    dens = float(rng.choice([0.05, 0.3]))
+    print("aln case seed=%d n=%d ld=%d (mod 32: %d) first row %d calls=%s" % (seed, n, ld, ld % 32, r0, calls), flush=True)
+    want = np.zeros((n, n), dtype=np.int64)
+    with P.PcoaEngine(n, gram_kernel="fp4") as eng:
+        ctx = eng._ctx
+        bufs = []
+        for v in calls:
+            x = (rng.random((v, n)) < dens).astype(np.uint8)
+            x[0, 0] = x[0, n - 1] = x[v - 1, 0] = x[v - 1, n - 1] = 1      # the corners of the sub-tile
+            want += int_gram(x)
+            a = np.full((v + r0, ld), np.nan, dtype=np.float32)
+            a[r0:, :n] = x
+            d = DevBuf(a)
+            eng._check(lib.pcoa_accumulate_dense_f32(ctx, ctypes.c_void_p(d.ptr.value + 4 * r0 * ld), v, ld, 1))
+            bufs.append(d)
+        check(eng, want, "fp32 sub-tiles with rows off the 128-byte lines")
+        tim = eng.timings()
+        for d in bufs:
+            d.free()
+        return int(tim["pipeline_launches"])
+
+
 def main():
+    if len(sys.argv) > 5 and sys.argv[5] == "aln":
+        n_cases, first = int(sys.argv[1]), int(sys.argv[2])
+        mode = lib.pcoa_debug_guard_mode()
+        print("guard mode %d (sub-tiles, pitches)" % mode, flush=True)
+        piped = sum(aln_case(first + i, i) for i in range(n_cases))
+        assert hip.hipDeviceSynchronize() == 0
+        assert piped > 0, "no contraction was launched beside a pre-pass: is PCOA_DEBUG_MAX_LAUNCH set?"
+        print("guard sweep ok: %d sub-tile / pitch cases, %d pipelined contraction launches, mode %d" % (n_cases, piped, mode), flush=True)
+        return
     if len(sys.argv) > 5 and sys.argv[5] == "ring":
         n_cases, first = int(sys.argv[1]), int(sys.argv[2])
         mode = lib.pcoa_debug_guard_mode()

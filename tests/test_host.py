@@ -668,3 +668,37 @@ def test_compiled_host_again_under_asan_and_ubsan(which, tmp_path, monkeypatch):
         test_variant_sets_with_the_same_file_stem_keep_distinct_callsets(tmp_path)
     else:
         test_gzip_path_with_shell_metacharacters_is_just_a_path(tmp_path)
+
+
+def test_bench_refuses_counter_traffic_of_another_tree(tmp_path, monkeypatch):
+    """roofline.traffic must come from --pmc passes of the tree being benchmarked: profiles/gram_pmc_live.json names its
+    tree by source hash (csrc/* + pcoa.h) and bench.pmc_for returns nothing for a file made from other sources."""
+    import importlib
+    import json
+    import shutil
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    lib = importlib.import_module("spark-examples_amd._lib")
+    here = lib.source_hash()
+    assert len(here) == 16 and here == lib.source_hash()
+    (tmp_path / "profiles").mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    rec, src = bench.pmc_for("kbits")
+    assert rec == {} and "no profiles/gram_pmc_live.json" in src
+    live = tmp_path / "profiles" / "gram_pmc_live.json"
+    live.write_text(json.dumps({"source_hash": "0" * 16, "kbits": {"gram_hbm_bytes_per_mvariants": 1.0}}))
+    rec, src = bench.pmc_for("kbits")
+    assert rec == {} and src.startswith("REFUSED")
+    live.write_text(json.dumps({"source_hash": here, "made": "today", "kbits": {"gram_hbm_bytes_per_mvariants": 1.0}}))
+    rec, src = bench.pmc_for("kbits")
+    assert rec == {"gram_hbm_bytes_per_mvariants": 1.0} and here in src
+    # the hash follows the kernel sources: the same files under another root with one byte more give another hash
+    pkg_copy = tmp_path / "pkg"
+    shutil.copytree(os.path.join(ROOT, "spark-examples_amd", "csrc"), pkg_copy / "p" / "csrc",
+                    ignore=shutil.ignore_patterns("*.o", "*.so", "*.hsaco", "*.s"))
+    shutil.copytree(os.path.join(ROOT, "include"), pkg_copy / "include")
+    monkeypatch.setattr(lib, "_HERE", str(pkg_copy / "p"))
+    assert lib.source_hash() == here
+    with open(pkg_copy / "p" / "csrc" / "center.hip", "a") as fh:
+        fh.write("\n")
+    assert lib.source_hash() != here

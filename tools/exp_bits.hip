@@ -537,6 +537,103 @@ static int coreside_main(int n, int64_t v, int reps, int num_cu, unsigned long l
   return bad ? 1 : 0;
 }
 
+// ---- --aln (r04x / r04y): the ring pre-pass over row pitches on and off the 128-byte lines, alone and co-resident ---------------
+// (r04x also had an "aligned window" form of the kernel for rows off the lines: per row class r mod 4 the wave read the aligned
+// 1 KiB its group starts in and permuted the variants of a 128-block accordingly.  Bit-exact, and worth nothing: 1.920 vs 1.927 ms
+// at ld = 2504.  The pitch sweep shows why -- 2520 (off the lines) runs like 2528, 2592 (on them) like 2504, and the same 2504
+// tile allocated twice differs by 6 %: the spread is where the 10 GB tile happens to lie, not how its rows sit in their lines.
+// profiles/r04y_ring_pitch_sweep.txt.  The form was removed.)
+static std::vector<int64_t> g_aln_lds;
+static bool g_aln_alone = false;
+static int aln_main(int n, int64_t v, int reps, int num_cu, unsigned long long* cnt) {
+  const int npad = (int)gram_packed_npad(n);
+  const int64_t nblk = gram_kb_pad(v, 2) / 4;
+  const size_t kbytes = (size_t)nblk * npad * 16;
+  int8_t* k1[2];
+  int32_t *sa, *sb, *flag;
+  for (int b = 0; b < 2; ++b) CK(hipMalloc(&k1[b], kbytes));
+  CK(hipMalloc(&sa, (size_t)n * n * 4));
+  CK(hipMalloc(&sb, (size_t)n * n * 4));
+  CK(hipMalloc(&flag, 64));
+  CK(hipMemset(flag, 0, 64));
+  hipStream_t ps, gs;
+  CK(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+  CK(hipStreamCreateWithFlags(&gs, hipStreamNonBlocking));
+  const int K = 12;
+  hipEvent_t packed[2], consumed[2], pe[K][2], ge[K][2];
+  for (int b = 0; b < 2; ++b) {
+    CK(hipEventCreateWithFlags(&packed[b], hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&consumed[b], hipEventDisableTiming));
+  }
+  for (int k = 0; k < K; ++k)
+    for (int j = 0; j < 2; ++j) { CK(hipEventCreate(&pe[k][j])); CK(hipEventCreate(&ge[k][j])); }
+  int bad = 0;
+  const double mv = (double)v / 1e6;
+  if (g_aln_lds.empty()) g_aln_lds = {(int64_t)n, (int64_t)((n + 31) / 32 * 32), (int64_t)n};
+  for (int64_t ld : g_aln_lds) {
+    float* x;
+    CK(hipMalloc(&x, (size_t)(v * ld * 4)));
+    hipLaunchKernelGGL(fill_kernel, dim3(8192), dim3(256), 0, 0, x, v, (int64_t)n, ld, 777u, 0x18000000u);
+    CK(hipDeviceSynchronize());
+    std::printf("-- ld = %lld floats (%lld B per row, %s)\n", (long long)ld, (long long)ld * 4,
+                (ld * 4) % 128 ? "rows OFF the 128-byte lines" : "rows on 128-byte lines");
+    // S through both forms
+    for (int form = 0; form < 2; ++form) {
+      CK(launch_pack_kbits_ring(x, ld, v, n, k1[form], flag, 0, nblk, 2 * num_cu, 8));
+      CK(hipMemset(form ? sb : sa, 0, (size_t)n * n * 4));
+      CK(launch_gram_kbits(k1[form], v, n, form ? sb : sa, num_cu, 0, 4));
+    }
+    CK(hipDeviceSynchronize());
+    const unsigned long long d = count_diff(sa, sb, (int64_t)n * n * 4, cnt);
+    std::printf("S(ring pre-pass twice): %s (%llu entries differ)\n", d ? "MISMATCH" : "bit-identical", d);
+    bad += d != 0;
+    auto line = [&](const char* what, float ms) { std::printf("time  %-66s %8.3f ms  (%.3f ms per 10^6 variants)\n", what, ms, ms / mv); };
+    for (int wgs : {num_cu, 2 * num_cu})
+      for (int ring : {8, 8})
+        line((std::string("ring alone, ") + std::to_string(wgs) + " workgroups").c_str(),
+             time_ms(0, reps, [&] { CK(launch_pack_kbits_ring(x, ld, v, n, k1[1], flag, 0, nblk, wgs, ring)); }));
+    for (int ring : {8, 8}) {
+      if (g_aln_alone) break;
+      double best = 1e30, bp = 0, bg = 0;
+      for (int round = 0; round < 3; ++round) {
+        CK(hipDeviceSynchronize());
+        const double t0 = now_ms();
+        for (int k = 0; k < K; ++k) {
+          const int b = k & 1;
+          if (k >= 2) CK(hipStreamWaitEvent(ps, consumed[b], 0));
+          if (k >= 1) hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, ps, (long long)10 * 100);
+          CK(hipEventRecord(pe[k][0], ps));
+          CK(launch_pack_kbits_ring(x, ld, v, n, k1[b], flag, ps, nblk, 2 * num_cu, ring));
+          CK(hipEventRecord(pe[k][1], ps));
+          CK(hipEventRecord(packed[b], ps));
+          CK(hipStreamWaitEvent(gs, packed[b], 0));
+          CK(hipEventRecord(ge[k][0], gs));
+          g_kbits_variant = 5;
+          CK(launch_gram_kbits(k1[b], v, n, sb, num_cu, gs, 2));
+          g_kbits_variant = 0;
+          CK(hipEventRecord(ge[k][1], gs));
+          CK(hipEventRecord(consumed[b], gs));
+        }
+        CK(hipDeviceSynchronize());
+        const double t = (now_ms() - t0) / K;
+        double sp = 0, sg = 0;
+        for (int k = 2; k < K - 1; ++k) {
+          float a = 0, c = 0;
+          CK(hipEventElapsedTime(&a, pe[k][0], pe[k][1]));
+          CK(hipEventElapsedTime(&c, ge[k][0], ge[k][1]));
+          sp += a; sg += c;
+        }
+        if (t < best) { best = t; bp = sp / (K - 3); bg = sg / (K - 3); }
+      }
+      std::printf("pipe  CO-RESIDENT %-28s 512 wgs || lock-step: %8.3f ms per step (%.0f M variants/s); pre-pass %.3f, contraction %.3f\n",
+                  "ring pre-pass", best, v / best / 1e3, bp, bg);
+    }
+    CK(hipFree(x));
+  }
+  std::printf("%s\n", bad ? "RESULT: FAILED" : "RESULT: ok");
+  return bad ? 1 : 0;
+}
+
 // ---- --coreside-alt (r03zd): the uint8 and bitset boundaries with their pre-pass beside the contraction -------------------------
 static int u8_ring_case(int n, int64_t v, int64_t ld8, uint32_t thr, int wgs, unsigned long long* cnt, int32_t* flag) {
   const int npad = (int)gram_packed_npad(n);
@@ -723,7 +820,7 @@ static int coreside_alt_main(int n, int64_t v, int reps, int num_cu, unsigned lo
 
 int main(int argc, char** argv) {
   int n = 2504, reps = 5;
-  bool pipe_study = false, coreside = false, coreside_alt = false;
+  bool pipe_study = false, coreside = false, coreside_alt = false, aln = false;
   int64_t v = (int64_t)1 << 20;
   for (int i = 1; i < argc; ++i) {
     if (!std::strcmp(argv[i], "--n") && i + 1 < argc) n = std::atoi(argv[++i]);
@@ -732,6 +829,11 @@ int main(int argc, char** argv) {
     if (!std::strcmp(argv[i], "--pipe-study")) pipe_study = true;
     if (!std::strcmp(argv[i], "--coreside")) coreside = true;
     if (!std::strcmp(argv[i], "--coreside-alt")) coreside_alt = true;
+    if (!std::strcmp(argv[i], "--aln")) aln = true;
+    if (!std::strcmp(argv[i], "--alone")) g_aln_alone = true;
+    if (!std::strcmp(argv[i], "--lds") && i + 1 < argc) {
+      for (char* t = std::strtok(argv[++i], ","); t; t = std::strtok(nullptr, ",")) g_aln_lds.push_back(std::atoll(t));
+    }
   }
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
@@ -743,6 +845,7 @@ int main(int argc, char** argv) {
   if (pipe_study) return pipe_study_main(n, v, reps, num_cu);
   if (coreside) return coreside_main(n, v, reps, num_cu, cnt);
   if (coreside_alt) return coreside_alt_main(n, v, reps, num_cu, cnt);
+  if (aln) return aln_main(n, v, reps, num_cu, cnt);
   int bad = 0;
   bad += small_case(1000, 777, 1003, 0x30000000u, num_cu, cnt);   // odd stride: generic paths
   bad += small_case(1000, 4100, 1000, 0x08000000u, num_cu, cnt);  // vector paths, several blocks

@@ -72,6 +72,18 @@ for s in $STEPS; do
       find $OUT/prof -name "*kernel_stats*" | head -3 | while read f; do echo "--- $f"; head -25 "$f" | cut -c1-220; done | tee -a $OUT/summary.txt
       # keep the merge-back small: drop the raw per-dispatch trace if it is large
       find $OUT/prof -name "*kernel_trace*" -size +8M -delete ;;
+    pmclive)
+      # live HBM traffic of the k-bits kernels of THIS tree -> $OUT/gram_pmc_live.json (copy to profiles/): the pipeline's
+      # kernels and the serial order's, FETCH_SIZE and WRITE_SIZE in their own passes (they do not fit one)
+      for tag in pipe serial; do
+        for c in FETCH_SIZE WRITE_SIZE; do
+          env=""; [ $tag = serial ] && env="PCOA_PIPELINE=0"
+          ( cd /tmp && env $env timeout 600 rocprofv3 --pmc $c --output-format csv -d $OLDPWD/$OUT/pmclive_${tag}_$c -o pmc -- python $OLDPWD/bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --pcoa-reps 1 > $OLDPWD/$OUT/pmclive_${tag}_$c.json 2> $OLDPWD/$OUT/pmclive_${tag}_$c.err )
+          echo "pmclive $tag $c exit $?" | tee -a $OUT/summary.txt
+        done
+      done
+      python tools/pmc_live.py $OUT | tee -a $OUT/summary.txt
+      find $OUT -name "*counter_collection*" -size +4M -delete ;;
     pmc)
       ( cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OLDPWD/$OUT/pmc_fetch -o pmc -- python $OLDPWD/bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --pcoa-reps 1 > /dev/null 2> $OLDPWD/$OUT/pmc_fetch.err )
       echo "pmc fetch exit $?" | tee -a $OUT/summary.txt
