@@ -307,7 +307,10 @@ def main():
         gram_cus = info.get("pipeline_contraction_cus", cus) if pipe else cus
         if kind == 3 and kbits:
             tile, peak = 256, PEAK_FP4_MFMA_TFLOPS
-            kname = "gram_kbits_kernel<3, 2, 2> (k-bits operand expanded to MX-FP4 in registers, ping-pong; %s launch)" % (
+            w4_name = bool(not (bool(info.get("pipeline")) and info.get("co_resident")) and os.environ.get("PCOA_KBITS_W4", "1") != "0")
+            kname = "%s (k-bits operand expanded to MX-FP4 in registers; %s launch)" % (
+                "gram_kbits_w4_kernel<4, 0, 69> (one wave per SIMD, hand-placed pipeline)" if w4_name else
+                "gram_kbits_kernel<3, 2, 2> (two waves per SIMD, ping-pong)",
                 "even-split" if info.get("even_split") else "lock-step" if info.get("lockstep") else "split-K")
             kdesc = ("pack fp32->k-bits (1 bit per genotype, HBM-bound, verifies values are 0/1) + MX-FP4 MFMA "
                      "v_mfma_f32_32x32x64_f8f6f4 (unscaled form, exact) fed from bit words expanded in registers (0.5 x 2.0 "
@@ -326,12 +329,17 @@ def main():
         else:
             tile, peak, kname = 128, PEAK_FP32_MFMA_TFLOPS, "gram_f32_kernel"
             kdesc = "fp32 MFMA v_mfma_f32_32x32x2_f32, upper-triangular 128x128 tiles, split-K"
-        frac_issued = issued_fraction(n, tile, idle_diag=(kind != 1 or True))
+        # which k-bits contraction ran: beside the ring pre-pass the two-waves-per-SIMD kernel (one idle wave pair per diagonal
+        # tile), everywhere else gram_kbits_w4_kernel (wave roles on diagonal tiles) unless PCOA_KBITS_W4=0
+        w4_ran = bool(kind == 3 and kbits and not (pipe and info.get("co_resident")) and os.environ.get("PCOA_KBITS_W4", "1") != "0")
+        frac_issued = issued_fraction(n, tile, diag=w4_diag_share() if w4_ran else None)
         issued = achieved * frac_issued
         roof_gram = {"bound": "mfma", "achieved": issued, "peak": peak, "unit": "TFLOP/s", "frac": issued / peak,
                      "convention": "ISSUED matrix-core work: only upper-triangular tiles are computed and the below-diagonal "
                                    "waves of diagonal tiles issue nothing (%.3f of the 2*V*N^2 of SURVEY 8d)" % frac_issued,
                      "algorithmic_tflops": achieved, "algorithmic_frac": achieved / peak,
+                     "useful_frac": achieved * useful_fraction(n) / peak,
+                     "useful_note": "the upper triangle with its diagonal, V*N*(N+1) flops: what S = X^T X needs at all",
                      "algorithmic_note": "2*V*N^2 per launch / launch duration (both triangles credited: can exceed 1)",
                      "cus_used": gram_cus, "frac_of_cus_used": issued / (peak * gram_cus / float(cus)),
                      # PMC traffic is stored per 10^6 variants and scaled to this run's average launch, like `achieved`
@@ -457,6 +465,8 @@ def main():
             ps = ts["pack_seconds"] / max(int(ts["pack_launches"]), 1)
             gs = ts["gram_kernel_seconds"] / max(int(ts["gram_kernel_launches"]), 1)
             gv = ts["gram_variants"] / max(int(ts["gram_kernel_launches"]), 1)
+            alone_w4 = os.environ.get("PCOA_KBITS_W4", "1") != "0"
+            alone_diag = w4_diag_share() if alone_w4 else 0.75
             out["roofline_standalone"] = {
                 "note": "pre-pass and contraction without the pipeline (PCOA_FLAG_NO_PIPELINE engine, 3 steps): each alone on all "
                         "%d CUs -- the pre-pass as pack_kbits_kernel (the ring form only runs beside a contraction; alone the two "
@@ -467,9 +477,16 @@ def main():
                              "unit": "GB/s", "frac": 4.0 * vs * n / ps / 1e9 / PEAK_HBM_GBS,
                              "bytes_convention": "SURVEY 8(d): 4*V*N bytes of X read once per launch"},
                 "contraction": {"bound": "mfma", "avg_launch_ms": 1e3 * gs, "unit": "TFLOP/s", "peak": PEAK_FP4_MFMA_TFLOPS,
-                                "achieved": 2.0 * gv * n * n / gs / 1e12 * issued_fraction(n, 256),
-                                "frac": 2.0 * gv * n * n / gs / 1e12 * issued_fraction(n, 256) / PEAK_FP4_MFMA_TFLOPS,
-                                "convention": "issued matrix-core work", "variants_per_launch": gv}}
+                                "achieved": 2.0 * gv * n * n / gs / 1e12 * issued_fraction(n, 256, diag=alone_diag),
+                                "frac": 2.0 * gv * n * n / gs / 1e12 * issued_fraction(n, 256, diag=alone_diag) / PEAK_FP4_MFMA_TFLOPS,
+                                "useful_frac": 2.0 * gv * n * n / gs / 1e12 * useful_fraction(n) / PEAK_FP4_MFMA_TFLOPS,
+                                "algorithmic_frac": 2.0 * gv * n * n / gs / 1e12 / PEAK_FP4_MFMA_TFLOPS,
+                                "convention": "frac = ISSUED matrix-core work (%.4f of 2*V*N^2: upper-triangular 256 x 256 tiles, %.4f of the "
+                                              "MFMAs of a diagonal tile); useful_frac = V*N*(N+1) (the upper triangle itself, %.4f); "
+                                              "algorithmic_frac = SURVEY 8(d)'s 2*V*N^2" % (
+                                                  issued_fraction(n, 256, diag=alone_diag), alone_diag, useful_fraction(n)),
+                                "kernel": "gram_kbits_w4_kernel<4, 0, 69>" if alone_w4 else "gram_kbits_kernel<3, 2, 2>",
+                                "variants_per_launch": gv}}
             pmc_alone, pmc_alone_src = pmc_for("kbits_standalone")
             for k2, fld, per in (("pre_pass", "pack_hbm_bytes_per_mvariants", vs), ("contraction", "gram_hbm_bytes_per_mvariants", gv)):
                 out["roofline_standalone"][k2]["traffic"] = pmc_alone[fld] * per / 1e6 if fld in pmc_alone else None
@@ -761,13 +778,26 @@ def csr_boundary(P, torch, dev, local_rank, n, x1, s_dense_steps, steps, operand
     return res
 
 
-def issued_fraction(n, bm, idle_diag=True):
+def issued_fraction(n, bm, idle_diag=True, diag=None):
     """Share of the 2*V*N^2 of SURVEY 8(d) the Gram kernels issue on the matrix cores: upper-triangular tiles only,
     and in a diagonal tile the waves that lie wholly below the diagonal skip their MFMAs (2 of 8 waves of a
-    256 x 256 tile: 0.75 of it; 1 of 4 waves of a 128 x 128 tile of the fp32 kernel)."""
+    256 x 256 tile: 0.75 of it; 1 of 4 waves of a 128 x 128 tile of the fp32 kernel).  diag: the share of a diagonal
+    tile's MFMAs that is issued, where the kernel is more selective (gram_kbits_w4_kernel, r04: 36 of 64 MFMA tiles)."""
     t = (n + bm - 1) // bm
-    diag = 0.75 if idle_diag else 1.0
+    if diag is None:
+        diag = 0.75 if idle_diag else 1.0
     return (t * (t - 1) / 2.0 + t * diag) / float(t * t)
+
+
+def w4_diag_share():
+    """gram_kbits_w4_kernel on a diagonal 256 x 256 tile: with wave roles (default) the two blocks on the diagonal issue 10 of
+    their 16 MFMA tiles and the block above it all 16 -- 36 of 64; PCOA_KBITS_W4_DIAG=0 (r04a form): 48 of 64."""
+    return 0.75 if os.environ.get("PCOA_KBITS_W4_DIAG", "-1") == "0" else 36.0 / 64.0
+
+
+def useful_fraction(n):
+    """Share of 2*V*N^2 that S = X^T X needs at all: the upper triangle with its diagonal, V*N*(N+1)."""
+    return (n + 1.0) / (2.0 * n)
 
 
 if __name__ == "__main__":

@@ -245,7 +245,14 @@ int pcoa_accumulate_calls_ex(pcoa_ctx* ctx, const int32_t* sample_idx, const int
  * pointer (is_device_ptr = 0; staged through pinned memory) or a device pointer (is_device_ptr = 1;
  * read in place, must stay valid until the next synchronising call).  ld >= N.
  * Replaces: the same mapPartitions body, with the RDD partition materialised as a matrix tile
- * (BASELINE.json configs[1]: "2,504 samples x 1M variants fp32"). */
+ * (BASELINE.json configs[1]: "2,504 samples x 1M variants fp32").
+ * Rates: a tile of 0 / 1 values runs the pipelined k-bits / MX-FP4 path.  A tile that holds carrier multiplicities
+ * 2..127 (not produced by the reference's call extraction: hasVariation is a boolean) takes the int8 path, which is NOT
+ * pipelined -- its pre-pass (one byte per genotype, 8x the operand bytes) and its contraction (int8 MFMA: half the MX-FP4
+ * rate) run in series on the ctx stream -- at about half the rate of a binary tile (225 vs 480 M variants/s for fp32
+ * tiles at N = 2504), and in the auto mode the tile is read twice (the binary pre-pass finds the multiplicity first).
+ * Any ld >= N that keeps rows 16-byte aligned (ld % 4 == 0) takes the fast pre-pass; the pitch needs no padding to
+ * 128-byte lines (measured: profiles/r04y_ring_pitch_sweep.txt). */
 int pcoa_accumulate_dense_f32(pcoa_ctx* ctx, const float* x, int64_t n_variants, int64_t ld,
                               int is_device_ptr);
 

@@ -524,6 +524,7 @@ __global__ __launch_bounds__(256) void densify_csr_kbits_kernel(const int32_t* _
     const int32_t c = idx[q];
     if (c < 0 || c >= n) {
       atomicOr(flag, 1);
+      flag[2] = c;  // one of the offending indices, for the error message (every flag buffer has >= 4 words)
       continue;
     }
     // (a carrier list that names a callset twice finds its bit already set: flag bit 5 -- the host then redoes the chunk on

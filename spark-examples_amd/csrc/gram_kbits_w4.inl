@@ -28,6 +28,23 @@ struct FragsW4 {
   i32x4 b[4];
 };
 
+// ROLE of a wave in a run (wave-uniform, chosen per tile):
+//   0 FULL  all 16 MFMA tiles of its 128 x 128 block (off-diagonal workgroup tiles, strip owners);
+//   1 DIAG  a block ON the diagonal: the 10 MFMA tiles with mi <= ni (the other 6 mirror them);
+//   2 / 3 HALF  the one block of a diagonal workgroup tile that lies above the diagonal is shared by the two waves that are
+//         not on it: column tiles ni < 2 / ni >= 2 of it, 8 MFMAs each (the wave below the diagonal used to idle);
+//   4 IDLE  (r04a form, kept for the harness) its share of the DMA and of the barriers, nothing else.
+// A diagonal workgroup tile then costs 10 MFMA slots per k-step instead of 16 (10 of 55 tiles at N = 2504).
+template <int ROLE, int T>
+constexpr bool w4_has_mfma() {
+  constexpr int mi = T / 4, ni = T % 4;
+  return ROLE == 0 ? true : ROLE == 1 ? (mi <= ni) : ROLE == 2 ? (ni < 2) : ROLE == 3 ? (ni >= 2) : false;
+}
+template <int ROLE, int G>
+constexpr bool w4_needs_b() {  // B fragment G (column tile G) is read by some MFMA of the role
+  return ROLE == 2 ? (G < 2) : ROLE == 3 ? (G >= 2) : true;
+}
+
 // MFMA T of a k-step: (mi, ni) = (T / 4, T % 4).  NOP wait states inside the statement, where nothing can be scheduled
 // between the pad and the instruction.  (gram_kbits.inl pads every MFMA: its late expansions write registers an MFMA issued
 // a cycle later may still read.  Here nothing an MFMA reads is written within 16 MFMAs of it and the accumulators are AGPRs no
@@ -104,16 +121,19 @@ __device__ __forceinline__ void w4_pin_in(u32x4 (&raw)[4]) {
   else if constexpr (j == 1) asm volatile("" : "+v"(raw[g >> 1]), "+v"(raw[2 + (g >> 1)]));
   else asm volatile("" : "+v"(raw[2 + (g >> 1)]));
 }
-template <int T>
+template <int T, int ROLE = 0>
 __device__ __forceinline__ void w4_pin_out(FragsW4& nf) {
   constexpr int g = T / 4, j = T % 4;
+  constexpr bool nb = w4_needs_b<ROLE, g>();
   if constexpr (j == 0) asm volatile("" : "+v"(nf.a[g]));
-  else if constexpr (j == 1) asm volatile("" : "+v"(nf.a[g]), "+v"(nf.b[g]));
-  else asm volatile("" : "+v"(nf.b[g]));
+  else if constexpr (j == 1 && nb) asm volatile("" : "+v"(nf.a[g]), "+v"(nf.b[g]));
+  else if constexpr (j == 1) asm volatile("" : "+v"(nf.a[g]));
+  else if constexpr (nb) asm volatile("" : "+v"(nf.b[g]));
 }
-template <int T, int WORD>
+template <int T, int WORD, int ROLE = 0>
 __device__ __forceinline__ void w4_ops(const u32x4 (&raw)[4], FragsW4& nf) {
   constexpr int g = T / 4, j = T % 4;
+  constexpr bool nb = w4_needs_b<ROLE, g>();
   const uint32_t wa = w4_word<g, WORD>(raw), wb = w4_word<4 + g, WORD>(raw);
   if constexpr (j == 0) {
     nf.a[g][0] = (int)(wa & 0x11111111u);
@@ -121,19 +141,21 @@ __device__ __forceinline__ void w4_ops(const u32x4 (&raw)[4], FragsW4& nf) {
     nf.a[g][2] = (int)(wa & 0x44444444u);
   } else if constexpr (j == 1) {
     nf.a[g][3] = (int)((wa >> 1) & 0x44444444u);
-    nf.b[g][1] = (int)(wb & 0x22222222u);
+    if constexpr (nb) nf.b[g][1] = (int)(wb & 0x22222222u);
   } else if constexpr (j == 2) {
-    nf.b[g][0] = (int)((wb << 2) & 0x44444444u);
-    nf.b[g][2] = (int)((wb >> 2) & 0x11111111u);
+    if constexpr (nb) {
+      nf.b[g][0] = (int)((wb << 2) & 0x44444444u);
+      nf.b[g][2] = (int)((wb >> 2) & 0x11111111u);
+    }
   } else {
-    nf.b[g][3] = (int)((wb >> 3) & 0x11111111u);
+    if constexpr (nb) nf.b[g][3] = (int)((wb >> 3) & 0x11111111u);
   }
 }
-template <int T, int WORD>
+template <int T, int WORD, int ROLE = 0>
 __device__ __forceinline__ void w4_gap(u32x4 (&raw)[4], FragsW4& nf) {
   w4_pin_in<T>(raw);
-  w4_ops<T, WORD>(raw, nf);
-  w4_pin_out<T>(nf);
+  w4_ops<T, WORD, ROLE>(raw, nf);
+  w4_pin_out<T, ROLE>(nf);
 }
 
 // One statement that reads and "redefines" all eight fragments of a buffer: it keeps the buffer's live range unbroken across
@@ -145,12 +167,12 @@ __device__ __forceinline__ void w4_tie(FragsW4& f) {
 }
 
 // all eight fragments of one k-step at once (prologue of a run: nothing to hide behind)
-template <int WORD>
+template <int WORD, int ROLE = 0>
 __device__ __forceinline__ void w4_expand_all(u32x4 (&raw)[4], FragsW4& nf) {
-  w4_gap<0, WORD>(raw, nf);  w4_gap<1, WORD>(raw, nf);  w4_gap<2, WORD>(raw, nf);  w4_gap<3, WORD>(raw, nf);
-  w4_gap<4, WORD>(raw, nf);  w4_gap<5, WORD>(raw, nf);  w4_gap<6, WORD>(raw, nf);  w4_gap<7, WORD>(raw, nf);
-  w4_gap<8, WORD>(raw, nf);  w4_gap<9, WORD>(raw, nf);  w4_gap<10, WORD>(raw, nf); w4_gap<11, WORD>(raw, nf);
-  w4_gap<12, WORD>(raw, nf); w4_gap<13, WORD>(raw, nf); w4_gap<14, WORD>(raw, nf); w4_gap<15, WORD>(raw, nf);
+  w4_gap<0, WORD, ROLE>(raw, nf);  w4_gap<1, WORD, ROLE>(raw, nf);  w4_gap<2, WORD, ROLE>(raw, nf);  w4_gap<3, WORD, ROLE>(raw, nf);
+  w4_gap<4, WORD, ROLE>(raw, nf);  w4_gap<5, WORD, ROLE>(raw, nf);  w4_gap<6, WORD, ROLE>(raw, nf);  w4_gap<7, WORD, ROLE>(raw, nf);
+  w4_gap<8, WORD, ROLE>(raw, nf);  w4_gap<9, WORD, ROLE>(raw, nf);  w4_gap<10, WORD, ROLE>(raw, nf); w4_gap<11, WORD, ROLE>(raw, nf);
+  w4_gap<12, WORD, ROLE>(raw, nf); w4_gap<13, WORD, ROLE>(raw, nf); w4_gap<14, WORD, ROLE>(raw, nf); w4_gap<15, WORD, ROLE>(raw, nf);
 }
 
 // raw[Q] of a slot: rows 2Q and 2Q+1 (512 bytes apart) by one ds_read2_b64.  As asm statements: the compiler's wait-count
@@ -211,25 +233,25 @@ __device__ __forceinline__ void w4_issue(StageBits* lds, W4Run<NST>& run, int wa
 #define W4_STEP(T_, K_, W_, P_)                                                                        \
   do {                                                                                                 \
     if constexpr (!(DBG & 1) && (OPT & 2) && !(OPT & 88)) w4_pin_in<T_>(raw[P_]);                      \
-    if constexpr (!(DBG & 16)) w4_mfma<T_, NOP>(f[K_]);                                           \
+    if constexpr (!(DBG & 16) && w4_has_mfma<ROLE, T_>()) w4_mfma<T_, NOP>(f[K_]);                     \
     if constexpr (!(DBG & 1)) {                                                                        \
       if constexpr (OPT & 88) __builtin_amdgcn_sched_barrier(0);                                       \
       if constexpr ((OPT & 16) && (T_) < 15) w4_pin_in<((T_) < 15 ? (T_) + 1 : 15)>(raw[P_]);          \
       if constexpr (!(OPT & 2) && !(OPT & 88)) w4_pin_in<T_>(raw[P_]);                                 \
-      w4_ops<T_, W_>(raw[P_], f[(K_) ^ 1]);                                                            \
+      w4_ops<T_, W_, ROLE>(raw[P_], f[(K_) ^ 1]);                                                      \
       if constexpr (OPT & 8) __builtin_amdgcn_sched_barrier(0);                                        \
-      else w4_pin_out<T_>(f[(K_) ^ 1]);                                                                \
+      else w4_pin_out<T_, ROLE>(f[(K_) ^ 1]);                                                          \
     }                                                                                                  \
   } while (0)
 #define W4_READ(Q_) do { if constexpr (!(DBG & 4)) w4_read<Q_>(run.addr_a[NSLOT], run.addr_b[NSLOT], raw[PAR ^ 1]); } while (0)
 // One stage.  Entry: f[0] = fragments of (stage s, k-step 0); raw[PAR] = words of stage s; this wave's DMA is issued through
 // stage s + NST - 1.  Exit: the same for stage s + 1 with PAR flipped.
-template <int NST, int SLOT, int PAR, bool DIAG, bool IDLE, int NOP, int OPT, int DBG>
+template <int NST, int SLOT, int PAR, bool DIAG, int ROLE, int NOP, int OPT, int DBG>
 __device__ __forceinline__ void w4_stage(StageBits* lds, W4Run<NST>& run, int wave, FragsW4 (&f)[2],
                                          u32x4 (&raw)[2][4]) {
   constexpr int PER = DIAG ? 1 : 2;
   constexpr int NSLOT = (SLOT + 1) % NST;
-  if constexpr (IDLE) {
+  if constexpr (ROLE == 4) {
     if constexpr (!(DBG & 8)) wait_vmcnt<PER * (NST - 2)>();
     if constexpr (!(DBG & 2)) raw_barrier();
     if constexpr (!(DBG & 8)) w4_issue<NST, SLOT, DIAG, OPT>(lds, run, wave);
@@ -239,15 +261,15 @@ __device__ __forceinline__ void w4_stage(StageBits* lds, W4Run<NST>& run, int wa
   //      fragments of k-step 1 (word 1 of raw[PAR] -> f[1])
   if constexpr (!(DBG & 1) && (OPT & 2) && !(OPT & 88)) w4_pin_in<0>(raw[PAR]);
   if constexpr (!(DBG & 1) && (OPT & 32)) w4_tie(f[1]);
-  if constexpr (!(DBG & 16)) w4_mfma<0, NOP>(f[0]);
+  if constexpr (!(DBG & 16) && w4_has_mfma<ROLE, 0>()) w4_mfma<0, NOP>(f[0]);
   if constexpr (!(DBG & 8)) wait_vmcnt<PER * (NST - 2)>();  // my share of stage s+1 has landed
   if constexpr (!(DBG & 2)) raw_barrier();  // everybody's has; everybody holds the words of stage s in registers
   if constexpr (!(DBG & 1)) {
     if constexpr (OPT & 16) w4_pin_in<1>(raw[PAR]);
     if constexpr (!(OPT & 2) && !(OPT & 88)) w4_pin_in<0>(raw[PAR]);
-    w4_ops<0, 1>(raw[PAR], f[1]);
+    w4_ops<0, 1, ROLE>(raw[PAR], f[1]);
     if constexpr (OPT & 8) __builtin_amdgcn_sched_barrier(0);
-    else w4_pin_out<0>(f[1]);
+    else w4_pin_out<0, ROLE>(f[1]);
   }
   W4_STEP(1, 0, 1, PAR);
   W4_READ(0);
@@ -304,10 +326,10 @@ __device__ __forceinline__ void w4_stage(StageBits* lds, W4Run<NST>& run, int wa
 #undef W4_STEP
 #undef W4_READ
 
-template <int NST, bool DIAG, bool IDLE, int NOP, int OPT, int DBG, int... Is>
+template <int NST, bool DIAG, int ROLE, int NOP, int OPT, int DBG, int... Is>
 __device__ __forceinline__ void w4_round(StageBits* lds, W4Run<NST>& run, int count, int wave,
                                          FragsW4 (&f)[2], u32x4 (&raw)[2][4], std::integer_sequence<int, Is...>) {
-  ((Is < count ? w4_stage<NST, Is % NST, Is & 1, DIAG, IDLE, NOP, OPT, DBG>(lds, run, wave, f, raw) : (void)0), ...);
+  ((Is < count ? w4_stage<NST, Is % NST, Is & 1, DIAG, ROLE, NOP, OPT, DBG>(lds, run, wave, f, raw) : (void)0), ...);
 }
 
 template <int NST, bool DIAG, int OPT, int I = 0>
@@ -319,7 +341,7 @@ __device__ __forceinline__ void w4_prologue_issue(StageBits* lds, W4Run<NST>& ru
 }
 
 // One run of `ns` stages of one tile, starting at block `first` (pointer to its first byte).
-template <int NST, bool DIAG, bool IDLE, int NOP, int OPT, int DBG>
+template <int NST, bool DIAG, int ROLE, int NOP, int OPT, int DBG>
 __device__ __forceinline__ void w4_loop(StageBits* lds, W4Run<NST>& run, const int8_t* first, int ns, int wave) {
   static_assert(NST % 2 == 0, "the raw-word parity of a slot must be a compile-time constant");
   constexpr int PER = DIAG ? 1 : 2;
@@ -334,20 +356,20 @@ __device__ __forceinline__ void w4_loop(StageBits* lds, W4Run<NST>& run, const i
   w4_prologue_issue<NST, DIAG, OPT>(lds, run, wave);
   wait_vmcnt<PER * (NST - 1)>();  // stage 0
   raw_barrier();
-  if constexpr (!IDLE) {
+  if constexpr (ROLE != 4) {
     w4_read<0>(run.addr_a[0], run.addr_b[0], raw[0]);
     w4_read<1>(run.addr_a[0], run.addr_b[0], raw[0]);
     w4_read<2>(run.addr_a[0], run.addr_b[0], raw[0]);
     w4_read<3>(run.addr_a[0], run.addr_b[0], raw[0]);
     w4_wait_words(raw[0]);
-    w4_expand_all<0>(raw[0], f[0]);
+    w4_expand_all<0, ROLE>(raw[0], f[0]);
     asm volatile("s_nop 1");
   }
   int s = 0;
   for (; s + NST <= ns; s += NST)
-    w4_round<NST, DIAG, IDLE, NOP, OPT, DBG>(lds, run, NST, wave, f, raw, std::make_integer_sequence<int, NST>{});
+    w4_round<NST, DIAG, ROLE, NOP, OPT, DBG>(lds, run, NST, wave, f, raw, std::make_integer_sequence<int, NST>{});
   if (s < ns)
-    w4_round<NST, DIAG, IDLE, NOP, OPT, DBG>(lds, run, ns - s, wave, f, raw, std::make_integer_sequence<int, NST - 1>{});
+    w4_round<NST, DIAG, ROLE, NOP, OPT, DBG>(lds, run, ns - s, wave, f, raw, std::make_integer_sequence<int, NST - 1>{});
   // drain: the clamped DMAs still in flight write slots the next run's prologue re-uses, and the last stage's speculative
   // ds_reads (words of a stage beyond the run, never used) must have returned before their registers are re-used
   wait_vmcnt<0>();
@@ -379,7 +401,7 @@ __device__ __forceinline__ void w4_store_tuple(const int32_t* rowbase, uint32_t 
                                                bool sym, int jend, int hi, std::integer_sequence<int, Rs...>) {
   (w4_store_elem<MASKED, MI, NI, Rs>(rowbase, voff, ld4, i0, jj, jorg, n, sym, jend, hi), ...);
 }
-template <bool MASKED, int MI>
+template <bool MASKED, int MI, int ROLE>
 __device__ __forceinline__ void w4_store_rows(int32_t* s32, int64_t ld, uint32_t voff0, int i0, int j0, int jorg, int n, bool sym,
                                               int jend, int l31, int hi) {
   const uint64_t a = (uint64_t)(uintptr_t)(s32 + (int64_t)(i0 + MI * 32) * ld + (j0 - jorg));
@@ -387,19 +409,20 @@ __device__ __forceinline__ void w4_store_rows(int32_t* s32, int64_t ld, uint32_t
   const int32_t* rowbase = reinterpret_cast<const int32_t*>(((uint64_t)up << 32) | lo);
   const uint32_t ld4 = (uint32_t)ld * 4u;
   constexpr std::make_integer_sequence<int, 16> rs{};
-  w4_store_tuple<MASKED, MI, 0>(rowbase, voff0, ld4, i0, j0 + l31, jorg, n, sym, jend, hi, rs);
-  w4_store_tuple<MASKED, MI, 1>(rowbase, voff0, ld4, i0, j0 + 32 + l31, jorg, n, sym, jend, hi, rs);
-  w4_store_tuple<MASKED, MI, 2>(rowbase, voff0, ld4, i0, j0 + 64 + l31, jorg, n, sym, jend, hi, rs);
-  w4_store_tuple<MASKED, MI, 3>(rowbase, voff0, ld4, i0, j0 + 96 + l31, jorg, n, sym, jend, hi, rs);
+  // only the tiles the role computed (the accumulators of the others hold zeros)
+  if constexpr (w4_has_mfma<ROLE, 4 * MI + 0>()) w4_store_tuple<MASKED, MI, 0>(rowbase, voff0, ld4, i0, j0 + l31, jorg, n, sym, jend, hi, rs);
+  if constexpr (w4_has_mfma<ROLE, 4 * MI + 1>()) w4_store_tuple<MASKED, MI, 1>(rowbase, voff0, ld4, i0, j0 + 32 + l31, jorg, n, sym, jend, hi, rs);
+  if constexpr (w4_has_mfma<ROLE, 4 * MI + 2>()) w4_store_tuple<MASKED, MI, 2>(rowbase, voff0, ld4, i0, j0 + 64 + l31, jorg, n, sym, jend, hi, rs);
+  if constexpr (w4_has_mfma<ROLE, 4 * MI + 3>()) w4_store_tuple<MASKED, MI, 3>(rowbase, voff0, ld4, i0, j0 + 96 + l31, jorg, n, sym, jend, hi, rs);
 }
-template <bool MASKED>
+template <bool MASKED, int ROLE = 0>
 __device__ __forceinline__ void w4_store(int32_t* s32, int64_t ld, int i0, int j0, int jorg, int n, bool sym, int jend, int l31,
                                          int hi) {
   const uint32_t voff0 = ((uint32_t)(4 * hi) * (uint32_t)ld + (uint32_t)l31) * 4u;
-  w4_store_rows<MASKED, 0>(s32, ld, voff0, i0, j0, jorg, n, sym, jend, l31, hi);
-  w4_store_rows<MASKED, 1>(s32, ld, voff0, i0, j0, jorg, n, sym, jend, l31, hi);
-  w4_store_rows<MASKED, 2>(s32, ld, voff0, i0, j0, jorg, n, sym, jend, l31, hi);
-  w4_store_rows<MASKED, 3>(s32, ld, voff0, i0, j0, jorg, n, sym, jend, l31, hi);
+  w4_store_rows<MASKED, 0, ROLE>(s32, ld, voff0, i0, j0, jorg, n, sym, jend, l31, hi);
+  w4_store_rows<MASKED, 1, ROLE>(s32, ld, voff0, i0, j0, jorg, n, sym, jend, l31, hi);
+  w4_store_rows<MASKED, 2, ROLE>(s32, ld, voff0, i0, j0, jorg, n, sym, jend, l31, hi);
+  w4_store_rows<MASKED, 3, ROLE>(s32, ld, voff0, i0, j0, jorg, n, sym, jend, l31, hi);
 }
 
 // Work decomposition and epilogue as gram_kbits_body (xcd_map 0 / 1 / 2 / 4); 256 x 256 workgroup tiles, a wave's block is
@@ -411,7 +434,7 @@ template <int NST, int NOP, int OPT, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void gram_kbits_w4_kernel(const int8_t* __restrict__ p, int npad, int64_t nstages, int n,
                                                                int ntile, int ntri, int splitk, int64_t stages_per,
                                                                int32_t* __restrict__ s32, int xcd_map,
-                                                               const int32_t* __restrict__ skip, GramStrip strip) {
+                                                               const int32_t* __restrict__ skip, GramStrip strip, int wdiag) {
   __shared__ __attribute__((aligned(16))) StageBits lds[NST];
   if (skip != nullptr && *skip != 0) return;
   const int lane = threadIdx.x & 63;
@@ -427,8 +450,30 @@ __global__ __launch_bounds__(256, 1) void gram_kbits_w4_kernel(const int8_t* __r
     const int64_t nwork = (int64_t)ntri * nstages;
     const int64_t nwg = gridDim.x;
     const int64_t slot = (nwg % kNumXcd == 0) ? (int64_t)(b & 7) * (nwg / kNumXcd) + (b >> 3) : (int64_t)b;
-    u = nwork * slot / nwg;
-    u_end = nwork * (slot + 1) / nwg;
+    if (wdiag > 0 && wdiag < 16 && strip.cols == 0 && ntile <= BAND) {
+      // a stage of a diagonal tile costs wdiag / 16 of a stage of any other (wave roles, w4_has_mfma): equal shares of the COST.
+      // Tiles are in row-major order here (tile_coords, one band) and the first tile of a row is the diagonal one.
+      auto unit_of = [&](int64_t x) -> int64_t {  // cost position -> tile * nstages + stage
+        int64_t t0 = 0;
+        for (int r = 0; r < ntile; ++r) {
+          const int64_t dspan = nstages * wdiag, fspan = nstages * 16, rspan = dspan + fspan * (ntile - r - 1);
+          if (x < rspan) {
+            if (x < dspan) return t0 * nstages + x / wdiag;
+            const int64_t y = x - dspan;
+            return (t0 + 1 + y / fspan) * nstages + (y % fspan) / 16;
+          }
+          x -= rspan;
+          t0 += ntile - r;
+        }
+        return nwork;
+      };
+      const int64_t cost = nstages * ((int64_t)ntile * wdiag + (int64_t)(ntri - ntile) * 16);
+      u = unit_of(cost * slot / nwg);
+      u_end = (slot + 1 == nwg) ? nwork : unit_of(cost * (slot + 1) / nwg);
+    } else {
+      u = nwork * slot / nwg;
+      u_end = nwork * (slot + 1) / nwg;
+    }
   } else {
     int tile, ks;
     if (xcd_map == 2) {
@@ -489,29 +534,49 @@ __global__ __launch_bounds__(256, 1) void gram_kbits_w4_kernel(const int8_t* __r
     // A diagonal tile runs the same code: panel J is panel I brought in a second time (10 of 55 tiles at N = 2504; the extra
     // 4 KiB per stage come out of the L1).  The wave whose block lies below the diagonal keeps its share of the DMA and of the
     // barriers and issues nothing else (the kernel is power-bound: MFMAs nobody needs cost clock).
-    const bool idle = row_blk == col_blk && strip.cols == 0 && wm > wn;
+    const bool diag_tile = row_blk == col_blk && strip.cols == 0;
+    // wave roles on a diagonal tile (w4_has_mfma): the two blocks on the diagonal compute their upper MFMA tiles, the block
+    // above it is shared by the other two waves -- the one below the diagonal takes the place of (wm, wn) = (0, 1) too
+    int role = 0, rm = wm, rn = wn;
+    if (diag_tile && wdiag > 0) {
+      role = (wm == wn) ? 1 : (wm < wn) ? 2 : 3;
+      if (wm != wn) { rm = 0; rn = 1; }
+    } else if (diag_tile && wm > wn) {
+      role = 4;
+    }
+    role = __builtin_amdgcn_readfirstlane(role);
+    if (wdiag > 0) {
+#pragma unroll
+      for (int q = 0; q < NST; ++q) {
+        run.addr_a[q] = lds0 + (uint32_t)(q * 8192 + (rm * 128 + l31) * 16 + hi * 8);
+        run.addr_b[q] = lds0 + (uint32_t)(q * 8192 + 4096 + (rn * 128 + l31) * 16 + hi * 8);
+      }
+    }
 
     run.off_i = (uint32_t)(col_i + wave * 64 + lane) * 16u;
     run.off_j = (uint32_t)(col_j + wave * 64 + lane) * 16u;
     const int8_t* first = p + ((DBG & 64) ? 0 : st_begin) * run.pitch;
     run.rem = __builtin_amdgcn_readfirstlane((int)(nstages - 1 - ((DBG & 64) ? 0 : st_begin)));
 
-    if (idle) {
-      w4_loop<NST, false, true, NOP, OPT, DBG>(lds, run, first, ns, wave);
-    } else {
-      w4_zero_acc();
-      w4_loop<NST, false, false, NOP, OPT, DBG>(lds, run, first, ns, wave);
-    }
+    if (role != 4) w4_zero_acc();
+    if (role == 0) w4_loop<NST, false, 0, NOP, OPT, DBG>(lds, run, first, ns, wave);
+    else if (role == 1) w4_loop<NST, false, 1, NOP, OPT, DBG>(lds, run, first, ns, wave);
+    else if (role == 2) w4_loop<NST, false, 2, NOP, OPT, DBG>(lds, run, first, ns, wave);
+    else if (role == 3) w4_loop<NST, false, 3, NOP, OPT, DBG>(lds, run, first, ns, wave);
+    else w4_loop<NST, false, 4, NOP, OPT, DBG>(lds, run, first, ns, wave);
 
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last asm MFMA -> read of D
-    if (!idle) {
-      const int i0 = col_i + wm * 128, j0 = col_j + wn * 128;
+    if (role != 4) {
+      const int i0 = col_i + rm * 128, j0 = col_j + rn * 128;
       const bool sym = strip.cols == 0;
       const int64_t ld = sym ? n : strip.cols;
       const int jorg = sym ? 0 : strip.col0, jend = sym ? n : strip.col0 + strip.cols;
       // inner: the whole tile inside the matrix and (symmetric job) above the diagonal / (strip) inside the strip's columns
       const bool inner = sym ? (col_j + 256 <= n && col_i + 256 <= col_j) : (col_i + 256 <= n && col_j >= jorg && col_j + 256 <= jend);
-      if (inner) w4_store<false>(s32, ld, i0, j0, jorg, n, sym, jend, l31, hi);
+      if (role == 1) w4_store<true, 1>(s32, ld, i0, j0, jorg, n, sym, jend, l31, hi);
+      else if (role == 2) w4_store<true, 2>(s32, ld, i0, j0, jorg, n, sym, jend, l31, hi);
+      else if (role == 3) w4_store<true, 3>(s32, ld, i0, j0, jorg, n, sym, jend, l31, hi);
+      else if (inner) w4_store<false>(s32, ld, i0, j0, jorg, n, sym, jend, l31, hi);
       else w4_store<true>(s32, ld, i0, j0, jorg, n, sym, jend, l31, hi);
     }
   }
@@ -534,8 +599,12 @@ int g_w4_variant = 0;  // harness knob
 #endif
 
 // Same contract as launch_gram_kbits (modes 0 / 2 / 4); 256-thread workgroups, one per CU.
+// wdiag: 0 = the r04a form of diagonal tiles (the wave below the diagonal idles); 1..15 = wave roles on diagonal tiles, and in
+// the even split a stage of a diagonal tile counts wdiag / 16 of another tile's; < 0 = the default (kW4DiagCost)
+constexpr int kW4DiagCost = 11;
 hipError_t launch_gram_kbits_w4(const int8_t* p, int64_t nv, int32_t n, int32_t* s32, int num_cu, hipStream_t stream, int mode,
-                                const int32_t* skip, GramStrip strip) {
+                                const int32_t* skip, GramStrip strip, int wdiag) {
+  if (wdiag < 0 || wdiag > 16) wdiag = kW4DiagCost;
   if (nv <= 0) return hipSuccess;
   const int cus = num_cu > 0 ? num_cu : 256;
   const int npad = (int)gram_packed_npad(n);
@@ -583,7 +652,7 @@ hipError_t launch_gram_kbits_w4(const int8_t* p, int64_t nv, int32_t n, int32_t*
   const dim3 grid((unsigned)nblocks), block(256);
 #define PCOA_LAUNCH_W4(NST_, NOP_, OPT_, DBG_)                                                                            \
   hipLaunchKernelGGL((gram_kbits_w4_kernel<NST_, NOP_, OPT_, DBG_>), grid, block, 0, stream, p, npad, nstages, n, ntile,   \
-                     ntri, (int)splitk, stages_per, s32, xcd_map, skip, strip)
+                     ntri, (int)splitk, stages_per, s32, xcd_map, skip, strip, wdiag)
 #ifdef PCOA_EXPERIMENTS
   switch (g_w4_variant) {
     case 1: PCOA_LAUNCH_W4(4, 0, 0, 0); break;   // builtin DMA, pins behind the MFMA

@@ -218,6 +218,7 @@ __global__ __launch_bounds__(256) void densify_csr_fp4_kernel(const int32_t* __r
     const int32_t c = idx[q];
     if (c < 0 || c >= n) {
       atomicOr(flag, 1);
+      flag[2] = c;  // one of the offending indices, for the error message (every flag buffer has >= 4 words)
       continue;
     }
     uint32_t* word = reinterpret_cast<uint32_t*>(p + ((size_t)kb * npad + c) * 16) + (t >> 3);

@@ -715,7 +715,7 @@ int fp4_launch(pcoa_ctx* c, int bi, bool overlapped, int side_kind = 1) {
       const int w4 = debug_knobs().kbits_w4;
       const bool use_w4 = w4 != 0 && (!(side && c->coreside) || w4 == 2);
       auto launch = [&](int m) {
-        return use_w4 ? launch_gram_kbits_w4(b.p, b.kb * 32, c->n, c->s32, cus, gs, m, skip, strip_of(c))
+        return use_w4 ? launch_gram_kbits_w4(b.p, b.kb * 32, c->n, c->s32, cus, gs, m, skip, strip_of(c), debug_knobs().kbits_w4_diag)
                       : launch_gram_kbits(b.p, b.kb * 32, c->n, c->s32, cus, gs, m, skip, strip_of(c));
       };
       e = launch(mode);
@@ -1231,6 +1231,7 @@ const DebugKnobs& debug_knobs() {
     if (const char* v = std::getenv("PCOA_PIPELINE")) k.pipeline = std::atoi(v) != 0;
     if (const char* v = std::getenv("PCOA_FORK_LAZY")) k.fork_lazy = std::atoi(v);
     if (const char* v = std::getenv("PCOA_HEADSTART_US")) k.headstart_us = std::atoi(v);
+    if (const char* v = std::getenv("PCOA_KBITS_W4_DIAG")) k.kbits_w4_diag = std::atoi(v);
     if (const char* v = std::getenv("PCOA_GRAM_LOCKSTEP")) k.lockstep = std::atoi(v) != 0;
     k.explicit_center = std::getenv("PCOA_EXPLICIT_CENTER") != nullptr;
     k.lanczos_first_check = (int)num("PCOA_LANCZOS_FIRST_CHECK");
@@ -1806,10 +1807,10 @@ int csr_validate(pcoa_ctx* c) {
   pcoa_ctx::Fp4Buf& b = c->fb[c->fb_active];
   hipStream_t s = b.fill_stream ? b.fill_stream : c->stream;
   const double t0 = wall_now();
-  HIP_TRY(c, hipMemcpyAsync(c->csr_flag_host, c->csr_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipMemcpyAsync(c->csr_flag_host, c->csr_flag, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
   c->csr_wait_s += wall_now() - t0;
-  const int32_t flag = c->csr_flag_host[0];
+  const int32_t flag = c->csr_flag_host[0], bad_index = c->csr_flag_host[2];
   std::vector<pcoa_ctx::CsrPending> pend;
   pend.swap(c->csr_pending);
   if (flag == 0) return PCOA_OK;
@@ -1818,11 +1819,14 @@ int csr_validate(pcoa_ctx* c) {
   for (const auto& q : pend) { kb += q.kb; vars += q.nv; }
   b.kb -= kb;
   b.vars -= vars;
-  HIP_TRY(c, hipMemsetAsync(c->csr_flag, 0, sizeof(int32_t), s));
+  HIP_TRY(c, hipMemsetAsync(c->csr_flag, 0, 4 * sizeof(int32_t), s));
   HIP_TRY(c, hipStreamSynchronize(s));
-  if (flag & 1)
-    return fail(c, PCOA_ERR_INDEX_RANGE, "a callset index outside [0, N) in a carrier list; S is unchanged by the calls "
-                                         "since the last synchronising call that reported no error");
+  if (flag & 1) {
+    char msg[256];
+    std::snprintf(msg, sizeof(msg), "callset index %d outside [0, %d) in a carrier list (found by the device-side check); S is "
+                  "unchanged by the calls since the last synchronising call that reported no error", bad_index, c->n);
+    return fail(c, PCOA_ERR_INDEX_RANGE, msg);
+  }
   if (c->packed_mode == 3)
     return fail(c, PCOA_ERR_INVALID_ARG,
                 "a carrier list repeats a callset (multiplicity > 1) and PCOA_FLAG_GRAM_FP4_MFMA was forced");

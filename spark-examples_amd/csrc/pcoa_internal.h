@@ -39,6 +39,7 @@ struct DebugKnobs {
   int symv_sym_min_n = 0;          // PCOA_SYMV_SYM_MIN_N: smallest N whose Lanczos mat-vec reads only the upper triangle of S (default 16384)
   int csr_legacy = 0;              // PCOA_CSR_LEGACY = 1: pcoa_accumulate_calls through the host-validated r03 path
   int kbits_w4 = -1;               // PCOA_KBITS_W4 = 0 | 1 | 2: one-wave-per-SIMD contraction (gram_kbits_w4.inl): 0 never, 1 wherever the kernel has its CUs to itself (default), 2 also beside the ring pre-pass
+  int kbits_w4_diag = -1;          // PCOA_KBITS_W4_DIAG: 0 = diagonal tiles as in r04a (one wave idles), 1..16 = wave roles on diagonal tiles with this cost (of 16) in the even split; default 11
   int kbits_coreside = -1;         // PCOA_KBITS_CORESIDE = 0 | 1: fp32 pipeline with pre-pass and contraction on the SAME CUs (ring pre-pass)
   int kbits_ring_prio = 0;         // PCOA_KBITS_RING_PRIO = 1: the ring pre-pass's waves at s_setprio 3 (harness knob)
   int kbits_ring_wgs = 0;          // PCOA_KBITS_RING_WGS: workgroups of the ring pre-pass beside a contraction (default 2 per CU)
@@ -120,7 +121,7 @@ hipError_t launch_gram_kbits(const int8_t* p, int64_t nv, int32_t n, int32_t* s3
                              const int32_t* skip = nullptr, GramStrip strip = GramStrip{});
 // the same contraction with one wave per SIMD and 128 x 128 wave tiles (gram_kbits_w4.inl); same modes
 hipError_t launch_gram_kbits_w4(const int8_t* p, int64_t nv, int32_t n, int32_t* s32, int num_cu, hipStream_t stream, int mode,
-                                const int32_t* skip = nullptr, GramStrip strip = GramStrip{});
+                                const int32_t* skip = nullptr, GramStrip strip = GramStrip{}, int wdiag = -1);
 int gram_lockstep_splitk(int32_t n, int cus);
 int gram_lockstep_workgroups(int32_t n, int splitk);
 hipError_t launch_gram_packed_lockstep(const int8_t* p, int fmt, int64_t nv, int32_t n, int32_t* s32, int num_cu,

@@ -92,6 +92,7 @@ int main(int argc, char** argv) {
   uint32_t thr = 0x14000000u;  // ~7.8 %
   std::vector<int> variants = {0, 1, 2, 3};
   std::vector<int> modes = {4, 2, 0};
+  std::vector<int> diags = {-1};
   for (int i = 1; i < argc; ++i) {
     if (!std::strcmp(argv[i], "--n") && i + 1 < argc) n = std::atoi(argv[++i]);
     if (!std::strcmp(argv[i], "--v") && i + 1 < argc) v = std::atoll(argv[++i]);
@@ -105,6 +106,10 @@ int main(int argc, char** argv) {
     if (!std::strcmp(argv[i], "--modes") && i + 1 < argc) {
       modes.clear();
       for (char* t = std::strtok(argv[++i], ","); t; t = std::strtok(nullptr, ",")) modes.push_back(std::atoi(t));
+    }
+    if (!std::strcmp(argv[i], "--diag") && i + 1 < argc) {
+      diags.clear();
+      for (char* t = std::strtok(argv[++i], ","); t; t = std::strtok(nullptr, ",")) diags.push_back(std::atoi(t));
     }
     if (!std::strcmp(argv[i], "--variants") && i + 1 < argc) {
       variants.clear();
@@ -147,21 +152,21 @@ int main(int argc, char** argv) {
       CK(launch_gram_kbits(k1, cv, cn, s_ref, num_cu, 0, ref_mode));
       CK(hipDeviceSynchronize());
     }
-    for (int var : variants) {
+    for (int var : variants) for (int wd : diags) {
       g_w4_variant = var;
       for (int mode : modes) {
         if (mode == 2 && gram_lockstep_splitk(cn, num_cu) == 0) continue;
         if (mode == 4 && ntri > 4 * num_cu) continue;
         if (!timeit && mode == 0 && cv > (1 << 16)) continue;
         CK(hipMemset(s_new, 0, (size_t)sbytes));
-        CK(launch_gram_kbits_w4(k1, cv, cn, s_new, num_cu, 0, mode));
+        CK(launch_gram_kbits_w4(k1, cv, cn, s_new, num_cu, 0, mode, nullptr, GramStrip{}, wd));
         CK(hipDeviceSynchronize());
         const unsigned long long d = count_diff(s_ref, s_new, sbytes, cnt);
         if (d && var < 100) ++fails;
         if (timeit) {
           unsigned long long zero4[4] = {0, 0, 0, 0};
           CK(hipMemcpyToSymbol(HIP_SYMBOL(g_w4_clk), zero4, sizeof(zero4)));
-          const float t = time_ms(reps, [&] { CK(launch_gram_kbits_w4(k1, cv, cn, s_new, num_cu, 0, mode)); });
+          const float t = time_ms(reps, [&] { CK(launch_gram_kbits_w4(k1, cv, cn, s_new, num_cu, 0, mode, nullptr, GramStrip{}, wd)); });
           unsigned long long clk[4] = {0, 0, 0, 0};
           CK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_w4_clk), sizeof(clk)));
           if (hot) {  // each launch behind 8 GB of HBM traffic, timed alone: the state the library's serial order leaves the chip in
@@ -174,7 +179,7 @@ int main(int argc, char** argv) {
               CK(hipMemsetAsync(junk, r, (size_t)4 << 30, 0));
               CK(hipMemsetAsync(junk, r + 1, (size_t)4 << 30, 0));
               CK(hipEventRecord(ea, 0));
-              CK(launch_gram_kbits_w4(k1, cv, cn, s_new, num_cu, 0, mode));
+              CK(launch_gram_kbits_w4(k1, cv, cn, s_new, num_cu, 0, mode, nullptr, GramStrip{}, wd));
               CK(hipEventRecord(eb, 0));
               CK(hipEventSynchronize(eb));
               float ms1 = 0;
@@ -193,7 +198,7 @@ int main(int argc, char** argv) {
             CK(hipDeviceSynchronize());
             CK(hipEventRecord(e0, st[0]));
             CK(hipStreamWaitEvent(st[1], e0, 0));
-            for (int r = 0; r < 2 * reps; ++r) CK(launch_gram_kbits_w4(k1, cv, cn, s_new, num_cu, st[r & 1], mode));
+            for (int r = 0; r < 2 * reps; ++r) CK(launch_gram_kbits_w4(k1, cv, cn, s_new, num_cu, st[r & 1], mode, nullptr, GramStrip{}, wd));
             CK(hipEventRecord(ej, st[1]));
             CK(hipStreamWaitEvent(st[0], ej, 0));
             CK(hipEventRecord(e1, st[0]));
@@ -203,11 +208,11 @@ int main(int argc, char** argv) {
             std::printf("n %d v %lld  w4 variant %d mode %d on two streams: %.4f ms per launch\n", cn, (long long)cv, var, mode, ms2 / (2 * reps));
             CK(hipStreamDestroy(st[0])); CK(hipStreamDestroy(st[1]));
           }
-          std::printf("n %d v %lld  w4 variant %d mode %d: %.4f ms   diff %llu %s   block 8: %llu shader cycles in %.1f us = %.3f GHz; slowest block %llu cycles, %.1f us\n", cn,
-                      (long long)cv, var, mode, t, d, var >= 100 ? "(timing-only build)" : d ? "MISMATCH" : "ok", clk[0], clk[1] / 100.0,
+          std::printf("n %d v %lld  w4 variant %d diag %d mode %d: %.4f ms   diff %llu %s   block 8: %llu shader cycles in %.1f us = %.3f GHz; slowest block %llu cycles, %.1f us\n", cn,
+                      (long long)cv, var, wd, mode, t, d, var >= 100 ? "(timing-only build)" : d ? "MISMATCH" : "ok", clk[0], clk[1] / 100.0,
                       clk[1] ? clk[0] / (clk[1] * 10.0) : 0.0, clk[2], clk[3] / 100.0);
         } else {
-          std::printf("n %d v %lld  w4 variant %d mode %d: diff %llu %s\n", cn, (long long)cv, var, mode, d, d ? "MISMATCH" : "ok");
+          std::printf("n %d v %lld  w4 variant %d diag %d mode %d: diff %llu %s\n", cn, (long long)cv, var, wd, mode, d, d ? "MISMATCH" : "ok");
         }
       }
     }
