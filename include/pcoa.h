@@ -65,8 +65,14 @@ typedef enum pcoa_status {
 #define PCOA_FLAG_EIG_HOUSEHOLDER 0x20u /* always use the dense Householder + bisection eigensolver        */
 #define PCOA_FLAG_EIG_LANCZOS    0x40u /* Lanczos only: PCOA_ERR_NOT_CONVERGED instead of falling back      */
 #define PCOA_FLAG_NO_PIPELINE    0x80u /* device tiles: pre-pass and contraction strictly one after the other on the ctx
-                                           stream (the default runs the pre-pass of one operand buffer beside the contraction
-                                           of the previous one, on two side streams, for N = 1,025 .. 16,384) */
+                                           stream (the default runs the pre-pass of one fp32 / uint8 operand buffer beside
+                                           the contraction of the previous one, on two side streams, for N = 1,025 .. 16,384;
+                                           bitset tiles, whose pre-pass is a fifth of their contraction, run in series).
+                                           The side streams want hardware queues of their own: HIP maps a process's streams
+                                           onto a handful of queues per device, so with SEVERAL ctxs alive on ONE device the
+                                           two kernels of a ctx can end up back to back (measured: uint8 tiles 1.62 instead of
+                                           1.16 ms per step with a second, idle ctx alive) -- one ctx per device is the fast
+                                           configuration */
 #define PCOA_FLAG_OPERAND_FP4    0x100u /* binary tiles: keep the re-laid-out operand in HBM as MX-FP4 (4 bits per genotype,
                                            the r01 / r02 form) instead of the default k-bits form (1 bit per genotype,
                                            expanded to MX-FP4 in registers by the contraction).  Same MFMA, same S. */

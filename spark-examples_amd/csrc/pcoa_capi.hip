@@ -887,7 +887,12 @@ int fp4_reserve(pcoa_ctx* c, int64_t kb, int64_t chunk_variants, int side_kind, 
   pcoa_ctx::Fp4Buf* b = &c->fb[c->fb_active];
   // side_kind: 0 = the chunk's pre-pass must run on the ctx stream; 1 = fp32 device tile that may run beside a contraction
   // (either pipeline form); 2 / 3 = uint8 / bitset device tile: only the co-resident form has pre-passes that fit beside one
-  const bool want_side = c->pipe_ok && (side_kind == 1 || (side_kind > 1 && c->coreside));
+  // (bitsets, r05: their transpose is 0.19 ms per 10^6 variants, and beside it the contraction has to be the kernel held to 224
+  // registers: same box, one engine, 1.13-1.15 ms per step co-resident against 1.10-1.14 for the transpose followed by the
+  // one-wave-per-SIMD kernel alone on the chip (tools/alt_inputs_ab.py, profiles/r05d) -- and the series does not depend on the
+  // two side streams landing on different hardware queues.  Bitsets stay on the ctx stream unless PCOA_BITS_PIPELINE=1.)
+  const bool want_side = c->pipe_ok && (side_kind == 1 || (side_kind == 2 && c->coreside) ||
+                                        (side_kind == 3 && c->coreside && debug_knobs().bits_pipeline != 0));
   // a generation filling on the masked stream only takes chunks that may run there; a generation that does not report
   // through its flag cannot start to (an earlier launch decision may already have been made without it)
   // (nor the other way round: a skipped launch would drop chunks that cannot be redone)
@@ -1231,6 +1236,7 @@ const DebugKnobs& debug_knobs() {
     if (const char* v = std::getenv("PCOA_PIPELINE")) k.pipeline = std::atoi(v) != 0;
     if (const char* v = std::getenv("PCOA_FORK_LAZY")) k.fork_lazy = std::atoi(v);
     if (const char* v = std::getenv("PCOA_HEADSTART_US")) k.headstart_us = std::atoi(v);
+    if (const char* v = std::getenv("PCOA_BITS_PIPELINE")) k.bits_pipeline = std::atoi(v);
     if (const char* v = std::getenv("PCOA_KBITS_W4_DIAG")) k.kbits_w4_diag = std::atoi(v);
     if (const char* v = std::getenv("PCOA_GRAM_LOCKSTEP")) k.lockstep = std::atoi(v) != 0;
     k.explicit_center = std::getenv("PCOA_EXPLICIT_CENTER") != nullptr;

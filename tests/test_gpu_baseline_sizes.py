@@ -100,7 +100,8 @@ def bench_shaped(P, O):
 def test_the_bench_shaped_job_three_resident_batches_through_the_co_resident_pipeline(P, bench_shaped, fmt):
     """VERDICT r03, Weak 8: default engine, 3 x 10^6 distinct resident variants in three calls of 10^6 -- one operand buffer
     each, so the pre-pass of batch k+1 runs BESIDE the contraction of batch k (pipeline_launches >= 2) -- and every one of the
-    6,270,016 entries of S equal to the oracle's.  The same job for each device-tile boundary."""
+    6,270,016 entries of S equal to the oracle's.  The same job for each device-tile boundary (bitsets: transpose and
+    contraction in series since r05 -- three launches of the one-wave-per-SIMD kernel in the even-split form)."""
     import torch
     n, v, batches, want = bench_shaped
     words = (n + 31) // 32
@@ -126,7 +127,10 @@ def test_the_bench_shaped_job_three_resident_batches_through_the_co_resident_pip
         s = eng.gram()
         tim = eng.timings()
         assert tim["gram_kernel_kind"] == 3 and tim["fp4_fallbacks"] == 0
-        assert tim["pipeline_launches"] >= 2, tim
+        if fmt == "bits":
+            assert tim["pipeline_launches"] == 0 and tim["evensplit_launches"] >= 3, tim
+        else:
+            assert tim["pipeline_launches"] >= 2, tim
     assert np.array_equal(s, want)
 
 
@@ -532,7 +536,7 @@ print(json.dumps(out))
 '''
 
 
-@pytest.mark.parametrize("env", [{}, {"PCOA_PIPELINE": "0"}, {"PCOA_PIPELINE": "0", "PCOA_GRAM_LOCKSTEP": "0"}])
+@pytest.mark.parametrize("env", [{}, {"PCOA_BITS_PIPELINE": "1"}, {"PCOA_PIPELINE": "0"}, {"PCOA_PIPELINE": "0", "PCOA_GRAM_LOCKSTEP": "0"}])
 def test_fp32_pipeline_and_deferred_verification_on_device_tiles(env):
     """The default path for fp32 device tiles at N = 2504: operand buffers of `max_launch` variants alternate, the
     pre-pass of one runs on CUs 0-15 of every XCD beside the lock-step contraction of the other on CUs 16-31, and the
@@ -555,5 +559,6 @@ def test_fp32_pipeline_and_deferred_verification_on_device_tiles(env):
     assert out["index_error"] and out["after_error_exact"]
     assert out["u8_exact"] and out["bits_exact"], out
     assert out["u8_mult_exact"] and out["u8_mult_fallbacks"] >= 1, out
-    if not env:   # the default: the co-resident pipeline takes uint8 and bitset tiles as well
-        assert out["u8_pipeline_launches"] >= 1 and out["bits_pipeline_launches"] >= 1, out
+    if "PCOA_PIPELINE" not in env:   # the co-resident pipeline takes uint8 tiles as well; bitsets only when asked to (r05)
+        assert out["u8_pipeline_launches"] >= 1, out
+        assert (out["bits_pipeline_launches"] >= 1) == (env.get("PCOA_BITS_PIPELINE") == "1"), out
