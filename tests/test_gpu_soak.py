@@ -15,7 +15,8 @@ def test_the_pipeline_is_exact_over_hundreds_of_steps_in_every_input_format():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_pipeline.py"), os.environ.get("PCOA_SOAK_STEPS", "300")],
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=900)
     assert res.returncode == 0 and "SOAK ok" in res.stdout, res.stdout[-3000:]
-    # and the pipeline was what ran
+    # and the pipeline was what ran (bitset tiles run their transpose and their contraction in series since r05)
     for line in res.stdout.splitlines():
         if "pipelined launches" in line:
-            assert int(line.split("pipelined launches")[1].split(",")[0]) > 100, line
+            piped = int(line.split("pipelined launches")[1].split(",")[0])
+            assert (piped == 0) if line.startswith("bitsets") else (piped > 100), line
