@@ -434,7 +434,8 @@ template <int NST, int NOP, int OPT, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void gram_kbits_w4_kernel(const int8_t* __restrict__ p, int npad, int64_t nstages, int n,
                                                                int ntile, int ntri, int splitk, int64_t stages_per,
                                                                int32_t* __restrict__ s32, int xcd_map,
-                                                               const int32_t* __restrict__ skip, GramStrip strip, int wdiag) {
+                                                               const int32_t* __restrict__ skip, GramStrip strip, int wdiag,
+                                                               int wepi) {
   __shared__ __attribute__((aligned(16))) StageBits lds[NST];
   if (skip != nullptr && *skip != 0) return;
   const int lane = threadIdx.x & 63;
@@ -453,21 +454,23 @@ __global__ __launch_bounds__(256, 1) void gram_kbits_w4_kernel(const int8_t* __r
     if (wdiag > 0 && wdiag < 16 && strip.cols == 0 && ntile <= BAND) {
       // a stage of a diagonal tile costs wdiag / 16 of a stage of any other (wave roles, w4_has_mfma): equal shares of the COST.
       // Tiles are in row-major order here (tile_coords, one band) and the first tile of a row is the diagonal one.
+      // wepi: what the run a workgroup starts when it crosses into the next tile costs on top (accumulator flush + refill of the
+      // ring, in the same units: 16 = a stage of a full tile) -- a stretch of that length in front of every tile
       auto unit_of = [&](int64_t x) -> int64_t {  // cost position -> tile * nstages + stage
         int64_t t0 = 0;
         for (int r = 0; r < ntile; ++r) {
-          const int64_t dspan = nstages * wdiag, fspan = nstages * 16, rspan = dspan + fspan * (ntile - r - 1);
+          const int64_t dspan = wepi + nstages * wdiag, fspan = wepi + nstages * 16, rspan = dspan + fspan * (ntile - r - 1);
           if (x < rspan) {
-            if (x < dspan) return t0 * nstages + x / wdiag;
-            const int64_t y = x - dspan;
-            return (t0 + 1 + y / fspan) * nstages + (y % fspan) / 16;
+            if (x < dspan) return t0 * nstages + (x > wepi ? (x - wepi) / wdiag : 0);
+            const int64_t y = x - dspan, z = y % fspan;
+            return (t0 + 1 + y / fspan) * nstages + (z > wepi ? (z - wepi) / 16 : 0);
           }
           x -= rspan;
           t0 += ntile - r;
         }
         return nwork;
       };
-      const int64_t cost = nstages * ((int64_t)ntile * wdiag + (int64_t)(ntri - ntile) * 16);
+      const int64_t cost = nstages * ((int64_t)ntile * wdiag + (int64_t)(ntri - ntile) * 16) + (int64_t)ntri * wepi;
       u = unit_of(cost * slot / nwg);
       u_end = (slot + 1 == nwg) ? nwork : unit_of(cost * (slot + 1) / nwg);
     } else {
@@ -602,6 +605,11 @@ int g_w4_variant = 0;  // harness knob
 // wdiag: 0 = the r04a form of diagonal tiles (the wave below the diagonal idles); 1..15 = wave roles on diagonal tiles, and in
 // the even split a stage of a diagonal tile counts wdiag / 16 of another tile's; < 0 = the default (kW4DiagCost)
 constexpr int kW4DiagCost = 11;
+// what the even split charges a workgroup for the run it starts when it crosses into the next tile (16 = one stage of a full
+// tile): 1440 = 90 stages ~ 45 us of accumulator flush (65,536 atomics) and ring refill.  Sweep at 14 % ones, two rounds
+// (profiles/r05n): 0 -> 0.922 / 0.931 ms per 2^20 variants, 480 -> 0.899 / 0.902, 960 -> 0.901 / 0.887, 1440 -> 0.889 / 0.878,
+// 1920 -> 0.899 / 0.896.
+int g_w4_epilogue_cost = 1440;
 hipError_t launch_gram_kbits_w4(const int8_t* p, int64_t nv, int32_t n, int32_t* s32, int num_cu, hipStream_t stream, int mode,
                                 const int32_t* skip, GramStrip strip, int wdiag) {
   if (wdiag < 0 || wdiag > 16) wdiag = kW4DiagCost;
@@ -652,7 +660,7 @@ hipError_t launch_gram_kbits_w4(const int8_t* p, int64_t nv, int32_t n, int32_t*
   const dim3 grid((unsigned)nblocks), block(256);
 #define PCOA_LAUNCH_W4(NST_, NOP_, OPT_, DBG_)                                                                            \
   hipLaunchKernelGGL((gram_kbits_w4_kernel<NST_, NOP_, OPT_, DBG_>), grid, block, 0, stream, p, npad, nstages, n, ntile,   \
-                     ntri, (int)splitk, stages_per, s32, xcd_map, skip, strip, wdiag)
+                     ntri, (int)splitk, stages_per, s32, xcd_map, skip, strip, wdiag, g_w4_epilogue_cost)
 #ifdef PCOA_EXPERIMENTS
   switch (g_w4_variant) {
     case 1: PCOA_LAUNCH_W4(4, 0, 0, 0); break;   // builtin DMA, pins behind the MFMA

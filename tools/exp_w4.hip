@@ -93,6 +93,7 @@ int main(int argc, char** argv) {
   std::vector<int> variants = {0, 1, 2, 3};
   std::vector<int> modes = {4, 2, 0};
   std::vector<int> diags = {-1};
+  std::vector<int> epis = {0};
   for (int i = 1; i < argc; ++i) {
     if (!std::strcmp(argv[i], "--n") && i + 1 < argc) n = std::atoi(argv[++i]);
     if (!std::strcmp(argv[i], "--v") && i + 1 < argc) v = std::atoll(argv[++i]);
@@ -106,6 +107,10 @@ int main(int argc, char** argv) {
     if (!std::strcmp(argv[i], "--modes") && i + 1 < argc) {
       modes.clear();
       for (char* t = std::strtok(argv[++i], ","); t; t = std::strtok(nullptr, ",")) modes.push_back(std::atoi(t));
+    }
+    if (!std::strcmp(argv[i], "--epi") && i + 1 < argc) {
+      epis.clear();
+      for (char* t = std::strtok(argv[++i], ","); t; t = std::strtok(nullptr, ",")) epis.push_back(std::atoi(t));
     }
     if (!std::strcmp(argv[i], "--diag") && i + 1 < argc) {
       diags.clear();
@@ -152,8 +157,9 @@ int main(int argc, char** argv) {
       CK(launch_gram_kbits(k1, cv, cn, s_ref, num_cu, 0, ref_mode));
       CK(hipDeviceSynchronize());
     }
-    for (int var : variants) for (int wd : diags) {
+    for (int var : variants) for (int wd : diags) for (int ep : epis) {
       g_w4_variant = var;
+      g_w4_epilogue_cost = ep;
       for (int mode : modes) {
         if (mode == 2 && gram_lockstep_splitk(cn, num_cu) == 0) continue;
         if (mode == 4 && ntri > 4 * num_cu) continue;
@@ -208,8 +214,8 @@ int main(int argc, char** argv) {
             std::printf("n %d v %lld  w4 variant %d mode %d on two streams: %.4f ms per launch\n", cn, (long long)cv, var, mode, ms2 / (2 * reps));
             CK(hipStreamDestroy(st[0])); CK(hipStreamDestroy(st[1]));
           }
-          std::printf("n %d v %lld  w4 variant %d diag %d mode %d: %.4f ms   diff %llu %s   block 8: %llu shader cycles in %.1f us = %.3f GHz; slowest block %llu cycles, %.1f us\n", cn,
-                      (long long)cv, var, wd, mode, t, d, var >= 100 ? "(timing-only build)" : d ? "MISMATCH" : "ok", clk[0], clk[1] / 100.0,
+          std::printf("n %d v %lld  w4 variant %d diag %d epi %d mode %d: %.4f ms   diff %llu %s   block 8: %llu shader cycles in %.1f us = %.3f GHz; slowest block %llu cycles, %.1f us\n", cn,
+                      (long long)cv, var, wd, ep, mode, t, d, var >= 100 ? "(timing-only build)" : d ? "MISMATCH" : "ok", clk[0], clk[1] / 100.0,
                       clk[1] ? clk[0] / (clk[1] * 10.0) : 0.0, clk[2], clk[3] / 100.0);
         } else {
           std::printf("n %d v %lld  w4 variant %d diag %d mode %d: diff %llu %s\n", cn, (long long)cv, var, wd, mode, d, d ? "MISMATCH" : "ok");
