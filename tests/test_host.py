@@ -702,3 +702,41 @@ def test_bench_refuses_counter_traffic_of_another_tree(tmp_path, monkeypatch):
     with open(pkg_copy / "p" / "csrc" / "center.hip", "a") as fh:
         fh.write("\n")
     assert lib.source_hash() != here
+
+
+def test_pmc_live_turns_counter_csvs_into_per_variant_traffic(tmp_path):
+    """tools/pmc_live.py: per-process FETCH_SIZE / WRITE_SIZE totals of the two kernel families / the variants the manifest
+    names, reads doubled (gfx950 tallies wide reads at half), KiB -> bytes; the file carries the manifest's source hash."""
+    import csv
+    import json
+    import subprocess
+    out = tmp_path / "tag"
+    rows = {"FETCH_SIZE": [("void pcoa::(anonymous namespace)::pack_kbits_ring_kernel<8, 0, 0>(float const*)", 1, 1000.0),
+                           ("void pcoa::(anonymous namespace)::pack_kbits_ring_kernel<8, 0, 0>(float const*)", 2, 3000.0),
+                           ("void pcoa::(anonymous namespace)::gram_kbits_kernel<3, 2, 2>(signed char const*)", 3, 500.0),
+                           ("void at::native::some_other_kernel()", 4, 1e9)],
+            "WRITE_SIZE": [("void pcoa::(anonymous namespace)::pack_kbits_kernel<float, 4, true, false>(float const*)", 1, 100.0),
+                           ("void pcoa::(anonymous namespace)::gram_kbits_w4_kernel<4, 0, 69, 0>(signed char const*)", 2, 50.0)]}
+    for tag in ("pipe", "serial"):
+        for c, rs in rows.items():
+            sub = out / ("pmclive_%s_%s" % (tag, c)) / "host"
+            sub.mkdir(parents=True)
+            with open(sub / "pmc_counter_collection.csv", "w", newline="") as fh:
+                w = csv.writer(fh)
+                w.writerow(["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"])
+                for name, disp, val in rs:
+                    w.writerow([disp, name, c, val])
+            (out / ("pmclive_%s_%s.json" % (tag, c))).write_text(json.dumps(
+                {"pmc_manifest": {"source_hash": "abcd" * 4, "fp32_variants_through_the_engine": 2000000}}))
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_live.py"), str(out)], stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, universal_newlines=True)
+    assert res.returncode == 0, res.stdout
+    rec = json.load(open(out / "gram_pmc_live.json"))
+    assert rec["source_hash"] == "abcd" * 4
+    for key in ("kbits", "kbits_standalone"):
+        k = rec[key]
+        assert k["pack_read_bytes_per_mvariants"] == 2 * 4000.0 * 1024 / 2.0      # 2 x KiB x 1024 / 2e6 variants x 1e6
+        assert k["gram_read_bytes_per_mvariants"] == 2 * 500.0 * 1024 / 2.0
+        assert k["pack_write_bytes_per_mvariants"] == 100.0 * 1024 / 2.0 and k["gram_write_bytes_per_mvariants"] == 50.0 * 1024 / 2.0
+        assert k["pack_hbm_bytes_per_mvariants"] == k["pack_read_bytes_per_mvariants"] + k["pack_write_bytes_per_mvariants"]
+        assert k["pack_dispatches"] == 1 and k["gram_dispatches"] == 1   # (the last pass read: WRITE_SIZE)
