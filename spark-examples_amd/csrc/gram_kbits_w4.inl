@@ -535,8 +535,9 @@ __global__ __launch_bounds__(256, 1) void gram_kbits_w4_kernel(const int8_t* __r
     }
     const int col_i = row_blk * 256, col_j = col_blk * TJ;
     // A diagonal tile runs the same code: panel J is panel I brought in a second time (10 of 55 tiles at N = 2504; the extra
-    // 4 KiB per stage come out of the L1).  The wave whose block lies below the diagonal keeps its share of the DMA and of the
-    // barriers and issues nothing else (the kernel is power-bound: MFMAs nobody needs cost clock).
+    // 4 KiB per stage come out of the L1).  In the r04a form (wdiag = 0, role 4) the wave whose block lies below the diagonal
+    // keeps its share of the DMA and of the barriers and issues nothing else; the default gives every wave a part of the tile's
+    // upper triangle instead (the kernel is power-bound: MFMAs nobody needs cost clock).
     const bool diag_tile = row_blk == col_blk && strip.cols == 0;
     // wave roles on a diagonal tile (w4_has_mfma): the two blocks on the diagonal compute their upper MFMA tiles, the block
     // above it is shared by the other two waves -- the one below the diagonal takes the place of (wm, wn) = (0, 1) too
