@@ -743,9 +743,23 @@ def csr_boundary(P, torch, dev, local_rank, n, x1, s_dense_steps, steps, operand
     idx_cpu, offs_cpu = idx_dev.cpu(), offs_dev.cpu()
     idx_pin, offs_pin = idx_cpu.pin_memory(), offs_cpu.pin_memory()
     half = v // 2 // 128 * 128
+    # what the link of THIS box delivers: the same pinned array through one plain async copy (best of 3)
+    land = torch.empty_like(idx_dev)
+    link = 0.0
+    for _ in range(3):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        land.copy_(idx_pin, non_blocking=True)
+        torch.cuda.synchronize(dev)
+        link = max(link, 4.0 * nnz / (time.perf_counter() - t0))
+    del land
+    link_bound = link / bytes_per_variant
     res = {"workload": "configs[1] batch 0 as carrier lists: %d variants, %d carriers (%.1f per variant), %.0f B per variant"
                        % (v, nnz, nnz / float(v), bytes_per_variant),
-           "pcie_bound_variants_per_s": pcie_bound, "pcie_gbs_assumed": 63.0}
+           "pcie_bound_variants_per_s": pcie_bound, "pcie_gbs_assumed": 63.0,
+           "link_gbs_measured": link / 1e9, "link_bound_variants_per_s": link_bound,
+           "link_note": "link_gbs_measured = one hipMemcpyAsync of the pinned index array (%.2f GB) on this box, best of 3; "
+                        "frac_of_measured_link = a leg's variants/s against that" % (4e-9 * nnz)}
     with P.PcoaEngine(n, device=local_rank, operand=operand) as e:
         e.reserve(v, 0)
         legs = [("pageable", idx_cpu, offs_cpu, False, 1), ("pinned", idx_pin, offs_pin, False, 1),
@@ -767,7 +781,8 @@ def csr_boundary(P, torch, dev, local_rank, n, x1, s_dense_steps, steps, operand
                 dt = time.perf_counter() - t0
             tt = e.timings()
             same = bool(np.array_equal(e.gram() * steps, s_dense_steps))
-            res[name] = {"variants_per_s": v / dt, "frac_of_pcie_bound": (v / dt) / pcie_bound, "seconds": dt,
+            res[name] = {"variants_per_s": v / dt, "frac_of_pcie_bound": (v / dt) / pcie_bound,
+                         "frac_of_measured_link": (v / dt) / link_bound, "seconds": dt,
                          "seconds_until_the_calls_returned": t_call,
                          "scatter_kernel_ms": 1e3 * tt["densify_seconds"], "contraction_ms": 1e3 * tt["gram_kernel_seconds"],
                          "host_staging_copy_s": tt["csr_stage_seconds"], "host_wait_for_device_check_s": tt["csr_wait_seconds"],

@@ -534,6 +534,77 @@ __global__ __launch_bounds__(256) void densify_csr_kbits_kernel(const int32_t* _
   }
 }
 
+// The same through the LDS (r05): one workgroup per block of 128 variants.  A block's carrier entries are ONE contiguous run
+// of idx[] (rows are consecutive), so the workgroup streams it with 16-byte loads -- a lane takes 4 consecutive entries
+// and finds their rows by a search over the block's 129 offsets in LDS -- and sets bit (row % 32) of word row / 32 of the
+// callset's 16-byte slot with a DS atomic OR, whose return value is the repeat check exactly as in the global form.  The
+// LDS image IS the global image of the block: it leaves with coalesced 16-byte stores, every word of the block written,
+// so the operand needs no zero fill.  Bound by the 4 bytes per carrier it reads, not by the L2's atomic units
+// (the global form: 7.4-8.6 ms per 10^6 variants of configs[1]; this one: see profiles/r06*).
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void densify_csr_kbits_lds_kernel(const int32_t* __restrict__ idx,
+                                                                        const int64_t* __restrict__ offs, int64_t nv,
+                                                                        int64_t offs_base, uint32_t* __restrict__ p,
+                                                                        int npad, int32_t n, int32_t* __restrict__ flag) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t dens_lds[];  // [npad][4] bit words, then 129 relative offsets
+  uint32_t* bits = dens_lds;
+  int32_t* rel = reinterpret_cast<int32_t*>(dens_lds + (size_t)npad * 4);
+  const int tid = threadIdx.x;
+  const int64_t blk = blockIdx.x;
+  const int64_t r0 = blk * 128;
+  const int nrows = r0 < nv ? (int)(nv - r0 < 128 ? nv - r0 : 128) : 0;  // blocks beyond the rows are written as zeros
+  for (int i = tid; i < npad; i += THREADS) reinterpret_cast<uint4*>(bits)[i] = make_uint4(0u, 0u, 0u, 0u);
+  const int64_t e0 = nrows > 0 ? offs[r0] : 0;
+  if (tid <= 128) {
+    const int64_t d = nrows > 0 ? offs[r0 + (tid < nrows ? tid : nrows)] - e0 : 0;
+    // (a block of sane lists has <= 128 * N entries; offsets that are not, e.g. garbage behind a device pointer, are
+    // reported as an index error instead of being followed)
+    rel[tid] = (d < 0 || d > (int64_t)0x7fffffff) ? -1 : (int32_t)d;
+  }
+  __syncthreads();
+  int total = rel[128];
+  bool bad = total < 0;
+  if (tid <= 127 && !bad) bad = rel[tid] < 0 || rel[tid] > rel[tid + 1];
+  if (__syncthreads_or(bad)) {
+    if (tid == 0) { atomicOr(flag, 1); flag[2] = -1; }
+    total = 0;
+  }
+  const int32_t* src = idx + (e0 - offs_base);
+  const int mis = (int)((reinterpret_cast<uintptr_t>(src) >> 2) & 3);  // src - mis is 16-byte aligned
+  for (int q = tid * 4 - mis; q < total; q += THREADS * 4) {
+    int32_t cs[4];
+    if (q >= 0 && q + 3 < total) {
+      const int4 v = *reinterpret_cast<const int4*>(src + q);
+      cs[0] = v.x; cs[1] = v.y; cs[2] = v.z; cs[3] = v.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cs[i] = (q + i >= 0 && q + i < total) ? src[q + i] : 0;
+    }
+    const int qs = q < 0 ? 0 : q;
+    int row = 0;  // the largest r with rel[r] <= qs: the (non-empty) row entry qs belongs to
+#pragma unroll
+    for (int s = 64; s >= 1; s >>= 1)
+      if (rel[row + s] <= qs) row += s;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int qi = q + i;
+      if (qi < 0 || qi >= total) continue;
+      while (rel[row + 1] <= qi) ++row;  // rel[128] = total > qi: row stays <= 127
+      const int32_t c = cs[i];
+      if (c < 0 || c >= n) {
+        atomicOr(flag, 1);
+        flag[2] = c;
+        continue;
+      }
+      const uint32_t bit = 1u << (row & 31);
+      if (atomicOr(&bits[(size_t)c * 4 + (row >> 5)], bit) & bit) atomicOr(flag, 32);
+    }
+  }
+  __syncthreads();
+  uint4* dst = reinterpret_cast<uint4*>(p + (size_t)blk * npad * 4);
+  for (int i = tid; i < npad; i += THREADS) dst[i] = reinterpret_cast<const uint4*>(bits)[i];
+}
+
 // ---------------------------------------------------------------------------------------------- contraction
 struct StageBits {
   uint32_t pi[256][4];  // panel I: [sample][word]; word 2 * hi + k2 is what lane half `hi` feeds to k-step k2
@@ -1073,6 +1144,24 @@ hipError_t launch_densify_csr_kbits(const int32_t* idx_dev, const int64_t* offs_
                                     int8_t* p, int32_t n, int32_t* flag, hipStream_t stream, int64_t nblk_out) {
   if (nv <= 0) return hipSuccess;
   const int npad = (int)gram_packed_npad(n);
+  // the LDS form while a block of 128 variants x npad samples (16 B per sample) + its offsets fit 128 KiB of LDS
+  // (npad <= 8,160); PCOA_CSR_GLOBAL_ATOMICS=1 gives the r04 form back (one wave per row, global atomic OR)
+  static const bool force_global = [] {
+    const char* v = std::getenv("PCOA_CSR_GLOBAL_ATOMICS");
+    return v && std::atoi(v) != 0;
+  }();
+  const size_t lds = (size_t)npad * 16 + 132 * sizeof(int32_t);
+  if (!force_global && lds <= 128 * 1024 && nblk_out > 0 && nblk_out <= 0x7fffffffLL) {
+    constexpr int T = 512;
+    if (lds > 64 * 1024) {  // opt in to more than 64 KiB of dynamic LDS (per device: cheap enough to repeat)
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(densify_csr_kbits_lds_kernel<T>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(densify_csr_kbits_lds_kernel<T>, dim3((unsigned)nblk_out), dim3(T), lds, stream, idx_dev, offs_dev, nv,
+                       offs_base, reinterpret_cast<uint32_t*>(p), npad, n, flag);
+    return hipGetLastError();
+  }
   hipError_t e = hipMemsetAsync(p, 0, (size_t)nblk_out * (size_t)npad * 16, stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(densify_csr_kbits_kernel, dim3((unsigned)((nv + 3) / 4)), dim3(256), 0, stream, idx_dev, offs_dev, nv,

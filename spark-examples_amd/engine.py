@@ -145,6 +145,8 @@ class PcoaEngine(object):
         assert sample_idx.dtype == torch.int32 and row_offsets.dtype == torch.int64
         assert sample_idx.dim() == 1 and row_offsets.dim() == 1 and sample_idx.is_contiguous() and row_offsets.is_contiguous()
         assert sample_idx.device == row_offsets.device
+        if sample_idx.numel() == 0:
+            return   # only empty lists: they add nothing (filtered at VariantsPca.scala:166); an empty tensor has no address
         flags = 0
         if sample_idx.is_cuda:
             flags |= L.PCOA_CALLS_DEVICE_PTR

@@ -464,6 +464,44 @@ def test_the_device_side_check_of_carrier_lists_rejects_rolls_back_and_redoes(P,
             eng.sync()
 
 
+@pytest.mark.parametrize("n", [5, 33, 300, 2504, 5000, 9000])
+def test_carrier_lists_through_the_lds_scatter_on_ragged_blocks_and_misaligned_arrays(P, O, n):
+    """r05: densify_csr_kbits_lds_kernel -- one workgroup per block of 128 variants streams the block's contiguous run of
+    entries with 16-byte loads and scatters bits in LDS.  What it has to get right: runs that start at any of the four
+    alignments (device arrays handed over as views, blocks that start anywhere in idx[]), empty rows at the ends and in the
+    middle of a block, full rows (all N callsets), row counts around the block size, N with more than 64 KiB of LDS
+    (5,000) and N where the r04 global-atomic form still runs (9,000)."""
+    import torch
+    rng = np.random.default_rng(n)
+    for v in (1, 127, 128, 129, 257, 700):
+        dens = rng.choice([0.002, 0.05, 0.4], size=v)
+        x = (rng.random((v, n)) < dens[:, None]).astype(np.float32)
+        x[0] = 0
+        x[v - 1] = 0
+        if v > 130:
+            x[127] = 0
+            x[128] = 1          # every callset
+            x[64:70] = 0
+        want = O.similarity_from_dense_blas(x)
+        idx, offs = _csr_of(x)
+        for shift in (0, 1, 2, 3):
+            big = torch.zeros(idx.size + 8, dtype=torch.int32, device="cuda")
+            big[shift:shift + idx.size] = torch.from_numpy(idx).cuda()
+            ti = big[shift:shift + idx.size]
+            to = torch.from_numpy(offs).cuda()
+            with P.PcoaEngine(n) as eng:
+                eng.accumulate_calls_tensors(ti, to)
+                got = eng.gram()
+            assert np.array_equal(got, want), (n, v, shift)
+        with P.PcoaEngine(n) as eng:   # host arrays, two calls: the second starts a new block of the operand
+            h = v // 2
+            for lo, hi in ((0, h), (h, v)):
+                if hi > lo:
+                    i2, o2 = _csr_of(x[lo:hi])
+                    eng.accumulate_calls_tensors(torch.from_numpy(i2), torch.from_numpy(o2))
+            assert np.array_equal(eng.gram(), want), (n, v, "host")
+
+
 @pytest.mark.parametrize("n", [1024, 2504, 3076, 4100])
 def test_upper_triangle_form_of_the_centred_matvec_agrees_with_the_row_form_and_the_oracle(P, O, n):
     """r04: from N = 16,384 the Lanczos mat-vec reads only the upper-triangular 1024 x 1024 tiles of S (each entry serves y_i and
