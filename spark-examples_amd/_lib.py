@@ -7,7 +7,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpcoa_hip.so")
+# PCOA_LIB: another build of the same library (A/B runs of two trees on one box, sanitizer builds); there is no fallback
+# either way -- the named file is loaded or the import fails
+LIB_PATH = os.environ.get("PCOA_LIB") or os.path.join(_HERE, "libpcoa_hip.so")
 
 PCOA_OK = 0
 PCOA_ERR_INVALID_ARG = -1

@@ -198,61 +198,90 @@ __device__ __forceinline__ int64_t sym_tile_index(int bi, int bj, int nb) {  // 
   return (int64_t)bi * nb - (int64_t)bi * (bi - 1) / 2 + (bj - bi);
 }
 
-template <bool DIAG>
-__global__ __launch_bounds__(256) void symv_sym_tiles_kernel(const int32_t* __restrict__ s32, int n, int nb,
-                                                             const double* __restrict__ cm, const double* __restrict__ stats,
-                                                             const double* __restrict__ x, double* __restrict__ part) {
-  __shared__ double colred[4][SYT];  // 32 KiB
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // DIAG: blockIdx.x = diagonal tile; else: blockIdx.x enumerates the strictly upper tiles row by row
-  int bi, bj;
-  if (DIAG) {
-    bi = bj = blockIdx.x;
-  } else {
-    int t = blockIdx.x;
-    bi = 0;
-    while (t >= nb - 1 - bi) {
-      t -= nb - 1 - bi;
-      ++bi;
-    }
-    bj = bi + 1 + t;
-  }
+// Sum over the 64 lanes on the VALU (DPP: xor 1, xor 2, mirror within 8, mirror within 16, then row 0 -> 1 / 2 -> 3 and
+// rows 0-1 -> 2-3 broadcasts); the total is in LANE 63.  One dependent chain of 18 VALU instructions instead of six LDS
+// round trips (ds_bpermute) per row.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int l2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
+  const int h2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+  return v + __hiloint2double(h2, l2);
+}
+__device__ __forceinline__ double wave_sum_to_lane63(double v) {
+  v = dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xF>(v);  // row_half_mirror
+  v = dpp_add<0x140, 0xF>(v);  // row_mirror: every lane holds the sum of its row of 16
+  v = dpp_add<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
+  v = dpp_add<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3
+  return v;
+}
+
+// r05: what the r04 form lost (4.4 TB/s): the row's x_i / rowMean_i were vector loads issued BEHIND the next row's
+// prefetch, and vector-memory returns are counted in order -- waiting for them waited for the prefetch as well
+// (s_waitcnt vmcnt(0) in every iteration); the `j < n` masks of the last block column were evaluated for every tile
+// (16 exec-mask branches per row); the row sum went through six LDS round trips; a lane's 16 columns cost 96 registers
+// of loop invariants (152 in all: three waves per SIMD).  Here the four waves of a workgroup are a 2 x 2 grid -- wave
+// (wr, wc) walks the rows of parity wr over the 512 columns of half wc, a lane owns 8 columns (48 registers of
+// invariants) --, the tile's 1024 x_i and rowMean_i are staged in LDS once, rows are prefetched FOUR deep (8 x 1 KiB per
+// wave in flight; the loop holds no vector-memory instruction but the 16-byte loads of S), interior tiles carry no masks
+// (EDGE is a per-workgroup branch), row sums are reduced with DPP and collected in LDS.  Nothing is combined across
+// waves inside the kernel: a tile writes the row sums of its two column halves and the column sums of its two row
+// parities (4 x 1024 doubles), symv_sym_gather_kernel adds them in a fixed order.
+constexpr int SYP = 4 * SYT;   // doubles of `part` per tile: row sums [wc = 0, 1][1024], column sums [wr = 0, 1][1024]
+constexpr int SYNB = 4;        // row buffers per wave
+
+template <bool DIAG, bool EDGE>
+__device__ __forceinline__ void symv_sym_tile_body(const int32_t* __restrict__ s32, int n, int nb,
+                                                   const double* __restrict__ cm, const double mmean,
+                                                   const double* __restrict__ x, double* __restrict__ part, int bi, int bj,
+                                                   double* xs, double* ms, double (*rs)[SYT]) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: the row loops branch on it)
+  const int wr = wave >> 1, wc = wave & 1;
   const int i0 = bi * SYT, j0 = bj * SYT;
-  const double mmean = stats[1];
-  // the lane's 16 columns: j0 + 256 q + 4 lane + {0..3}
-  double xj[16], mj[16], cacc[16];
+  const int jw = j0 + 512 * wc + 4 * lane;   // the lane's 8 columns: jw + 256 q + {0..3}
+  const int rows = EDGE ? min(SYT, n - i0) : SYT;
+  for (int r = threadIdx.x; r < SYT; r += 256) {
+    const bool in = !EDGE || i0 + r < n;
+    xs[r] = in ? x[i0 + r] : 0.0;
+    ms[r] = in ? cm[i0 + r] : 0.0;
+  }
+  double xj[8], mj[8], cacc[8];
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+  for (int q = 0; q < 2; ++q)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int j = j0 + 256 * q + 4 * lane + e;
-      xj[4 * q + e] = j < n ? x[j] : 0.0;
-      mj[4 * q + e] = j < n ? cm[j] : 0.0;
+      const int j = jw + 256 * q + e;
+      const bool in = !EDGE || j < n;
+      xj[4 * q + e] = in ? x[j] : 0.0;
+      mj[4 * q + e] = in ? cm[j] : 0.0;
       cacc[4 * q + e] = 0.0;
     }
-  const int rows = min(SYT, n - i0);
-  double* prow = part + sym_tile_index(bi, bj, nb) * (2 * SYT);
-  auto load_row = [&](int r, int4 (&v)[4]) {
-    const int32_t* rowp = s32 + (int64_t)(i0 + r) * n + j0 + 4 * lane;
+  __syncthreads();
+  const int32_t* base = s32 + (int64_t)i0 * n + jw;
+  auto load_row = [&](int r, int4 (&v)[2]) {
+    const int32_t* rowp = base + (int64_t)r * n;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int j = j0 + 256 * q + 4 * lane;
-      v[q] = (j < n) ? *reinterpret_cast<const int4*>(rowp + 256 * q) : make_int4(0, 0, 0, 0);   // n % 4 == 0: whole or none
+    for (int q = 0; q < 2; ++q) {
+      if (EDGE) {
+        const bool in = r < rows && jw + 256 * q < n;   // n % 4 == 0: a quad is whole or absent
+        v[q] = in ? *reinterpret_cast<const int4*>(rowp + 256 * q) : make_int4(0, 0, 0, 0);
+      } else {
+        v[q] = *reinterpret_cast<const int4*>(rowp + 256 * q);
+      }
     }
   };
-  int4 cur[4], nxt[4];
-  if (wave < rows) load_row(wave, cur);
-  for (int r = wave; r < rows; r += 4) {
-    if (r + 4 < rows) load_row(r + 4, nxt);
+  auto use_row = [&](int r, const int4 (&v)[2]) {
     const int i = i0 + r;
-    const double xi = x[i], mi = cm[i];
+    const double xi = xs[r], mi = ms[r];
     double racc = 0.0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int sv[4] = {cur[q].x, cur[q].y, cur[q].z, cur[q].w};
+    for (int q = 0; q < 2; ++q) {
+      const int sv[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int j = j0 + 256 * q + 4 * lane + e;
+        const int j = jw + 256 * q + e;
         const double d = (double)sv[e];
         double bij, bji;
         {
@@ -265,48 +294,117 @@ __global__ __launch_bounds__(256) void symv_sym_tiles_kernel(const int32_t* __re
           bji = bji + mmean;
         }
         if (DIAG) {  // the tile's own upper triangle: the diagonal counts once (in the row sums)
-          if (j >= i && j < n) racc += bij * xj[4 * q + e];
-          if (j > i && j < n) cacc[4 * q + e] += bji * xi;
-        } else {
+          const bool in = !EDGE || j < n;
+          racc += (j >= i && in) ? bij * xj[4 * q + e] : 0.0;
+          cacc[4 * q + e] += (j > i && in) ? bji * xi : 0.0;
+        } else if (EDGE) {
           // (columns >= n of the last block column: x and S were read as 0 but the centred entry is not 0 -> mask)
-          if (j < n) {
-            racc += bij * xj[4 * q + e];
-            cacc[4 * q + e] += bji * xi;
-          }
+          racc += j < n ? bij * xj[4 * q + e] : 0.0;
+          cacc[4 * q + e] += j < n ? bji * xi : 0.0;
+        } else {
+          racc += bij * xj[4 * q + e];
+          cacc[4 * q + e] += bji * xi;
         }
       }
     }
-    racc = wave_sum(racc);
-    if (lane == 0) prow[r] = racc;
+    racc = wave_sum_to_lane63(racc);
+    if (lane == 63) rs[wc][r] = racc;
+    // one row at a time: left alone, the compiler computes the four row sums of the unrolled loop body first and keeps
+    // their 32 converted entries alive for the column sums (183 registers, or spills) -- the column sums are pinned
+    // here, and nothing moves across the barrier
 #pragma unroll
-    for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+    for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(cacc[c]));
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // rows wr, wr + 2, ..: SYNB buffers, each refilled as soon as its row is used
+  int4 buf[SYNB][2];
+  const int nr = rows > wr ? (rows - wr + 1) / 2 : 0;   // this wave's row count
+#pragma unroll
+  for (int b = 0; b < SYNB; ++b)
+    if (b < nr) load_row(wr + 2 * b, buf[b]);
+  int k = 0;
+  for (; k + 2 * SYNB <= nr; k += SYNB) {   // every refill is a row of the tile: no conditions in the steady state
+#pragma unroll
+    for (int b = 0; b < SYNB; ++b) {
+      use_row(wr + 2 * (k + b), buf[b]);
+      load_row(wr + 2 * (k + b + SYNB), buf[b]);
+    }
   }
-  for (int r = rows + (int)threadIdx.x; r < SYT; r += 256) prow[r] = 0.0;   // rows beyond N in the last block row
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+  for (int b = 0; b < SYNB; ++b)   // the last < 2 SYNB rows
+    if (k + b < nr) {
+      use_row(wr + 2 * (k + b), buf[b]);
+      if (k + b + SYNB < nr) load_row(wr + 2 * (k + b + SYNB), buf[b]);
+    }
+  k += SYNB;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) colred[wave][256 * q + 4 * lane + e] = cacc[4 * q + e];
+  for (int b = 0; b < SYNB; ++b)
+    if (k + b < nr) use_row(wr + 2 * (k + b), buf[b]);
+  double* ptile = part + sym_tile_index(bi, bj, nb) * SYP;
+  double* pcol = ptile + 2 * SYT + wr * SYT + 512 * wc + 4 * lane;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    *reinterpret_cast<double2*>(pcol + 256 * q) = make_double2(cacc[4 * q], cacc[4 * q + 1]);
+    *reinterpret_cast<double2*>(pcol + 256 * q + 2) = make_double2(cacc[4 * q + 2], cacc[4 * q + 3]);
+  }
   __syncthreads();
-  for (int cidx = threadIdx.x; cidx < SYT; cidx += 256)
-    prow[SYT + cidx] = ((colred[0][cidx] + colred[1][cidx]) + colred[2][cidx]) + colred[3][cidx];
+  for (int r = threadIdx.x; r < SYT; r += 256) {   // rows beyond N in the last block row: 0
+    ptile[r] = r < rows ? rs[0][r] : 0.0;
+    ptile[SYT + r] = r < rows ? rs[1][r] : 0.0;
+  }
 }
 
-// y_i = sum over the tiles of block row bi (their row sums, left to right) + over the tiles of block column bi above the
-// diagonal (their column sums, top to bottom): a fixed order
+// Four instantiations, each with its own register allocation: interior tiles (no masks) and the tiles of the last block
+// column / row when N is not a multiple of 1024 (EDGE), above the diagonal and on it.  nbi = block columns that lie wholly
+// inside N.  <false, false>: one workgroup per tile bi < bj < nbi, enumerated row by row; <false, true>: bj = nb - 1,
+// bi = blockIdx.x; <true, false>: bi = bj = blockIdx.x; <true, true>: the corner tile.
+template <bool DIAG, bool EDGE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(64)))  // (counts halves of the unified file: 128 registers) four workgroups per CU
+void symv_sym_tiles_kernel(const int32_t* __restrict__ s32, int n, int nb, int nbi,
+                           const double* __restrict__ cm, const double* __restrict__ stats,
+                           const double* __restrict__ x, double* __restrict__ part) {
+  __shared__ double xs[SYT], ms[SYT];  // 16 KiB: x_i and rowMean_i of the tile's rows
+  __shared__ double rs[2][SYT];        // 16 KiB: the row sums over the two column halves
+  int bi, bj;
+  if (DIAG) {
+    bi = bj = EDGE ? nb - 1 : (int)blockIdx.x;
+  } else if (EDGE) {
+    bi = blockIdx.x;
+    bj = nb - 1;
+  } else {
+    int t = blockIdx.x;
+    bi = 0;
+    while (t >= nbi - 1 - bi) {
+      t -= nbi - 1 - bi;
+      ++bi;
+    }
+    bj = bi + 1 + t;
+  }
+  symv_sym_tile_body<DIAG, EDGE>(s32, n, nb, cm, stats[1], x, part, bi, bj, xs, ms, rs);
+}
+
+// y_i = over the tiles of block row bi, left to right, their two row sums (column half 0, then 1) + over the tiles of
+// block column bi from the top down to the diagonal tile, their two column sums (row parity 0, then 1): a fixed order
 __global__ __launch_bounds__(256) void symv_sym_gather_kernel(const double* __restrict__ part, int n, int nb, double* __restrict__ y) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int bi = i / SYT, r = i - bi * SYT;
   double acc = 0.0;
-  for (int bj = bi; bj < nb; ++bj) acc += part[sym_tile_index(bi, bj, nb) * (2 * SYT) + r];
-  for (int bk = 0; bk <= bi; ++bk) acc += part[sym_tile_index(bk, bi, nb) * (2 * SYT) + SYT + r];  // (the diagonal tile's too)
+  for (int bj = bi; bj < nb; ++bj) {
+    const double* t = part + sym_tile_index(bi, bj, nb) * SYP;
+    acc += t[r] + t[SYT + r];
+  }
+  for (int bk = 0; bk <= bi; ++bk) {
+    const double* t = part + sym_tile_index(bk, bi, nb) * SYP + 2 * SYT;
+    acc += t[r] + t[SYT + r];
+  }
   y[i] = acc;
 }
 
 // doubles of workspace the symmetric form needs (0: not used at this N)
 size_t symv_sym_workspace_doubles_impl(int n) {
   const int64_t nb = (n + SYT - 1) / SYT;
-  return (size_t)(nb * (nb + 1) / 2) * (size_t)(2 * SYT);
+  return (size_t)(nb * (nb + 1) / 2) * (size_t)SYP;
 }
 
 void launch_symv(const EigWorkspace& ws, int n, const double* x, double* y, hipStream_t stream) {
@@ -318,11 +416,19 @@ void launch_symv(const EigWorkspace& ws, int n, const double* x, double* y, hipS
                        ws.stats, x, y);
   } else if (ws.sym_part && (n & 3) == 0) {
     const int nb = (n + SYT - 1) / SYT;
-    if (nb > 1)
-      hipLaunchKernelGGL(symv_sym_tiles_kernel<false>, dim3((unsigned)((int64_t)nb * (nb - 1) / 2)), dim3(256), 0, stream, ws.s32, n,
-                         nb, ws.colmean, ws.stats, x, ws.sym_part);
-    hipLaunchKernelGGL(symv_sym_tiles_kernel<true>, dim3((unsigned)nb), dim3(256), 0, stream, ws.s32, n, nb, ws.colmean, ws.stats, x,
-                       ws.sym_part);
+    const int nbi = n / SYT;   // block columns wholly inside N (nb or nb - 1)
+    if (nbi > 1)
+      hipLaunchKernelGGL((symv_sym_tiles_kernel<false, false>), dim3((unsigned)((int64_t)nbi * (nbi - 1) / 2)), dim3(256), 0, stream,
+                         ws.s32, n, nb, nbi, ws.colmean, ws.stats, x, ws.sym_part);
+    if (nbi < nb && nb > 1)
+      hipLaunchKernelGGL((symv_sym_tiles_kernel<false, true>), dim3((unsigned)(nb - 1)), dim3(256), 0, stream, ws.s32, n, nb, nbi,
+                         ws.colmean, ws.stats, x, ws.sym_part);
+    if (nbi > 0)
+      hipLaunchKernelGGL((symv_sym_tiles_kernel<true, false>), dim3((unsigned)nbi), dim3(256), 0, stream, ws.s32, n, nb, nbi,
+                         ws.colmean, ws.stats, x, ws.sym_part);
+    if (nbi < nb)
+      hipLaunchKernelGGL((symv_sym_tiles_kernel<true, true>), dim3(1), dim3(256), 0, stream, ws.s32, n, nb, nbi, ws.colmean,
+                         ws.stats, x, ws.sym_part);
     hipLaunchKernelGGL(symv_sym_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ws.sym_part, n, nb, y);
   } else {
     hipLaunchKernelGGL(symv_centered_kernel<false>, dim3(rows4), dim3(256), 0, stream, ws.s32, ws.s64, n, ws.colmean,

@@ -274,8 +274,15 @@ struct pcoa_ctx {
   std::vector<CsrPending> csr_pending;  // committed provisionally into the ACTIVE operand buffer, not yet validated
   double csr_stage_s = 0, csr_wait_s = 0;  // host seconds spent copying into pinned staging / waiting in validation
   int64_t csr_fast_chunks = 0, csr_redo_chunks = 0;
-  uint8_t* bed_raw = nullptr;      // raw PLINK .bed rows of one chunk (pcoa_accumulate_plink_bed, host input)
-  int64_t bed_raw_cap = 0;
+  // raw PLINK .bed rows (pcoa_accumulate_plink_bed, host input): two device slots filled on the copy stream (csr_stream),
+  // so that the H2D of one chunk runs beside the decode / transpose / contraction of the one before
+  struct BedSlot {
+    uint8_t* raw = nullptr; int64_t cap = 0;
+    hipEvent_t copied = nullptr, freed = nullptr;   // H2D done / the decode kernel that read the slot done
+    bool used = false;
+  };
+  BedSlot bs[2];
+  int bed_k = 0;
   uint32_t* thr_dev = nullptr;
   int64_t thr_cap = 0;
   int32_t* sample_pop = nullptr;   // [n]
@@ -1378,13 +1385,18 @@ void pcoa_destroy(pcoa_ctx* c) {
     if (sl.pin) (void)hipHostFree(sl.pin);
     if (sl.pin_offs) (void)hipHostFree(sl.pin_offs);
   }
+  for (auto& sl : c->bs) {
+    if (sl.copied) (void)hipEventDestroy(sl.copied);
+    if (sl.freed) (void)hipEventDestroy(sl.freed);
+    if (sl.raw) dev_free(sl.raw);
+  }
   if (c->csr_stream) (void)hipStreamDestroy(c->csr_stream);
   if (c->csr_flag) dev_free(c->csr_flag);
   if (c->csr_flag_host) (void)hipHostFree(c->csr_flag_host);
   if (c->fb_flags_host) (void)hipHostFree(c->fb_flags_host);
   if (c->hw) (void)hipHostFree(c->hw);
   if (c->ws.host_rec) (void)hipHostFree(c->ws.host_rec);
-  void* bufs[] = {c->s32, c->s64, c->zeros, c->err_flag, c->tile, c->csr_idx, c->csr_offs, c->thr_dev, c->bed_raw,
+  void* bufs[] = {c->s32, c->s64, c->zeros, c->err_flag, c->tile, c->csr_idx, c->csr_offs, c->thr_dev,
                   c->sample_pop, c->xfer, c->coll, c->fb_flags, c->strip_ws, c->strip_means, c->pack_buf, c->lanczos_ws, c->sym_part, c->ws.a, c->ws.d, c->ws.e, c->ws.tau, c->ws.q, c->ws.w, c->ws.lam,
                   c->ws.z, c->ws.wy, c->ws.scratch, c->ws.iscratch, c->row_sums, c->colmean, c->stats, c->nz,
                   c->out_dev};
@@ -1599,24 +1611,52 @@ int pcoa_accumulate_plink_bed(pcoa_ctx* c, const uint8_t* bed_rows, int64_t n_va
   const int64_t rows_cap = std::min<int64_t>(n_variants, (int64_t)1 << 17);
   int rc = ensure(c, &c->tile, &c->tile_elems, rows_cap * words);
   if (rc != PCOA_OK) return rc;
-  if (!is_device_ptr && (rc = ensure(c, &c->bed_raw, &c->bed_raw_cap, rows_cap * row_bytes)) != PCOA_OK) return rc;
+  if (!is_device_ptr) {
+    if (!c->csr_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->csr_stream, hipStreamNonBlocking));
+    for (auto& sl : c->bs)
+      if (!sl.copied) {
+        HIP_TRY(c, hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&sl.freed, hipEventDisableTiming));
+      }
+  }
   uint32_t* bits = reinterpret_cast<uint32_t*>(c->tile);
+  pcoa_ctx::BedSlot* last = nullptr;
   for (int64_t v0 = 0; v0 < n_variants; v0 += rows_cap) {
     const int64_t rows = std::min(rows_cap, n_variants - v0);
     const uint8_t* src = bed_rows + v0 * row_bytes;
+    pcoa_ctx::BedSlot* sl = nullptr;
     if (!is_device_ptr) {
-      HIP_TRY(c, hipMemcpyAsync(c->bed_raw, src, (size_t)(rows * row_bytes), hipMemcpyHostToDevice, c->stream));
-      src = c->bed_raw;
+      // r05: the copy travels on the copy stream into one of two slots -- beside the decode, transpose and contraction of
+      // the chunk (or the call) before; the r04 form queued everything on the ctx stream and drained it before returning
+      sl = &c->bs[c->bed_k++ & 1];
+      if (sl->used) HIP_TRY(c, hipEventSynchronize(sl->freed));  // the decode that read this slot is done
+      if (rows * row_bytes > sl->cap) {
+        if (sl->raw) dev_free(sl->raw);
+        sl->raw = nullptr;
+        sl->cap = 0;
+        HIP_TRY(c, dev_alloc((void**)&sl->raw, (size_t)(rows_cap * row_bytes), c->device));
+        sl->cap = rows_cap * row_bytes;
+      }
+      HIP_TRY(c, hipMemcpyAsync(sl->raw, src, (size_t)(rows * row_bytes), hipMemcpyHostToDevice, c->csr_stream));
+      HIP_TRY(c, hipEventRecord(sl->copied, c->csr_stream));
+      HIP_TRY(c, hipStreamWaitEvent(c->stream, sl->copied, 0));
+      src = sl->raw;
+      last = sl;
     }
     {
       ScopedTimer t(c, T_DENSIFY);
       HIP_TRY(c, launch_plink_bed_to_bits(src, row_bytes, rows, c->n, words, ref_is_a1 ? 1 : 0, bits, c->stream));
     }
+    if (sl) {
+      HIP_TRY(c, hipEventRecord(sl->freed, c->stream));
+      sl->used = true;
+    }
     if ((rc = gram_device_bits(c, bits, rows, words, false)) != PCOA_OK) return rc;
   }
-  // host rows are consumed, and the shared staging buffers are free for the next call, once the stream has drained; a
-  // device input (read by the decode kernel only) follows the lifetime rule of every device input
-  if (!is_device_ptr) HIP_TRY(c, hipStreamSynchronize(c->stream));
+  // host rows are consumed once their copy is done (copies complete in order on the copy stream); what the device still
+  // has to do with them is queued.  A device input (read by the decode kernel only) follows the lifetime rule of every
+  // device input
+  if (last) HIP_TRY(c, hipEventSynchronize(last->copied));
   return PCOA_OK;
 }
 
@@ -1751,7 +1791,7 @@ constexpr int64_t kCsrChunkEntries = (int64_t)8 << 20;
 
 int csr_setup(pcoa_ctx* c) {
   if (c->csr_flag) return PCOA_OK;
-  HIP_TRY(c, hipStreamCreateWithFlags(&c->csr_stream, hipStreamNonBlocking));
+  if (!c->csr_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->csr_stream, hipStreamNonBlocking));
   for (auto& sl : c->cs) {
     HIP_TRY(c, hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&sl.freed, hipEventDisableTiming));

@@ -619,7 +619,7 @@ void stream_plink_shard(const Conf& conf, const PlinkMeta& m, int g, int k, pcoa
   const size_t bpv = m.bpv, words = (m.n + 31) / 32;
   const bool ref_a1 = conf.plink_ref_allele == "a1";
   // buf: two page-locked blocks of --stream-rows rows (pcoa_host_alloc_pinned): the engine's DMA reads them at link speed
-  const unsigned read_threads = std::max(1u, std::min(4u, std::thread::hardware_concurrency() / (2u * (unsigned)k)));
+  const unsigned read_threads = std::max(1u, std::min(8u, std::thread::hardware_concurrency() / (2u * (unsigned)k)));
   std::vector<uint32_t> bits;
   if (conf.plink_decode == "host") bits.resize((size_t)block * words);
   auto read_block = [&](int64_t b0, int which) -> int64_t {  // returns kept rows, compacted to the front of buf[which]
