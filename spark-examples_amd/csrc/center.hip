@@ -185,11 +185,12 @@ hipError_t launch_col_means(const double* row_sums, int32_t n, double* cm, hipSt
 }
 
 hipError_t launch_center(const int32_t* s32, const int64_t* s64_or_null, int32_t n, double* row_sums,
-                         double* stats, int32_t* nz, double* b, hipStream_t stream) {
+                         double* stats, int32_t* nz, double* b, hipStream_t stream, bool row_sums_done) {
   // row_sums_i64 lives right behind stats[0..1] (the caller allocates stats as 2 + n doubles)
   int64_t* rs_i64 = reinterpret_cast<int64_t*>(stats + 2);
-  hipLaunchKernelGGL(row_sums_kernel, dim3((unsigned)n), dim3(256), 0, stream, s32, s64_or_null, n, row_sums,
-                     rs_i64);
+  if (!row_sums_done)   // (large N: launch_row_sums_sym has filled row_sums / rs_i64 from the upper triangle)
+    hipLaunchKernelGGL(row_sums_kernel, dim3((unsigned)n), dim3(256), 0, stream, s32, s64_or_null, n, row_sums,
+                       rs_i64);
   hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(256), 0, stream, rs_i64, n, stats, nz);
   if (b) {
     hipLaunchKernelGGL(center_kernel, dim3((unsigned)n), dim3(256), 0, stream, s32, s64_or_null, n, row_sums, stats,

@@ -354,33 +354,42 @@ __device__ __forceinline__ void symv_sym_tile_body(const int32_t* __restrict__ s
   }
 }
 
-// Four instantiations, each with its own register allocation: interior tiles (no masks) and the tiles of the last block
-// column / row when N is not a multiple of 1024 (EDGE), above the diagonal and on it.  nbi = block columns that lie wholly
-// inside N.  <false, false>: one workgroup per tile bi < bj < nbi, enumerated row by row; <false, true>: bj = nb - 1,
-// bi = blockIdx.x; <true, false>: bi = bj = blockIdx.x; <true, true>: the corner tile.
-template <bool DIAG, bool EDGE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(64)))  // (counts halves of the unified file: 128 registers) four workgroups per CU
+// One launch for all tiles (r05: as four launches the 97 diagonal tiles, the 97 tiles of the last block column and the corner
+// ran one kind after the other behind the interior tiles -- 0.8 ms of a 4.2-ms mat-vec at N = 100,000).  The four bodies --
+// interior tiles (no masks) and the tiles of the last block column / row when N is not a multiple of 1024 (EDGE), above the
+// diagonal and on it -- are branches of one kernel (120 registers: four workgroups per CU); the few masked tiles come FIRST
+// in the block order so that they run beside the interior ones instead of behind them.  nbi = block columns wholly inside N.
+// blockIdx.x: [corner (nb - nbi)] [diagonal nbi] [last block column (nb - nbi) * (nb - 1)] [interior nbi (nbi - 1) / 2, row by row]
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(64)))  // (counts halves of the unified file: 128 registers)
 void symv_sym_tiles_kernel(const int32_t* __restrict__ s32, int n, int nb, int nbi,
                            const double* __restrict__ cm, const double* __restrict__ stats,
                            const double* __restrict__ x, double* __restrict__ part) {
   __shared__ double xs[SYT], ms[SYT];  // 16 KiB: x_i and rowMean_i of the tile's rows
   __shared__ double rs[2][SYT];        // 16 KiB: the row sums over the two column halves
-  int bi, bj;
-  if (DIAG) {
-    bi = bj = EDGE ? nb - 1 : (int)blockIdx.x;
-  } else if (EDGE) {
-    bi = blockIdx.x;
-    bj = nb - 1;
-  } else {
-    int t = blockIdx.x;
-    bi = 0;
-    while (t >= nbi - 1 - bi) {
-      t -= nbi - 1 - bi;
-      ++bi;
-    }
-    bj = bi + 1 + t;
+  const double mmean = stats[1];
+  int t = blockIdx.x;
+  const int edge = nb - nbi;           // 0 or 1
+  if (t < edge) {
+    symv_sym_tile_body<true, true>(s32, n, nb, cm, mmean, x, part, nb - 1, nb - 1, xs, ms, rs);
+    return;
   }
-  symv_sym_tile_body<DIAG, EDGE>(s32, n, nb, cm, stats[1], x, part, bi, bj, xs, ms, rs);
+  t -= edge;
+  if (t < nbi) {
+    symv_sym_tile_body<true, false>(s32, n, nb, cm, mmean, x, part, t, t, xs, ms, rs);
+    return;
+  }
+  t -= nbi;
+  if (t < edge * (nb - 1)) {
+    symv_sym_tile_body<false, true>(s32, n, nb, cm, mmean, x, part, t, nb - 1, xs, ms, rs);
+    return;
+  }
+  t -= edge * (nb - 1);
+  int bi = 0;
+  while (t >= nbi - 1 - bi) {
+    t -= nbi - 1 - bi;
+    ++bi;
+  }
+  symv_sym_tile_body<false, false>(s32, n, nb, cm, mmean, x, part, bi, bi + 1 + t, xs, ms, rs);
 }
 
 // y_i = over the tiles of block row bi, left to right, their two row sums (column half 0, then 1) + over the tiles of
@@ -401,6 +410,125 @@ __global__ __launch_bounds__(256) void symv_sym_gather_kernel(const double* __re
   y[i] = acc;
 }
 
+// ---- large N: the exact row sums of S from its upper triangle (r05) ---------------------------------------------------------
+// computePca's first pass (VariantsPca.scala:206: rowSums) read all N^2 entries, one workgroup per row with 4-byte loads:
+// 11 ms of a 77-ms PCoA at N = 100,000.  S is symmetric and, once finalized, whole: an upper-triangular tile gives the row
+// sums of its rows AND -- as column sums -- the contributions to the rows of its block column, in int64 (exact, as the
+// reference's fold over integers below 2^53).  Same tiling, wave grid and prefetch as the mat-vec above; `part` is the
+// mat-vec's workspace read as int64.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int64_t dpp_add_i64(int64_t v) {
+  const int lo = (int)(uint32_t)v, hi = (int)(uint32_t)((uint64_t)v >> 32);
+  const uint32_t l2 = (uint32_t)__builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
+  const uint32_t h2 = (uint32_t)__builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+  return v + (int64_t)(((uint64_t)h2 << 32) | l2);
+}
+__device__ __forceinline__ int64_t wave_sum_i64_to_lane63(int64_t v) {
+  v = dpp_add_i64<0xB1, 0xF>(v);
+  v = dpp_add_i64<0x4E, 0xF>(v);
+  v = dpp_add_i64<0x141, 0xF>(v);
+  v = dpp_add_i64<0x140, 0xF>(v);
+  v = dpp_add_i64<0x142, 0xA>(v);
+  v = dpp_add_i64<0x143, 0xC>(v);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void rowsums_sym_tiles_kernel(const int32_t* __restrict__ s32, int n, int nb,
+                                                                int64_t* __restrict__ part) {
+  __shared__ int64_t rs[2][SYT];  // 16 KiB
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  int t = blockIdx.x, bi = 0;   // all tiles bi <= bj, row by row
+  while (t >= nb - bi) {
+    t -= nb - bi;
+    ++bi;
+  }
+  const int bj = bi + t;
+  const bool diag = bi == bj;
+  const int i0 = bi * SYT, j0 = bj * SYT;
+  const int jw = j0 + 512 * wc + 4 * lane;
+  const int rows = min(SYT, n - i0);
+  const bool full = j0 + SYT <= n;   // (rows < SYT only on the diagonal corner, where full is false as well)
+  int64_t cacc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) cacc[c] = 0;
+  const int32_t* base = s32 + (int64_t)i0 * n + jw;
+  auto load_row = [&](int r, int4 (&v)[2]) {
+    const int32_t* rowp = base + (int64_t)r * n;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      v[q] = (full || (r < rows && jw + 256 * q < n)) ? *reinterpret_cast<const int4*>(rowp + 256 * q) : make_int4(0, 0, 0, 0);
+  };
+  auto use_row = [&](int r, const int4 (&v)[2]) {
+    const int i = i0 + r;
+    int64_t racc = 0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int sv[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int j = jw + 256 * q + e;   // (entries at j >= n were loaded as 0)
+        racc += (!diag || j >= i) ? sv[e] : 0;
+        cacc[4 * q + e] += (!diag || j > i) ? sv[e] : 0;
+      }
+    }
+    racc = wave_sum_i64_to_lane63(racc);
+    if (lane == 63) rs[wc][r] = racc;
+  };
+  int4 buf[SYNB][2];
+  const int nr = rows > wr ? (rows - wr + 1) / 2 : 0;
+#pragma unroll
+  for (int b = 0; b < SYNB; ++b)
+    if (b < nr) load_row(wr + 2 * b, buf[b]);
+  int k = 0;
+  for (; k + 2 * SYNB <= nr; k += SYNB) {
+#pragma unroll
+    for (int b = 0; b < SYNB; ++b) {
+      use_row(wr + 2 * (k + b), buf[b]);
+      load_row(wr + 2 * (k + b + SYNB), buf[b]);
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < SYNB; ++b)
+    if (k + b < nr) {
+      use_row(wr + 2 * (k + b), buf[b]);
+      if (k + b + SYNB < nr) load_row(wr + 2 * (k + b + SYNB), buf[b]);
+    }
+  k += SYNB;
+#pragma unroll
+  for (int b = 0; b < SYNB; ++b)
+    if (k + b < nr) use_row(wr + 2 * (k + b), buf[b]);
+  int64_t* ptile = part + sym_tile_index(bi, bj, nb) * SYP;
+  int64_t* pcol = ptile + 2 * SYT + wr * SYT + 512 * wc + 4 * lane;
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pcol[256 * q + e] = cacc[4 * q + e];
+  __syncthreads();
+  for (int r = threadIdx.x; r < SYT; r += 256) {
+    ptile[r] = r < rows ? rs[0][r] : 0;
+    ptile[SYT + r] = r < rows ? rs[1][r] : 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void rowsums_sym_gather_kernel(const int64_t* __restrict__ part, int n, int nb,
+                                                                 double* __restrict__ row_sums, int64_t* __restrict__ row_sums_i64) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int bi = i / SYT, r = i - bi * SYT;
+  int64_t acc = 0;
+  for (int bj = bi; bj < nb; ++bj) {
+    const int64_t* t = part + sym_tile_index(bi, bj, nb) * SYP;
+    acc += t[r] + t[SYT + r];
+  }
+  for (int bk = 0; bk <= bi; ++bk) {
+    const int64_t* t = part + sym_tile_index(bk, bi, nb) * SYP + 2 * SYT;
+    acc += t[r] + t[SYT + r];
+  }
+  row_sums_i64[i] = acc;
+  row_sums[i] = (double)acc;
+}
+
 // doubles of workspace the symmetric form needs (0: not used at this N)
 size_t symv_sym_workspace_doubles_impl(int n) {
   const int64_t nb = (n + SYT - 1) / SYT;
@@ -417,18 +545,8 @@ void launch_symv(const EigWorkspace& ws, int n, const double* x, double* y, hipS
   } else if (ws.sym_part && (n & 3) == 0) {
     const int nb = (n + SYT - 1) / SYT;
     const int nbi = n / SYT;   // block columns wholly inside N (nb or nb - 1)
-    if (nbi > 1)
-      hipLaunchKernelGGL((symv_sym_tiles_kernel<false, false>), dim3((unsigned)((int64_t)nbi * (nbi - 1) / 2)), dim3(256), 0, stream,
-                         ws.s32, n, nb, nbi, ws.colmean, ws.stats, x, ws.sym_part);
-    if (nbi < nb && nb > 1)
-      hipLaunchKernelGGL((symv_sym_tiles_kernel<false, true>), dim3((unsigned)(nb - 1)), dim3(256), 0, stream, ws.s32, n, nb, nbi,
-                         ws.colmean, ws.stats, x, ws.sym_part);
-    if (nbi > 0)
-      hipLaunchKernelGGL((symv_sym_tiles_kernel<true, false>), dim3((unsigned)nbi), dim3(256), 0, stream, ws.s32, n, nb, nbi,
-                         ws.colmean, ws.stats, x, ws.sym_part);
-    if (nbi < nb)
-      hipLaunchKernelGGL((symv_sym_tiles_kernel<true, true>), dim3(1), dim3(256), 0, stream, ws.s32, n, nb, nbi, ws.colmean,
-                         ws.stats, x, ws.sym_part);
+    hipLaunchKernelGGL(symv_sym_tiles_kernel, dim3((unsigned)((int64_t)nb * (nb + 1) / 2)), dim3(256), 0, stream, ws.s32, n, nb, nbi,
+                       ws.colmean, ws.stats, x, ws.sym_part);
     hipLaunchKernelGGL(symv_sym_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ws.sym_part, n, nb, y);
   } else {
     hipLaunchKernelGGL(symv_centered_kernel<false>, dim3(rows4), dim3(256), 0, stream, ws.s32, ws.s64, n, ws.colmean,
@@ -587,6 +705,15 @@ __global__ __launch_bounds__(1024) void residual_kernel(const double* __restrict
 }  // namespace
 
 size_t symv_sym_workspace_doubles(int32_t n) { return symv_sym_workspace_doubles_impl(n); }
+hipError_t launch_row_sums_sym(const int32_t* s32, int32_t n, double* sym_part, double* row_sums, int64_t* row_sums_i64,
+                               hipStream_t stream) {
+  const int nb = (n + SYT - 1) / SYT;
+  int64_t* part = reinterpret_cast<int64_t*>(sym_part);
+  hipLaunchKernelGGL(rowsums_sym_tiles_kernel, dim3((unsigned)((int64_t)nb * (nb + 1) / 2)), dim3(256), 0, stream, s32, n, nb, part);
+  hipLaunchKernelGGL(rowsums_sym_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, part, n, nb, row_sums,
+                     row_sums_i64);
+  return hipGetLastError();
+}
 void launch_centred_matvec(const EigWorkspace& ws, int32_t n, const double* x, double* y, hipStream_t stream) { launch_symv(ws, n, x, y, stream); }
 
 size_t lanczos_workspace_doubles(int32_t n, int32_t k, int32_t mmax) {

@@ -1587,8 +1587,11 @@ int pcoa_accumulate_bits(pcoa_ctx* c, const uint32_t* bits, int64_t n_variants, 
   uint32_t* stage = reinterpret_cast<uint32_t*>(c->tile);
   for (int64_t v0 = 0; v0 < n_variants; v0 += rows_cap) {
     const int64_t rows = std::min(rows_cap, n_variants - v0);
-    HIP_TRY(c, hipMemcpy2DAsync(stage, (size_t)need_words * 4, bits + v0 * ld_words, (size_t)ld_words * 4,
-                                (size_t)need_words * 4, (size_t)rows, hipMemcpyHostToDevice, c->stream));
+    if (ld_words == need_words)   // dense rows: one linear copy (the strided form crosses the link at ~30 GB/s, this one at ~55)
+      HIP_TRY(c, hipMemcpyAsync(stage, bits + v0 * ld_words, (size_t)rows * (size_t)need_words * 4, hipMemcpyHostToDevice, c->stream));
+    else
+      HIP_TRY(c, hipMemcpy2DAsync(stage, (size_t)need_words * 4, bits + v0 * ld_words, (size_t)ld_words * 4,
+                                  (size_t)need_words * 4, (size_t)rows, hipMemcpyHostToDevice, c->stream));
     rc = gram_device_bits(c, stage, rows, need_words, false);
     if (rc != PCOA_OK) return rc;
   }
@@ -2092,8 +2095,6 @@ int pcoa_debug_centred_matvec(pcoa_ctx* c, const double* x, double* y, int upper
   if ((rc = check_device_flags(c)) != PCOA_OK) return rc;
   if ((rc = ensure_workspace(c, 1)) != PCOA_OK) return rc;
   const int32_t n = c->n;
-  HIP_TRY(c, launch_center(c->s32, c->s64, n, c->row_sums, c->stats, c->nz, nullptr, c->stream));
-  HIP_TRY(c, launch_col_means(c->row_sums, n, c->colmean, c->stream));
   EigWorkspace wl = c->ws;
   wl.a = nullptr;
   wl.s32 = c->s32;
@@ -2105,7 +2106,11 @@ int pcoa_debug_centred_matvec(pcoa_ctx* c, const double* x, double* y, int upper
     if (c->s64 || (n & 3)) return fail(c, PCOA_ERR_STATE, "the upper-triangle form needs N % 4 == 0 and no int64 part");
     if ((rc = ensure(c, &c->sym_part, &c->sym_part_cap, (int64_t)symv_sym_workspace_doubles(n))) != PCOA_OK) return rc;
     wl.sym_part = c->sym_part;
+    // the large-N form of computePca's first pass as well: row sums from the upper-triangular tiles
+    HIP_TRY(c, launch_row_sums_sym(c->s32, n, c->sym_part, c->row_sums, reinterpret_cast<int64_t*>(c->stats + 2), c->stream));
   }
+  HIP_TRY(c, launch_center(c->s32, c->s64, n, c->row_sums, c->stats, c->nz, nullptr, c->stream, upper_triangle_form != 0));
+  HIP_TRY(c, launch_col_means(c->row_sums, n, c->colmean, c->stream));
   double* xd = c->ws.q;   // two N-vectors of the eigensolver workspace
   double* yd = c->ws.w;
   HIP_TRY(c, hipMemcpyAsync(xd, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
@@ -2386,10 +2391,17 @@ int pcoa_compute(pcoa_ctx* c, int32_t num_pc, double* out_components, double* ou
   // matrix); B is only materialised for the dense solver.  PCOA_EXPLICIT_CENTER=1 restores the materialised form.
   const bool explicit_b = !try_lanczos || debug_knobs().explicit_center != 0;
   if (explicit_b && (rc = ensure_b(c)) != PCOA_OK) return rc;
+  // large N: row sums and mat-vec read only the upper triangle of S (half the bytes; rowsums_sym_tiles_kernel,
+  // symv_sym_tiles_kernel)
+  const int sym_min = debug_knobs().symv_sym_min_n > 0 ? debug_knobs().symv_sym_min_n : 16384;
+  const bool sym_form = !explicit_b && !c->s64 && n >= sym_min && (n & 3) == 0;
+  if (sym_form && (rc = ensure(c, &c->sym_part, &c->sym_part_cap, (int64_t)symv_sym_workspace_doubles(n))) != PCOA_OK) return rc;
   {
     ScopedTimer t(c, T_CENTER);
+    if (sym_form)
+      HIP_TRY(c, launch_row_sums_sym(c->s32, n, c->sym_part, c->row_sums, reinterpret_cast<int64_t*>(c->stats + 2), c->stream));
     HIP_TRY(c, launch_center(c->s32, c->s64, n, c->row_sums, c->stats, c->nz, explicit_b ? c->ws.a : nullptr,
-                             c->stream));
+                             c->stream, sym_form));
     HIP_TRY(c, launch_col_means(c->row_sums, n, c->colmean, c->stream));
   }
   c->ws.s32 = c->s32;
@@ -2412,13 +2424,7 @@ int pcoa_compute(pcoa_ctx* c, int32_t num_pc, double* out_components, double* ou
       ScopedTimer t(c, T_LANCZOS);
       EigWorkspace wl = c->ws;
       if (!b_ready) wl.a = nullptr;  // implicit form
-      // large N: the mat-vec reads only the upper triangle of S (half the bytes; symv_sym_tiles_kernel)
-      const int sym_min = debug_knobs().symv_sym_min_n > 0 ? debug_knobs().symv_sym_min_n : 16384;
-      wl.sym_part = nullptr;
-      if (!wl.a && !wl.s64 && n >= sym_min && (n & 3) == 0) {
-        if ((rc = ensure(c, &c->sym_part, &c->sym_part_cap, (int64_t)symv_sym_workspace_doubles(n))) != PCOA_OK) return rc;
-        wl.sym_part = c->sym_part;
-      }
+      wl.sym_part = (sym_form && !wl.a) ? c->sym_part : nullptr;
       HIP_TRY(c, lanczos_topk(wl, c->lanczos_ws, n, num_pc, mmax, 1e-11, sel.data(), &conv, &steps, c->stream));
     }
     c->lanczos_steps = steps;

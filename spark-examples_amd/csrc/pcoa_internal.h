@@ -153,7 +153,7 @@ hipError_t launch_synth_fill_f32(uint64_t seed, const uint32_t* thresholds_dev, 
 // cm[j] = rowSums(j) / N (the division center_kernel performs per entry, done once)
 hipError_t launch_col_means(const double* row_sums, int32_t n, double* cm, hipStream_t stream);
 hipError_t launch_center(const int32_t* s32, const int64_t* s64_or_null, int32_t n, double* row_sums,
-                         double* stats, int32_t* nz, double* b, hipStream_t stream);
+                         double* stats, int32_t* nz, double* b, hipStream_t stream, bool row_sums_done = false);
 
 // ---- strip owner reductions (center.hip): S is [n][cols], column jj = sample col0 + jj
 // ws: strip_ws_doubles(n, cols) doubles; the result (cols doubles) lands at ws[0 .. cols)
@@ -193,6 +193,10 @@ struct EigWorkspace {
   double* sym_part = nullptr;
 };
 size_t symv_sym_workspace_doubles(int32_t n);
+// exact row sums of a finalized (symmetric) int32 S from its upper-triangular tiles: half the bytes of launch_center's row
+// pass; sym_part = the mat-vec's workspace (symv_sym_workspace_doubles(n) doubles), n % 4 == 0
+hipError_t launch_row_sums_sym(const int32_t* s32, int32_t n, double* sym_part, double* row_sums, int64_t* row_sums_i64,
+                               hipStream_t stream);
 void launch_centred_matvec(const EigWorkspace& ws, int32_t n, const double* x, double* y, hipStream_t stream);  // one y = B x (test hook)
 hipError_t launch_tridiagonalize(const EigWorkspace& ws, int32_t n, hipStream_t stream);
 // eigenvalues with ascending indices idx[0..count) of T -> lam_out[0..count) (device)

@@ -529,6 +529,46 @@ def test_upper_triangle_form_of_the_centred_matvec_agrees_with_the_row_form_and_
             assert np.array_equal(eng.debug_centred_matvec(e, 1), b[:, k]) and np.array_equal(eng.debug_centred_matvec(e, 0), b[:, k])
 
 
+@pytest.mark.parametrize("n", [1024, 2504, 4100])
+def test_compute_pca_through_the_large_n_forms_matches_the_oracle(P, O, n):
+    """computePca as it runs from N = 16,384 -- exact row sums and the Lanczos mat-vec both from the upper-triangular tiles of S
+    (rowsums_sym_tiles_kernel, symv_sym_tiles_kernel; r05: all tile kinds in one launch) -- forced at small N in a fresh process
+    (PCOA_SYMV_SYM_MIN_N): eigenpairs within 1e-6 of the oracle's computePca, nonZeroRows equal (two callsets carry nothing),
+    and the same eigenpairs as the default forms to 1e-12."""
+    import tempfile
+    rng = np.random.default_rng(n + 5)
+    v = 900
+    pops = rng.integers(0, 3, size=n)
+    x8 = np.zeros((v, n), dtype=np.uint8)
+    for r in range(v):
+        k = rng.integers(0, 3)
+        x8[r] = rng.random(n) < np.where(pops == k, 0.45, 0.06)
+    x8[:, 7] = 0
+    x8[:, n - 1] = 0
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r);"
+            "from conftest import load_pkg; P = load_pkg(); x = np.load(sys.argv[1]);"
+            "e = P.PcoaEngine(x.shape[1]); e.accumulate_dense_u8(x); c, lam, nz = e.compute(2);"
+            "np.savez(sys.argv[2], c=c, lam=lam, nz=nz, s=e.gram(), method=e.timings()['eig_method'])") % (ROOT, os.path.join(ROOT, "tests"))
+    with tempfile.TemporaryDirectory() as td:
+        np.save(os.path.join(td, "x.npy"), x8)
+        res = {}
+        for tag, extra in (("large_n_forms", {"PCOA_SYMV_SYM_MIN_N": "1024"}), ("default", {})):
+            subprocess.check_call([sys.executable, "-c", code, os.path.join(td, "x.npy"), os.path.join(td, tag + ".npz")],
+                                  env=dict(os.environ, **extra))
+            res[tag] = np.load(os.path.join(td, tag + ".npz"))
+    got = res["large_n_forms"]
+    ref = O.compute_pca(got["s"], 2)
+    assert int(got["method"]) == 1, "the Lanczos path (the one with the large-N forms) must have run"
+    assert int(got["nz"]) == ref["nonzero_rows"] == n - 2
+    assert np.allclose(got["lam"], ref["eigenvalues"], rtol=1e-6)
+    for tag, other in (("oracle", ref["components"]), ("default forms", res["default"]["c"])):
+        for k in range(2):
+            a, b = got["c"][:, k], other[:, k]
+            if np.dot(a, b) < 0:
+                a = -a
+            assert np.linalg.norm(a - b) < (1e-6 if tag == "oracle" else 1e-12), (tag, k)
+
+
 def test_accumulation_is_additive_shard_invariant_and_resumable(P, O):
     rng = np.random.default_rng(11)
     n, v = 150, 900

@@ -79,3 +79,48 @@ feed("pinned, 8 threads copying", pins)
 stop = True
 for t in th:
     t.join()
+
+# the streaming reader's own pattern: while block b is fed from one page-locked buffer, 8 threads pread the next block out of the
+# page cache into the OTHER page-locked buffer
+path = "/tmp/bed_probe.bin"
+with open(path, "wb") as f:
+    for _ in range(4):
+        f.write(src.tobytes())
+fd = os.open(path, os.O_RDONLY)
+views = [memoryview((ctypes.c_ubyte * nbytes).from_address(p.value)).cast("B") for p in pins]
+
+
+def pread_into(which, nthreads=8):
+    per = (nbytes + nthreads - 1) // nthreads
+    def one(i):
+        lo, hi = i * per, min(nbytes, (i + 1) * per)
+        while lo < hi:
+            lo += os.preadv(fd, [views[which][lo:hi]], lo)
+    ts = [threading.Thread(target=one, args=(i,)) for i in range(nthreads)]
+    for t in ts:
+        t.start()
+    return ts
+
+
+for nthreads in (8, 4):
+    with P.PcoaEngine(n) as e:
+        for w in range(2):
+            lib.pcoa_accumulate_plink_bed(e._ctx, pins[w], rows, bpv, 0, 0)
+        e.finalize(); e.sync(); e.reset(); e.sync()
+        per, rd = [], []
+        t0 = time.perf_counter()
+        for b in range(blocks):
+            ts = pread_into((b & 1) ^ 1, nthreads)
+            t1 = time.perf_counter()
+            assert lib.pcoa_accumulate_plink_bed(e._ctx, pins[b & 1], rows, bpv, 0, 0) == 0
+            t2 = time.perf_counter()
+            for t in ts:
+                t.join()
+            per.append(t2 - t1); rd.append(time.perf_counter() - t2)
+        e.finalize(); e.sync()
+        dt = time.perf_counter() - t0
+        per, rd = np.array(per) * 1e3, np.array(rd) * 1e3
+        print("fed beside %d pread threads    %d blocks: %.1f M variants/s, feed call median %.3f ms (max %.3f), read not hidden median %.3f ms" %
+              (nthreads, blocks, blocks * rows / dt / 1e6, np.median(per), per.max(), np.median(rd)), flush=True)
+os.close(fd)
+os.unlink(path)

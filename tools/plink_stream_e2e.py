@@ -3,7 +3,7 @@
 written as .bed/.bim/.fam (genotype codes drawn on the GPU, ~14 % carriers), then
   variants_pca_driver --input-path <prefix>.bed [--gpus k --gpu-map ...]
 with the device decode and with the host decode; prints each run's own report (variants/s of ingest -> S, peak RSS) and checks
-that both give the same S and the same coordinates.  usage: tools/plink_stream_e2e.py [V] [N] [dir]"""
+that both give the same S and the same coordinates.  usage: tools/plink_stream_e2e.py [V] [N] [dir] ["extra host args"]"""
 import os, subprocess, sys, time
 import numpy as np
 import torch
@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 v = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 2504
 d = sys.argv[3] if len(sys.argv) > 3 else "/tmp/plink_e2e"
+host_extra = sys.argv[4].split() if len(sys.argv) > 4 else []
 os.makedirs(d, exist_ok=True)
 prefix = os.path.join(d, "cohort")
 bpv = (n + 3) // 4
@@ -40,7 +41,7 @@ outs = {}
 for tag, extra in (("device decode", []), ("device decode again (page cache warm)", []), ("host decode", ["--plink-decode", "host"]),
                    ("two engines on one GPU", ["--gpus", "2", "--gpu-map", "0,0"])):
     t1 = time.perf_counter()
-    res = subprocess.run([exe, "--input-path", prefix + ".bed", "--all-references", "--dump-similarity", os.path.join(d, "s.bin")] + extra,
+    res = subprocess.run([exe, "--input-path", prefix + ".bed", "--all-references", "--dump-similarity", os.path.join(d, "s.bin")] + host_extra + extra,
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
     wall = time.perf_counter() - t1
     assert res.returncode == 0, res.stderr
