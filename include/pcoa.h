@@ -285,8 +285,14 @@ int pcoa_accumulate_bits(pcoa_ctx* ctx, const uint32_t* bits, int64_t n_variants
  * hasVariation, VariantsPca.scala:56-60 -- iff its code is 10 or the homozygous NON-reference one: 00 when A2 is the reference
  * allele (plink --keep-allele-order / plink2 --make-bed; ref_is_a1 = 0), 11 when A1 is (ref_is_a1 = 1); a missing call
  * carries nothing.  The decode runs on the device (a host only reads the file: 626 B per variant at N = 2504), then the
- * bitset path of pcoa_accumulate_bits.  Host or device pointer as there.
+ * bitset path of pcoa_accumulate_bits.  is_device_ptr: 0 host rows (consumed when the call returns), 1 device rows (lifetime
+ * rule of every device input), PCOA_BED_HOST_ASYNC (r05) host rows in PAGE-LOCKED memory (pcoa_host_alloc_pinned) that the
+ * call only QUEUES: it returns while the copy may still be running, so a host that rotates >= 3 blocks keeps the link busy
+ * while it reads the next block.  The rows of such a call must stay unmodified until the SECOND later call of this
+ * function on the same ctx has returned (host rows travel through two device slots: a call that takes a slot first waits
+ * for the decode of the call that used it last) or until any synchronising call (pcoa_sync, pcoa_gram_finalize, ..).
  * Replaces: the same RDD[Seq[Int]] rows (getCallsRdd, VariantsPca.scala:153-168) for a cohort stored as a PLINK fileset. */
+#define PCOA_BED_HOST_ASYNC 2
 int pcoa_accumulate_plink_bed(pcoa_ctx* ctx, const uint8_t* bed_rows, int64_t n_variants, int64_t row_bytes, int ref_is_a1,
                               int is_device_ptr);
 

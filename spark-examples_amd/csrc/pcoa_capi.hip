@@ -1609,6 +1609,10 @@ int pcoa_accumulate_plink_bed(pcoa_ctx* c, const uint8_t* bed_rows, int64_t n_va
   if (row_bytes < ((int64_t)c->n + 3) / 4) return fail(c, PCOA_ERR_INVALID_ARG, "row_bytes must be >= ceil(n_samples / 4)");
   if (!c->use_i8)
     return fail(c, PCOA_ERR_INVALID_ARG, "the PLINK boundary needs a packed-operand engine (not PCOA_FLAG_GRAM_F32_MFMA)");
+  if (is_device_ptr != 0 && is_device_ptr != 1 && is_device_ptr != PCOA_BED_HOST_ASYNC)
+    return fail(c, PCOA_ERR_INVALID_ARG, "is_device_ptr must be 0, 1 or PCOA_BED_HOST_ASYNC");
+  const bool host_async = is_device_ptr == PCOA_BED_HOST_ASYNC;
+  if (host_async) is_device_ptr = 0;
   if (n_variants == 0) return PCOA_OK;
   const int64_t words = ((int64_t)c->n + 31) / 32;
   const int64_t rows_cap = std::min<int64_t>(n_variants, (int64_t)1 << 17);
@@ -1659,7 +1663,7 @@ int pcoa_accumulate_plink_bed(pcoa_ctx* c, const uint8_t* bed_rows, int64_t n_va
   // host rows are consumed once their copy is done (copies complete in order on the copy stream); what the device still
   // has to do with them is queued.  A device input (read by the decode kernel only) follows the lifetime rule of every
   // device input
-  if (last) HIP_TRY(c, hipEventSynchronize(last->copied));
+  if (last && !host_async) HIP_TRY(c, hipEventSynchronize(last->copied));
   return PCOA_OK;
 }
 

@@ -226,9 +226,16 @@ class PcoaEngine(object):
         ldv = a.shape[1] if ld_words is None else int(ld_words)
         self._check(self._lib.pcoa_accumulate_bits(self._ctx, _ptr(a), nv, ldv, 0))
 
-    def accumulate_plink_bed(self, rows, ref_is_a1=False):
+    def accumulate_plink_bed(self, rows, ref_is_a1=False, asynchronous=False):
         """Raw variant-major PLINK .bed rows, numpy uint8 [V][row_bytes] (host) or a torch uint8 CUDA tensor: decoded on the
-        device (pcoa_accumulate_plink_bed)."""
+        device (pcoa_accumulate_plink_bed).  asynchronous=True: a PINNED torch uint8 CPU tensor that is only queued
+        (PCOA_BED_HOST_ASYNC): it must stay unmodified until the second later call has returned, or the next sync()."""
+        if asynchronous:
+            import torch  # plumbing only
+            assert rows.dtype == torch.uint8 and rows.dim() == 2 and rows.stride(1) == 1 and rows.is_pinned()
+            self._check(self._lib.pcoa_accumulate_plink_bed(self._ctx, ctypes.c_void_p(rows.data_ptr()), int(rows.shape[0]),
+                                                            int(rows.stride(0)), int(bool(ref_is_a1)), L.PCOA_BED_HOST_ASYNC))
+            return
         if hasattr(rows, "data_ptr") and getattr(rows, "is_cuda", False):
             import torch  # plumbing only
             assert rows.dtype == torch.uint8 and rows.dim() == 2 and rows.stride(1) == 1

@@ -70,7 +70,7 @@ struct Conf {  // PcaConf / GenomicsConf (GenomicsConf.scala:31-101), same flag 
   std::vector<int> gpu_map;           // --gpu-map a,b,..: device ordinal of each engine (default: --gpu, --gpu + 1, ..)
   std::string reduce = "auto";        // --reduce auto|rccl|peer: all-reduce over RCCL / peer copies + int64 adds
   std::string plink_decode = "device";  // --plink-decode device|host: where the 2-bit codes become carrier bits
-  long stream_rows = 65536;           // --stream-rows: variants per block of the streaming PLINK reader
+  long stream_rows = 131072;          // --stream-rows: variants per block of the streaming PLINK reader (three blocks are page-locked: 246 MB at N = 2504)
   bool no_stream = false;             // --no-stream: PLINK through the in-memory path of r03 (carrier lists)
 };
 
@@ -599,6 +599,54 @@ void bed_row_to_bits(const unsigned char* row, size_t bpv, size_t n, bool ref_a1
   }
 }
 
+// A few reader threads that live as long as a shard is streamed (r05: eight threads created per 41-MB block cost a quarter of
+// the block's feed time): run(job) hands job(t) to every thread t and returns when all are done.
+class ReaderPool {
+ public:
+  explicit ReaderPool(unsigned n) {
+    for (unsigned t = 0; t < n; ++t)
+      th_.emplace_back([this, t] {
+        int seen = 0;
+        for (;;) {
+          std::unique_lock<std::mutex> lk(mu_);
+          cv_job_.wait(lk, [&] { return stop_ || gen_ != seen; });
+          if (stop_) return;
+          seen = gen_;
+          const std::function<void(unsigned)> j = job_;
+          lk.unlock();
+          j(t);
+          lk.lock();
+          if (--pending_ == 0) cv_done_.notify_all();
+        }
+      });
+  }
+  ~ReaderPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+    }
+    cv_job_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  unsigned size() const { return (unsigned)th_.size(); }
+  void run(const std::function<void(unsigned)>& job) {
+    std::unique_lock<std::mutex> lk(mu_);
+    job_ = job;
+    pending_ = (int)th_.size();
+    ++gen_;
+    cv_job_.notify_all();
+    cv_done_.wait(lk, [&] { return pending_ == 0; });
+  }
+
+ private:
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable cv_job_, cv_done_;
+  std::function<void(unsigned)> job_;
+  int gen_ = 0, pending_ = 0;
+  bool stop_ = false;
+};
+
 struct StreamStats {
   std::mutex mu;
   int64_t variants = 0;
@@ -607,10 +655,10 @@ struct StreamStats {
 
 // Shard g of a PLINK fileset, streamed: blocks of --stream-rows variants are read (pread, own descriptor) one block ahead of
 // the engine, rows outside --references squeezed out, and handed over as they lie in the file (device decode) or as bitsets
-// decoded here.  Never more than two blocks in memory per engine (VariantsRDD.compute is an iterator, rdd/VariantsRDD.scala:
+// decoded here.  Never more than three blocks in memory per engine (VariantsRDD.compute is an iterator, rdd/VariantsRDD.scala:
 // 205-235; the reference never holds a data set either).
 void stream_plink_shard(const Conf& conf, const PlinkMeta& m, int g, int k, pcoa_ctx* ctx, StreamStats* st,
-                        unsigned char* const (&buf)[2]) {
+                        unsigned char* const (&buf)[3]) {
   int64_t r0, r1;
   shard_range(g, k, (int64_t)m.keep.size(), &r0, &r1);
   const int fd = ::open((m.prefix + ".bed").c_str(), O_RDONLY);
@@ -618,8 +666,9 @@ void stream_plink_shard(const Conf& conf, const PlinkMeta& m, int g, int k, pcoa
   const int64_t block = conf.stream_rows;
   const size_t bpv = m.bpv, words = (m.n + 31) / 32;
   const bool ref_a1 = conf.plink_ref_allele == "a1";
-  // buf: two page-locked blocks of --stream-rows rows (pcoa_host_alloc_pinned): the engine's DMA reads them at link speed
+  // buf: three page-locked blocks of --stream-rows rows (pcoa_host_alloc_pinned): the engine's DMA reads them at link speed
   const unsigned read_threads = std::max(1u, std::min(8u, std::thread::hardware_concurrency() / (2u * (unsigned)k)));
+  ReaderPool pool(read_threads > 1 ? read_threads : 0);
   std::vector<uint32_t> bits;
   if (conf.plink_decode == "host") bits.resize((size_t)block * words);
   auto read_block = [&](int64_t b0, int which) -> int64_t {  // returns kept rows, compacted to the front of buf[which]
@@ -635,13 +684,11 @@ void stream_plink_shard(const Conf& conf, const PlinkMeta& m, int g, int k, pcoa
     if (read_threads <= 1 || want < ((size_t)8 << 20)) {
       read_range(0, want);
     } else {
-      std::vector<std::thread> rt;
       const size_t per = (want + read_threads - 1) / read_threads;
-      for (unsigned t = 0; t < read_threads; ++t) {
+      pool.run([&](unsigned t) {
         const size_t lo = std::min(want, per * t), hi = std::min(want, per * (t + 1));
-        if (hi > lo) rt.emplace_back(read_range, lo, hi);
-      }
-      for (auto& x : rt) x.join();
+        if (hi > lo) read_range(lo, hi);
+      });
     }
     int64_t kept = 0;
     for (int64_t r = 0; r < rows; ++r) {
@@ -655,6 +702,31 @@ void stream_plink_shard(const Conf& conf, const PlinkMeta& m, int g, int k, pcoa
   int64_t total = 0;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto secs = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
+  if (conf.plink_decode != "host") {
+    // Device decode (r05): the feed call only QUEUES the block (PCOA_BED_HOST_ASYNC) and this thread reads the next one
+    // meanwhile -- three blocks rotate, so the block being rewritten was handed over three calls ago (pcoa.h asks for
+    // two).  The link idles only while a read takes longer than the copy beside it.
+    auto t0 = now();
+    int64_t kept = r0 < r1 ? read_block(r0, 0) : 0;
+    read_s += secs(t0, now());
+    int i = 0;
+    for (int64_t b0 = r0; b0 < r1; b0 += block, ++i) {
+      auto t1 = now();
+      if (kept > 0) {
+        check(ctx, pcoa_accumulate_plink_bed(ctx, buf[i % 3], kept, (int64_t)bpv, ref_a1 ? 1 : 0, PCOA_BED_HOST_ASYNC), "getSimilarityMatrix");
+        total += kept;
+      }
+      auto t2 = now();
+      feed_s += secs(t1, t2);
+      if (b0 + block < r1) {
+        kept = read_block(b0 + block, (i + 1) % 3);
+        read_s += secs(t2, now());
+      }
+    }
+    auto t3 = now();
+    check(ctx, pcoa_sync(ctx), "getSimilarityMatrix");  // the blocks are released by the caller next
+    feed_s += secs(t3, now());
+  } else {
   int which = 0;
   std::future<int64_t> next;
   auto t0 = now();
@@ -665,19 +737,15 @@ void stream_plink_shard(const Conf& conf, const PlinkMeta& m, int g, int k, pcoa
     if (b1 < r1) next = std::async(std::launch::async, read_block, b1, which ^ 1);  // the next block is read beside this one's feed
     auto t1 = now();
     if (kept > 0) {
-      if (conf.plink_decode == "host") {
-        const unsigned nt = std::max(1u, std::min<unsigned>(conf.ingest_threads > 0 ? (unsigned)conf.ingest_threads : std::thread::hardware_concurrency(), 16u) / (unsigned)k);
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; ++t)
-          th.emplace_back([&, t] {
-            for (int64_t r = t; r < kept; r += nt)
-              bed_row_to_bits(buf[which] + (size_t)r * bpv, bpv, m.n, ref_a1, bits.data() + (size_t)r * words, words);
-          });
-        for (auto& x : th) x.join();
-        check(ctx, pcoa_accumulate_bits(ctx, bits.data(), kept, (int64_t)words, 0), "getSimilarityMatrix");
-      } else {
-        check(ctx, pcoa_accumulate_plink_bed(ctx, buf[which], kept, (int64_t)bpv, ref_a1 ? 1 : 0, 0), "getSimilarityMatrix");
-      }
+      const unsigned nt = std::max(1u, std::min<unsigned>(conf.ingest_threads > 0 ? (unsigned)conf.ingest_threads : std::thread::hardware_concurrency(), 16u) / (unsigned)k);
+      std::vector<std::thread> th;
+      for (unsigned t = 0; t < nt; ++t)
+        th.emplace_back([&, t] {
+          for (int64_t r = t; r < kept; r += nt)
+            bed_row_to_bits(buf[which] + (size_t)r * bpv, bpv, m.n, ref_a1, bits.data() + (size_t)r * words, words);
+        });
+      for (auto& x : th) x.join();
+      check(ctx, pcoa_accumulate_bits(ctx, bits.data(), kept, (int64_t)words, 0), "getSimilarityMatrix");
       total += kept;
     }
     feed_s += secs(t1, now());
@@ -687,6 +755,7 @@ void stream_plink_shard(const Conf& conf, const PlinkMeta& m, int g, int k, pcoa
       read_s += secs(t2, now());  // (only what the feed did not hide)
       which ^= 1;
     }
+  }
   }
   ::close(fd);
   std::lock_guard<std::mutex> lk(st->mu);
@@ -699,7 +768,7 @@ void stream_plink_shard(const Conf& conf, const PlinkMeta& m, int g, int k, pcoa
 // a device of its own and the collective runtime binds; else peer copies + int64 adds (pcoa_gram_reduce_from), which also work
 // with several engines on ONE device (--gpu-map 0,0: the way this path is tested on a single-GPU box).
 pcoa_ctx* run_engines(const Conf& conf, int32_t n, const std::function<void(int, int, pcoa_ctx*)>& feed, std::string* how,
-                      double* feed_seconds, const std::function<void()>& prepare) {
+                      double* feed_seconds, const std::function<void(const std::vector<pcoa_ctx*>&)>& prepare) {
   const int k = conf.gpus;
   std::vector<pcoa_ctx*> ctx((size_t)k, nullptr);
   for (int g = 0; g < k; ++g)
@@ -720,7 +789,7 @@ pcoa_ctx* run_engines(const Conf& conf, int32_t n, const std::function<void(int,
   }
   std::vector<int> rccl_rc((size_t)k, PCOA_OK);
   std::vector<std::thread> th;
-  prepare();  // (what the feed needs once a HIP device is up: the pinned blocks of the streaming reader)
+  prepare(ctx);  // (what the feed needs once a HIP device is up: the pinned blocks of the streaming reader, their first use)
   const auto t_feed = std::chrono::steady_clock::now();  // engines exist: from here to the reduced S is the job
   for (int g = 0; g < k; ++g)
     th.emplace_back([&, g] {
@@ -873,12 +942,12 @@ int main(int argc, char** argv) {
       }
   }
   StreamStats stream_stats;
-  std::vector<unsigned char*> blocks;  // page-locked blocks of the streaming reader, two per engine (filled by `prepare`)
+  std::vector<unsigned char*> blocks;  // page-locked blocks of the streaming reader, three per engine (filled by `prepare`)
   // engine g of k takes the contiguous range shard_range(g, k, rows) -- the reference's partitions (:184)
   std::function<void(int, int, pcoa_ctx*)> feed = [&](int g, int k, pcoa_ctx* ctx) {
     if (stream_plink) {
-      unsigned char* const two[2] = {blocks[(size_t)(2 * g)], blocks[(size_t)(2 * g + 1)]};
-      stream_plink_shard(conf, plink, g, k, ctx, &stream_stats, two);
+      unsigned char* const three[3] = {blocks[(size_t)(3 * g)], blocks[(size_t)(3 * g + 1)], blocks[(size_t)(3 * g + 2)]};
+      stream_plink_shard(conf, plink, g, k, ctx, &stream_stats, three);
       return;
     }
     int64_t ra, rb;
@@ -905,12 +974,26 @@ int main(int argc, char** argv) {
   };
   std::string how;
   double feed_s = 0;
-  auto prepare = [&] {
+  auto prepare = [&](const std::vector<pcoa_ctx*>& engines) {
     if (!stream_plink) return;
-    for (int q = 0; q < 2 * conf.gpus; ++q) {
+    for (int q = 0; q < 3 * conf.gpus; ++q) {
       void* b = nullptr;
       if (pcoa_host_alloc_pinned((size_t)conf.stream_rows * plink.bpv, &b) != PCOA_OK) die("pcoa_host_alloc_pinned failed");
       blocks.push_back(static_cast<unsigned char*>(b));
+    }
+    if (conf.plink_decode == "host") return;
+    // the rest of an executor's warm-up (pcoa_reserve covers the operand buffers): one block of homozygous-reference rows
+    // through the device decode -- staging slots, the bitset tile and the kernels' code objects exist before the first real
+    // block; it adds nothing to S and is taken out of the books again
+    const bool ref_a1 = conf.plink_ref_allele == "a1";
+    for (int g = 0; g < conf.gpus; ++g) {
+      unsigned char* b = blocks[(size_t)(3 * g)];
+      std::memset(b, ref_a1 ? 0x00 : 0xFF, (size_t)conf.stream_rows * plink.bpv);
+      pcoa_ctx* e = engines[(size_t)g];
+      check(e, pcoa_accumulate_plink_bed(e, b, conf.stream_rows, (int64_t)plink.bpv, ref_a1 ? 1 : 0, 0), "warm-up");
+      check(e, pcoa_sync(e), "warm-up");
+      check(e, pcoa_reset(e), "warm-up");
+      check(e, pcoa_reset_timings(e), "warm-up");
     }
   };
   pcoa_ctx* ctx = run_engines(conf, n, feed, &how, &feed_s, prepare);
@@ -921,7 +1004,7 @@ int main(int argc, char** argv) {
     getrusage(RUSAGE_SELF, &ru);
     if (stream_plink)
       std::fprintf(stderr, "Streamed %lld variants x %d samples from %s.bed in %.3f s = %.1f M variants/s (ingest -> reduced S, engines "
-                   "already created; %s; slowest shard: read not hidden %.3f s, decode + accumulate %.3f s; %s decode); peak RSS %.0f MB\n", (long long)stream_stats.variants, n,
+                   "already created; %s; slowest shard: reads %.3f s, feed calls %.3f s; %s decode); peak RSS %.0f MB\n", (long long)stream_stats.variants, n,
                    plink.prefix.c_str(), feed_s, stream_stats.variants / feed_s / 1e6, how.c_str(), stream_stats.read_s,
                    stream_stats.feed_s, conf.plink_decode.c_str(), ru.ru_maxrss / 1024.0);
     else

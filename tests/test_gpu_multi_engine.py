@@ -110,3 +110,27 @@ def test_peer_reduction_and_device_side_bed_decode_through_the_c_abi(P):
                 a.reduce_from(b)
             with pytest.raises(P.PcoaError):
                 a.reduce_from(a)
+
+
+def test_queued_bed_blocks_from_three_rotating_page_locked_buffers(P):
+    """PCOA_BED_HOST_ASYNC (r05, the streaming host's feed): the call only queues a page-locked block; three buffers rotate and
+    each is REWRITTEN as soon as the rule of pcoa.h allows (after the second later call has returned) -- so a copy that had
+    not finished by then would contract the wrong bytes.  Blocks of different sizes, one of them larger than the 2^17-row
+    chunk of the device slots; the result must equal the bitset path on the same bytes."""
+    import torch
+    rng = np.random.default_rng(9)
+    n = 2504
+    bpv = (n + 3) // 4
+    sizes = [5000, 70000, 131072 + 777, 1, 4096, 65536, 33333, 9]
+    blocks = [rng.integers(0, 256, size=(v, bpv), dtype=np.uint8) | np.uint8(0xAA) for v in sizes]   # codes 10 / 11: sparse carriers
+    pins = [torch.empty((max(sizes), bpv), dtype=torch.uint8).pin_memory() for _ in range(3)]
+    with P.PcoaEngine(n) as ref, P.PcoaEngine(n) as eng:
+        for i, blk in enumerate(blocks):
+            ref.accumulate_plink_bed(blk)
+            buf = pins[i % 3]
+            buf[:blk.shape[0]].copy_(torch.from_numpy(blk))          # overwrites the block handed over three calls ago
+            eng.accumulate_plink_bed(buf[:blk.shape[0]], asynchronous=True)
+        eng.sync()
+        for b in pins:
+            b.fill_(0xFF)                                            # after a synchronising call the buffers are the caller's
+        assert np.array_equal(eng.gram(), ref.gram())
