@@ -287,7 +287,7 @@ int pcoa_accumulate_bits(pcoa_ctx* ctx, const uint32_t* bits, int64_t n_variants
  * carries nothing.  The decode runs on the device (a host only reads the file: 626 B per variant at N = 2504), then the
  * bitset path of pcoa_accumulate_bits.  is_device_ptr: 0 host rows (consumed when the call returns), 1 device rows (lifetime
  * rule of every device input), PCOA_BED_HOST_ASYNC (r05) host rows in PAGE-LOCKED memory (pcoa_host_alloc_pinned) that the
- * call only QUEUES: it returns while the copy may still be running, so a host that rotates >= 3 blocks keeps the link busy
+ * call only QUEUES: it returns while the copy may still be running, so a host that rotates a few blocks keeps the link busy
  * while it reads the next block.  The rows of such a call must stay unmodified until the SECOND later call of this
  * function on the same ctx has returned (host rows travel through two device slots: a call that takes a slot first waits
  * for the decode of the call that used it last) or until any synchronising call (pcoa_sync, pcoa_gram_finalize, ..).

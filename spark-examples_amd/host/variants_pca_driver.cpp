@@ -43,6 +43,7 @@
 #include <future>
 #include <mutex>
 #include <condition_variable>
+#include <deque>
 #include <sys/resource.h>
 
 extern char** environ;
@@ -70,7 +71,7 @@ struct Conf {  // PcaConf / GenomicsConf (GenomicsConf.scala:31-101), same flag 
   std::vector<int> gpu_map;           // --gpu-map a,b,..: device ordinal of each engine (default: --gpu, --gpu + 1, ..)
   std::string reduce = "auto";        // --reduce auto|rccl|peer: all-reduce over RCCL / peer copies + int64 adds
   std::string plink_decode = "device";  // --plink-decode device|host: where the 2-bit codes become carrier bits
-  long stream_rows = 131072;          // --stream-rows: variants per block of the streaming PLINK reader (three blocks are page-locked: 246 MB at N = 2504)
+  long stream_rows = 131072;          // --stream-rows: variants per block of the streaming PLINK reader (four blocks are page-locked: 328 MB at N = 2504)
   bool no_stream = false;             // --no-stream: PLINK through the in-memory path of r03 (carrier lists)
 };
 
@@ -655,10 +656,10 @@ struct StreamStats {
 
 // Shard g of a PLINK fileset, streamed: blocks of --stream-rows variants are read (pread, own descriptor) one block ahead of
 // the engine, rows outside --references squeezed out, and handed over as they lie in the file (device decode) or as bitsets
-// decoded here.  Never more than three blocks in memory per engine (VariantsRDD.compute is an iterator, rdd/VariantsRDD.scala:
+// decoded here.  Never more than four blocks in memory per engine (VariantsRDD.compute is an iterator, rdd/VariantsRDD.scala:
 // 205-235; the reference never holds a data set either).
 void stream_plink_shard(const Conf& conf, const PlinkMeta& m, int g, int k, pcoa_ctx* ctx, StreamStats* st,
-                        unsigned char* const (&buf)[3]) {
+                        unsigned char* const (&buf)[4]) {
   int64_t r0, r1;
   shard_range(g, k, (int64_t)m.keep.size(), &r0, &r1);
   const int fd = ::open((m.prefix + ".bed").c_str(), O_RDONLY);
@@ -666,7 +667,7 @@ void stream_plink_shard(const Conf& conf, const PlinkMeta& m, int g, int k, pcoa
   const int64_t block = conf.stream_rows;
   const size_t bpv = m.bpv, words = (m.n + 31) / 32;
   const bool ref_a1 = conf.plink_ref_allele == "a1";
-  // buf: three page-locked blocks of --stream-rows rows (pcoa_host_alloc_pinned): the engine's DMA reads them at link speed
+  // buf: four page-locked blocks of --stream-rows rows (pcoa_host_alloc_pinned): the engine's DMA reads them at link speed
   const unsigned read_threads = std::max(1u, std::min(8u, std::thread::hardware_concurrency() / (2u * (unsigned)k)));
   ReaderPool pool(read_threads > 1 ? read_threads : 0);
   std::vector<uint32_t> bits;
@@ -703,26 +704,81 @@ void stream_plink_shard(const Conf& conf, const PlinkMeta& m, int g, int k, pcoa
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto secs = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
   if (conf.plink_decode != "host") {
-    // Device decode (r05): the feed call only QUEUES the block (PCOA_BED_HOST_ASYNC) and this thread reads the next one
-    // meanwhile -- three blocks rotate, so the block being rewritten was handed over three calls ago (pcoa.h asks for
-    // two).  The link idles only while a read takes longer than the copy beside it.
-    auto t0 = now();
-    int64_t kept = r0 < r1 ? read_block(r0, 0) : 0;
-    read_s += secs(t0, now());
-    int i = 0;
-    for (int64_t b0 = r0; b0 < r1; b0 += block, ++i) {
+    // Device decode (r05): the feed call only QUEUES a block (PCOA_BED_HOST_ASYNC); a reader thread fills the next blocks
+    // meanwhile.  Four blocks rotate: one being read, one filled and waiting, and the two the engine may still be copying
+    // (pcoa.h: the rows of a queued call stay untouched until the second later call has returned).  The link idles only
+    // while the reads are slower than the copies.
+    constexpr int NB = 4;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool is_free[NB] = {true, true, true, true};
+    std::deque<std::pair<int, int64_t>> filled;   // (block buffer, kept rows) in file order
+    std::deque<int> queued;                       // buffers handed over, in call order
+    bool reader_done = false;
+    // (the reader takes ANY free buffer: tying block i to buffer i % 4 deadlocks when --references drops whole blocks --
+    // no call is made for them, so the buffer the reader is waiting for is never released)
+    std::thread reader([&] {
+      for (int64_t b0 = r0; b0 < r1; b0 += block) {
+        int w = -1;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] {
+            for (int q = 0; q < NB; ++q)
+              if (is_free[q]) {
+                w = q;
+                return true;
+              }
+            return false;
+          });
+          is_free[w] = false;
+        }
+        auto t0 = now();
+        const int64_t kept = read_block(b0, w);
+        read_s += secs(t0, now());
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          filled.emplace_back(w, kept);
+        }
+        cv.notify_all();
+      }
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        reader_done = true;
+      }
+      cv.notify_all();
+    });
+    for (;;) {
+      int w = -1;
+      int64_t kept = 0;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !filled.empty() || reader_done; });
+        if (filled.empty()) break;
+        w = filled.front().first;
+        kept = filled.front().second;
+        filled.pop_front();
+      }
       auto t1 = now();
       if (kept > 0) {
-        check(ctx, pcoa_accumulate_plink_bed(ctx, buf[i % 3], kept, (int64_t)bpv, ref_a1 ? 1 : 0, PCOA_BED_HOST_ASYNC), "getSimilarityMatrix");
+        check(ctx, pcoa_accumulate_plink_bed(ctx, buf[w], kept, (int64_t)bpv, ref_a1 ? 1 : 0, PCOA_BED_HOST_ASYNC), "getSimilarityMatrix");
         total += kept;
       }
-      auto t2 = now();
-      feed_s += secs(t1, t2);
-      if (b0 + block < r1) {
-        kept = read_block(b0 + block, (i + 1) % 3);
-        read_s += secs(t2, now());
+      feed_s += secs(t1, now());
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (kept <= 0) {
+          is_free[w] = true;                              // nothing was handed over
+        } else {
+          queued.push_back(w);
+          if (queued.size() > 2) {                        // two later CALLS have returned: that block is the reader's again
+            is_free[queued.front()] = true;
+            queued.pop_front();
+          }
+        }
       }
+      cv.notify_all();
     }
+    reader.join();
     auto t3 = now();
     check(ctx, pcoa_sync(ctx), "getSimilarityMatrix");  // the blocks are released by the caller next
     feed_s += secs(t3, now());
@@ -942,12 +998,12 @@ int main(int argc, char** argv) {
       }
   }
   StreamStats stream_stats;
-  std::vector<unsigned char*> blocks;  // page-locked blocks of the streaming reader, three per engine (filled by `prepare`)
+  std::vector<unsigned char*> blocks;  // page-locked blocks of the streaming reader, four per engine (filled by `prepare`)
   // engine g of k takes the contiguous range shard_range(g, k, rows) -- the reference's partitions (:184)
   std::function<void(int, int, pcoa_ctx*)> feed = [&](int g, int k, pcoa_ctx* ctx) {
     if (stream_plink) {
-      unsigned char* const three[3] = {blocks[(size_t)(3 * g)], blocks[(size_t)(3 * g + 1)], blocks[(size_t)(3 * g + 2)]};
-      stream_plink_shard(conf, plink, g, k, ctx, &stream_stats, three);
+      unsigned char* const four[4] = {blocks[(size_t)(4 * g)], blocks[(size_t)(4 * g + 1)], blocks[(size_t)(4 * g + 2)], blocks[(size_t)(4 * g + 3)]};
+      stream_plink_shard(conf, plink, g, k, ctx, &stream_stats, four);
       return;
     }
     int64_t ra, rb;
@@ -976,7 +1032,7 @@ int main(int argc, char** argv) {
   double feed_s = 0;
   auto prepare = [&](const std::vector<pcoa_ctx*>& engines) {
     if (!stream_plink) return;
-    for (int q = 0; q < 3 * conf.gpus; ++q) {
+    for (int q = 0; q < 4 * conf.gpus; ++q) {
       void* b = nullptr;
       if (pcoa_host_alloc_pinned((size_t)conf.stream_rows * plink.bpv, &b) != PCOA_OK) die("pcoa_host_alloc_pinned failed");
       blocks.push_back(static_cast<unsigned char*>(b));
@@ -987,7 +1043,7 @@ int main(int argc, char** argv) {
     // block; it adds nothing to S and is taken out of the books again
     const bool ref_a1 = conf.plink_ref_allele == "a1";
     for (int g = 0; g < conf.gpus; ++g) {
-      unsigned char* b = blocks[(size_t)(3 * g)];
+      unsigned char* b = blocks[(size_t)(4 * g)];
       std::memset(b, ref_a1 ? 0x00 : 0xFF, (size_t)conf.stream_rows * plink.bpv);
       pcoa_ctx* e = engines[(size_t)g];
       check(e, pcoa_accumulate_plink_bed(e, b, conf.stream_rows, (int64_t)plink.bpv, ref_a1 ? 1 : 0, 0), "warm-up");

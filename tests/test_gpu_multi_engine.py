@@ -134,3 +134,23 @@ def test_queued_bed_blocks_from_three_rotating_page_locked_buffers(P):
         for b in pins:
             b.fill_(0xFF)                                            # after a synchronising call the buffers are the caller's
         assert np.array_equal(eng.gram(), ref.gram())
+
+
+def test_streamed_plink_with_a_references_filter_that_drops_whole_blocks_equals_the_in_memory_path(tmp_path):
+    """The queued feed (r05: four rotating page-locked blocks, a reader thread) when --references keeps two disjoint ranges:
+    blocks in front, between and behind them hold no kept row at all and are never handed over -- the rule that frees a
+    block counts CALLS, not blocks -- and blocks at the range ends are squeezed.  Same S and output as --no-stream."""
+    g = load_golden("pops40")
+    n = int(g["n_samples"])
+    prefix = str(tmp_path / "p")
+    write_golden_plink(g, prefix)
+    pos = lambda k: 41196312 + 7 * k                                  # noqa: E731  (the .bim of write_golden_plink)
+    refs = "17:%d:%d,17:%d:%d" % (pos(20) - 1, pos(61) - 1, pos(110) - 1, pos(150) - 1)
+    base = ["--input-path", prefix + ".bed", "--references", refs]
+    s_mem, r_mem = _similarity(base + ["--no-stream"], n, tmp_path, "mem")
+    assert 0 < int(np.trace(s_mem)) < int(np.trace(g["similarity"]))   # a proper subset of the variants
+    for tag, extra in (("rows3", ["--stream-rows", "3"]), ("rows16", ["--stream-rows", "16"]),
+                       ("rows3_two_engines", ["--stream-rows", "3", "--gpus", "2", "--gpu-map", "0,0"])):
+        s, r = _similarity(base + extra, n, tmp_path, tag)
+        assert np.array_equal(s, s_mem), tag
+        assert r.stdout == r_mem.stdout, tag
