@@ -594,6 +594,7 @@ def main():
                                              "(pcoa_accumulate_bits, SURVEY 8d '1-bit-packed twin'); reported separately"}
             del bits
             out["csr_boundary"] = csr_boundary(P, torch, dev, local_rank, n, x1, s_dense, steps, args.operand)
+            out["plink_bed_boundary"] = plink_bed_boundary(P, torch, dev, local_rank, n, x1, s_dense, steps, args.operand)
         if world == 1 and not args.no_extras and args.config2_variants > 0:
             # BASELINE configs[2] on ONE GPU: the whole 40 M-variant cohort as carrier bitsets (12.6 GB, resident), one job
             out["config2_one_gpu_bits"] = config2_one_gpu_bits(P, synth, torch, dev, local_rank, n, args.config2_variants,
@@ -790,6 +791,47 @@ def csr_boundary(P, torch, dev, local_rank, n, x1, s_dense_steps, steps, operand
     res["note"] = ("device-validated path (range + repeats checked by the scatter kernel; a call reaches S only after its check): "
                    "pageable arrays are copied into pinned staging by host threads beside the H2D of the previous chunk; "
                    "PCOA_CSR_LEGACY=1 gives the r03 path (host-serial validation, one staging buffer) for comparison")
+    return res
+
+
+def plink_bed_boundary(P, torch, dev, local_rank, n, x1, s_dense_steps, steps, operand):
+    """The configs[1] batch as the rows of a variant-major PLINK 1 .bed (2 bits per genotype, ceil(N / 4) bytes per variant;
+    carriers heterozygous, the rest homozygous A2 = reference) through pcoa_accumulate_plink_bed: the boundary a cohort stored
+    as a PLINK fileset crosses (the compiled host streams files this way), whole job = H2D + device decode + transpose +
+    contraction + finalize."""
+    v = int(x1.shape[0])
+    bpv = (n + 3) // 4
+    raw = torch.empty((v, bpv), dtype=torch.uint8, device=dev)
+    sh = torch.tensor([0, 2, 4, 6], dtype=torch.uint8, device=dev)
+    for r0 in range(0, v, 1 << 16):
+        c = torch.nn.functional.pad(x1[r0:r0 + (1 << 16)] > 0, (0, bpv * 4 - n))
+        codes = (3 - c.to(torch.uint8)).view(-1, bpv, 4)            # carrier -> 10, non-carrier -> 11
+        raw[r0:r0 + codes.shape[0]] = (codes << sh).sum(dim=2).to(torch.uint8)
+    del c, codes
+    block = 131072
+    raw_pin = raw.cpu().pin_memory()
+    res = {"workload": "configs[1] batch 0 as PLINK .bed rows: %d variants x %d samples, %d B per variant" % (v, n, bpv),
+           "link_bound_variants_per_s_at_63_gbs": 63e9 / bpv}
+    with P.PcoaEngine(n, device=local_rank, operand=operand) as e:
+        e.reserve(v, 0)
+        for name in ("device_rows", "pinned_rows_queued"):
+            for timed in (False, True):
+                e.reset(); e.reset_timings(); e.sync()
+                t0 = time.perf_counter()
+                if name == "device_rows":
+                    e.accumulate_plink_bed(raw)
+                else:   # page-locked rows, queued block by block (PCOA_BED_HOST_ASYNC): what the streaming host's feed does
+                    for r0 in range(0, v, block):
+                        e.accumulate_plink_bed(raw_pin[r0:r0 + block], asynchronous=True)
+                e.finalize(); e.sync()
+                dt = time.perf_counter() - t0
+            tt = e.timings()
+            res[name] = {"variants_per_s": v / dt, "seconds": dt, "gb_per_s_of_rows": v * bpv / dt / 1e9,
+                         "decode_ms": 1e3 * tt["densify_seconds"], "transpose_ms": 1e3 * tt["pack_seconds"],
+                         "contraction_ms": 1e3 * tt["gram_kernel_seconds"],
+                         "same_gram_as_dense_input": bool(np.array_equal(e.gram() * steps, s_dense_steps))}
+    res["note"] = ("pinned_rows_queued: the rows lie in page-locked memory already (no file, no host copy) -- file -> reduced S "
+                   "with the compiled host: profiles/r06h_plink_stream_final.txt")
     return res
 
 

@@ -133,7 +133,7 @@ def load_vcf(path, references=None):
     return indexes, dict(zip(ids, samples)), [("csr", idx, np.asarray(offs, dtype=np.int64))]
 
 
-def load_plink(path, references=None, ref_allele="a2", chunk_variants=4096, as_bits=False):
+def load_plink(path, references=None, ref_allele="a2", chunk_variants=4096, as_bits=False, as_bed=False):
     """PLINK 1 binary fileset (<prefix>.bed / .bim / .fam; `path` is the prefix or any of the three files).  The .bed is
     variant-major, two bits per genotype, four samples to a byte (sample s in bits 2 (s % 4) of byte s // 4):
     00 homozygous A1, 01 missing, 10 heterozygous, 11 homozygous A2.  hasVariation (VariantsPca.scala:56-60: some allele
@@ -144,7 +144,10 @@ def load_plink(path, references=None, ref_allele="a2", chunk_variants=4096, as_b
     --references filter are the VCF reader's (0-based start = bp - 1).
     as_bits=True returns [("bits", uint32 [variants][ceil(N / 32)])] instead: the carrier bitsets pcoa_accumulate_bits
     takes (sample i -> bit i & 31 of word i >> 5), one table look-up per .bed byte and no CSR in between -- 1 bit per
-    genotype instead of 4 bytes per carrier; rows without a carrier stay (they add nothing to S)."""
+    genotype instead of 4 bytes per carrier; rows without a carrier stay (they add nothing to S).
+    as_bed=True (r05) decodes nothing at all: [("bed", memory-mapped uint8 [variants][ceil(N / 4)] rows as they lie in the
+    file, keep mask over the .bim lines, ref_is_a1)] -- what pcoa_accumulate_plink_bed takes block by block (the device
+    decodes; the numpy decode above runs at ~0.2 M variants/s, a memory-mapped block copy at GB/s)."""
     prefix = path[:-4] if path[-4:] in (".bed", ".bim", ".fam") else path
     regions = parse_references(references)
     set_id = set_id_of(prefix + ".bed")
@@ -178,6 +181,8 @@ def load_plink(path, references=None, ref_allele="a2", chunk_variants=4096, as_b
     geno = raw[3:].reshape(keep.size, bpv)
     ids = ["%s-%d" % (set_id, i) for i in range(n)]
     indexes = dict((cid, i) for i, cid in enumerate(ids))
+    if as_bed:
+        return indexes, dict(zip(ids, names)), [("bed", geno, keep, ref_allele != "a2")]
     if as_bits:
         # a genotype varies iff the LOW bit of its code is 0 (A2 = reference: codes 00, 10) / the HIGH bit is 1 (A1 =
         # reference: codes 10, 11): one nibble of carrier bits per .bed byte, eight nibbles to a word

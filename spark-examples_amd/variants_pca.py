@@ -28,6 +28,8 @@ import numpy as np
 
 from .engine import PcoaEngine
 
+PLINK_BLOCK_ROWS = 1 << 16   # raw .bed rows handed to pcoa_accumulate_plink_bed per call (41 MB at N = 2504)
+
 
 # --------------------------------------------------------------------------------------------- a1/a2
 def extract_call_info(variant, mapping):
@@ -155,7 +157,20 @@ def calculate_similarity_matrix(call_rdd, matrix_size, engine=None, device=0):
     (VariantsPca.scala:182-191).  call_rdd: list of index lists, or a (sample_idx, row_offsets) CSR
     pair.  Returns the PcoaEngine holding S in HBM (use .gram() for the N^2 entries)."""
     eng = engine if engine is not None else PcoaEngine(matrix_size, device=device)
-    if isinstance(call_rdd, tuple) and isinstance(call_rdd[0], str) and call_rdd[0] == "bits":
+    if isinstance(call_rdd, tuple) and isinstance(call_rdd[0], str) and call_rdd[0] == "bed":
+        # a PLINK fileset as it lies in the file: blocks of raw 2-bit rows, decoded on the device (pcoa_accumulate_plink_bed);
+        # rows outside --references are squeezed out of a block before it is handed over
+        _, geno, keep, ref_is_a1 = call_rdd
+        all_kept = bool(keep.all())
+        for v0 in range(0, geno.shape[0], PLINK_BLOCK_ROWS):
+            rows = geno[v0:v0 + PLINK_BLOCK_ROWS]
+            if not all_kept:
+                k = keep[v0:v0 + PLINK_BLOCK_ROWS]
+                if not k.any():
+                    continue
+                rows = rows[k]
+            eng.accumulate_plink_bed(np.ascontiguousarray(rows), ref_is_a1=ref_is_a1)
+    elif isinstance(call_rdd, tuple) and isinstance(call_rdd[0], str) and call_rdd[0] == "bits":
         bits = call_rdd[1]                          # carrier bitsets [variants][ceil(N / 32)] (a PLINK fileset)
         for v0 in range(0, bits.shape[0], 1 << 20):
             eng.accumulate_bits(bits[v0:v0 + (1 << 20)])
@@ -322,6 +337,8 @@ class VariantsPcaDriver(object):
         if variant_set_count == 1:
             d = data[0]
             if isinstance(d, tuple):  # pre-extracted carriers: CSR rows (already filtered) or bitsets
+                if d[0] == "bed":
+                    return d
                 return ("bits", d[1]) if d[0] == "bits" else (d[1], d[2])
             return prepare_call_data(d, self.indexes)
         if any(isinstance(d, tuple) for d in data):
@@ -404,7 +421,7 @@ def load_dataset(conf):
         if paths[0].endswith(".npz"):
             return ingest.load_npz(paths[0])
         if paths[0][-4:] in (".bed", ".bim", ".fam"):
-            return ingest.load_plink(paths[0], refs, ref_allele=conf.plink_ref_allele, as_bits=True)
+            return ingest.load_plink(paths[0], refs, ref_allele=conf.plink_ref_allele, as_bed=True)
         return ingest.load_vcf(paths[0], refs)
     # several variant sets (or the AF filter): full variant records are needed for keys and INFO/AF
     if any(p.endswith(".npz") or p[-4:] in (".bed", ".bim", ".fam") for p in paths):

@@ -482,14 +482,18 @@ def test_plink_reader_refuses_what_it_cannot_read(tmp_path):
     open(prefix + ".bed", "wb").write(raw)
     conf = vp.PcaConf(["--input-path", prefix + ".bed", "--all-references"])
     indexes, names, data = vp.load_dataset(conf)
-    assert len(indexes) == int(g["n_samples"]) and data[0][0] == "bits"
+    assert len(indexes) == int(g["n_samples"]) and data[0][0] == "bed"   # r05: raw rows, decoded on the device
 
     class Recorder(object):                     # what the front end hands to the engine, without a GPU
         def __init__(self):
-            self.bits, self.finalized = [], False
+            self.bits, self.bed, self.finalized = [], [], False
 
         def accumulate_bits(self, b):
             self.bits.append(np.array(b))
+
+        def accumulate_plink_bed(self, rows, ref_is_a1=False):
+            assert rows.dtype == np.uint8 and rows.flags["C_CONTIGUOUS"]
+            self.bed.append((np.array(rows), ref_is_a1))
 
         def finalize(self):
             self.finalized = True
@@ -498,7 +502,25 @@ def test_plink_reader_refuses_what_it_cannot_read(tmp_path):
     rec = Recorder()
     out = vp.calculate_similarity_matrix(driver.getCallsRdd([driver.filterDataset(d) for d in driver.data]),
                                          len(indexes), engine=rec)
-    assert out is rec and rec.finalized and len(rec.bits) == 1 and np.array_equal(rec.bits[0], data[0][1])
+    nvar = len(json.loads(str(g["variants_json"])))
+    assert out is rec and rec.finalized and not rec.bits and len(rec.bed) == 1 and rec.bed[0][1] is False
+    assert np.array_equal(rec.bed[0][0], np.frombuffer(raw[3:], dtype=np.uint8).reshape(nvar, -1))
+    # a --references window squeezes the rows outside it out of every block, and blocks without a kept row are skipped
+    old_block = vp.PLINK_BLOCK_ROWS
+    try:
+        vp.PLINK_BLOCK_ROWS = 3
+        lo, hi = 41196312 + 7 * 4 - 1, 41196312 + 7 * 11 - 1        # variants 4 .. 10 of write_golden_plink's .bim
+        conf2 = vp.PcaConf(["--input-path", prefix + ".bed", "--references", "17:%d:%d" % (lo, hi)])
+        i2, n2, d2 = vp.load_dataset(conf2)
+        rec2 = Recorder()
+        drv2 = vp.VariantsPcaDriver(conf2, i2, n2, d2)
+        vp.calculate_similarity_matrix(drv2.getCallsRdd([drv2.filterDataset(d) for d in drv2.data]), len(i2), engine=rec2)
+        got = np.concatenate([b for b, _ in rec2.bed])
+        assert np.array_equal(got, np.frombuffer(raw[3:], dtype=np.uint8).reshape(nvar, -1)[4:11]) and len(rec2.bed) == 3
+    finally:
+        vp.PLINK_BLOCK_ROWS = old_block
+    # the numpy decode of the same bytes (as_bits) is what the device decode must reproduce: held together on the GPU by
+    # tests/test_gpu_multi_engine.py::test_peer_reduction_and_device_side_bed_decode_through_the_c_abi
     with pytest.raises(SystemExit):
         vp.load_dataset(vp.PcaConf(["--input-path", prefix + ".bed", prefix + ".bed", "--all-references"]))
 
