@@ -90,6 +90,27 @@ JNIEXPORT jint JNICALL FN(accumulateBits)(JNIEnv* env, jobject, jlong ctx, jobje
                               static_cast<int64_t>(ld_words), /*is_device_ptr=*/0);
 }
 
+// pcoa_host_alloc_pinned as a direct ByteBuffer over page-locked memory (null when it cannot be had): what
+// accumulateCallsEx(.. CallsPinned ..) and accumulatePlinkBed(.. BedHostAsync) read at link speed.  freePinned releases it;
+// the buffer must not be used afterwards (the JVM does not own this memory and never frees it by itself).
+JNIEXPORT jobject JNICALL FN(allocPinned)(JNIEnv* env, jobject, jlong bytes) {
+  void* p = nullptr;
+  if (bytes <= 0 || pcoa_host_alloc_pinned(static_cast<size_t>(bytes), &p) != PCOA_OK) return nullptr;
+  jobject buf = env->NewDirectByteBuffer(p, bytes);
+  if (!buf) (void)pcoa_host_free_pinned(p);
+  return buf;
+}
+JNIEXPORT jint JNICALL FN(freePinned)(JNIEnv* env, jobject, jobject buf) {
+  return pcoa_host_free_pinned(direct<void>(env, buf));
+}
+
+// pcoa_accumulate_plink_bed: the rows of a variant-major PLINK .bed as they lie in the file; mode 0 host rows (consumed on
+// return), 1 device address, 2 = PCOA_BED_HOST_ASYNC (page-locked rows, only queued)
+JNIEXPORT jint JNICALL FN(accumulatePlinkBed)(JNIEnv* env, jobject, jlong ctx, jobject rows, jlong n_variants, jlong row_bytes,
+                                              jint ref_is_a1, jint mode) {
+  return pcoa_accumulate_plink_bed(ctx_of(ctx), direct<const uint8_t>(env, rows), n_variants, row_bytes, ref_is_a1, mode);
+}
+
 // pcoa_gram_finalize
 JNIEXPORT jint JNICALL FN(gramFinalize)(JNIEnv*, jobject, jlong ctx) { return pcoa_gram_finalize(ctx_of(ctx)); }
 

@@ -31,6 +31,7 @@ object NativePcoa {
   val CallsDevicePtr = 1
   val CallsPinned = 2
   val CallsAsync = 4
+  val BedHostAsync = 2 // PCOA_BED_HOST_ASYNC: page-locked .bed rows are only queued (untouched until the second later call returned, or sync)
 
   @native def create(nSamples: Int, device: Int, flags: Int): Long // pcoa_create; throws IllegalStateException
   @native def destroy(ctx: Long): Unit // pcoa_destroy
@@ -41,6 +42,9 @@ object NativePcoa {
   @native def sync(ctx: Long): Int // pcoa_sync
   @native def gramReduceFrom(dst: Long, src: Long): Int // pcoa_gram_reduce_from (two engines of this JVM)
   @native def accumulateBits(ctx: Long, bits: ByteBuffer, nVariants: Long, ldWords: Long): Int // pcoa_accumulate_bits
+  @native def allocPinned(bytes: Long): ByteBuffer // pcoa_host_alloc_pinned as a direct buffer (null on failure); set order(LITTLE_ENDIAN)
+  @native def freePinned(buf: ByteBuffer): Int // pcoa_host_free_pinned; the buffer is dead afterwards
+  @native def accumulatePlinkBed(ctx: Long, rows: ByteBuffer, nVariants: Long, rowBytes: Long, refIsA1: Int, mode: Int): Int // pcoa_accumulate_plink_bed (mode: 0 host, 1 device address, BedHostAsync)
   @native def gramFinalize(ctx: Long): Int // pcoa_gram_finalize
   @native def commUniqueId(): Array[Byte] // pcoa_comm_unique_id (128 bytes; null on failure)
   @native def commInit(ctx: Long, id: Array[Byte], rank: Int, nRanks: Int): Long // pcoa_comm_init (0 on failure)

@@ -14,6 +14,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <string>
 #include <vector>
@@ -29,6 +30,10 @@ jint FN(reset)(JNIEnv*, jobject, jlong);
 jint FN(accumulateCalls)(JNIEnv*, jobject, jlong, jobject, jobject, jlong);
 jint FN(accumulateBits)(JNIEnv*, jobject, jlong, jobject, jlong, jlong);
 jint FN(gramFinalize)(JNIEnv*, jobject, jlong);
+jint FN(sync)(JNIEnv*, jobject, jlong);
+jobject FN(allocPinned)(JNIEnv*, jobject, jlong);
+jint FN(freePinned)(JNIEnv*, jobject, jobject);
+jint FN(accumulatePlinkBed)(JNIEnv*, jobject, jlong, jobject, jlong, jlong, jint, jint);
 jbyteArray FN(commUniqueId)(JNIEnv*, jobject);
 jlong FN(commInit)(JNIEnv*, jobject, jlong, jbyteArray, jint, jint);
 jint FN(commDestroy)(JNIEnv*, jobject, jlong);
@@ -119,5 +124,38 @@ int main(int argc, char** argv) {
   EXPECT((int64_t)t3[0] > 0 || nv == 0);
   std::printf("nonzero %d\n", nz->ints[0]);
   FN(destroy)(&env, self, ctx);
+  // ---- the same records as the rows of a PLINK .bed (carrier = heterozygous, the rest homozygous A2 = reference) in
+  // page-locked direct buffers from allocPinned, queued in three pieces (BedHostAsync = 2): the S of the CSR path again
+  {
+    const jlong bpv = ((jlong)n + 3) / 4;
+    const int64_t cut[4] = {0, nv / 3, nv / 3 + (nv - nv / 3) / 2, nv};
+    const jlong c2 = FN(create)(&env, self, n, 0, 0);
+    EXPECT(c2 != 0);
+    jobject pin[3] = {nullptr, nullptr, nullptr};
+    for (int q = 0; q < 3; ++q) {
+      const int64_t rows = cut[q + 1] - cut[q];
+      if (rows == 0) continue;
+      pin[q] = FN(allocPinned)(&env, self, rows * bpv);
+      EXPECT(pin[q] != nullptr && env.GetDirectBufferCapacity(pin[q]) == rows * bpv);
+      uint8_t* b = static_cast<uint8_t*>(env.GetDirectBufferAddress(pin[q]));
+      std::memset(b, 0xFF, (size_t)(rows * bpv));                       // every sample homozygous A2
+      for (int64_t r = 0; r < rows; ++r)
+        for (int64_t e = offs[(size_t)(cut[q] + r)]; e < offs[(size_t)(cut[q] + r + 1)]; ++e) {
+          const int32_t c = idx[(size_t)e];
+          b[r * bpv + c / 4] = (uint8_t)(b[r * bpv + c / 4] & ~(1u << (2 * (c % 4))));   // 11 -> 10: heterozygous
+        }
+      EXPECT(FN(accumulatePlinkBed)(&env, self, c2, pin[q], rows, bpv, 0, 2) == PCOA_OK);
+    }
+    EXPECT(FN(accumulatePlinkBed)(&env, self, c2, env.heapBuffer(), 1, bpv, 0, 0) == PCOA_ERR_INVALID_ARG);
+    EXPECT(FN(sync)(&env, self, c2) == PCOA_OK);                           // the queued rows are the caller's again
+    for (int q = 0; q < 3; ++q)
+      if (pin[q]) EXPECT(FN(freePinned)(&env, self, pin[q]) == PCOA_OK);
+    EXPECT(FN(gramFinalize)(&env, self, c2) == PCOA_OK);
+    std::vector<int64_t> s2((size_t)n * (size_t)n);
+    EXPECT(FN(gramRead)(&env, self, c2, env.wrapDirect(s2.data(), 8 * (jlong)s2.size())) == PCOA_OK);
+    EXPECT(s2 == s);
+    FN(destroy)(&env, self, c2);
+    std::printf("plink rows through the shim: same S\n");
+  }
   return 0;
 }

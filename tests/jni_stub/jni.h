@@ -40,6 +40,7 @@ struct JNIEnv {
 
   void* GetDirectBufferAddress(jobject buf) { return (buf && buf->kind == _jobject::DIRECT_BUFFER) ? buf->address : nullptr; }
   jlong GetDirectBufferCapacity(jobject buf) { return (buf && buf->kind == _jobject::DIRECT_BUFFER) ? buf->capacity : -1; }
+  jobject NewDirectByteBuffer(void* p, jlong cap) { return p ? wrapDirect(p, cap) : nullptr; }
   jbyteArray NewByteArray(jsize n) { jobject o = make(_jobject::BYTE_ARRAY); o->bytes.assign((size_t)n, 0); return o; }
   jsize GetArrayLength(jobject a) { return a->kind == _jobject::BYTE_ARRAY ? (jsize)a->bytes.size() : (jsize)a->ints.size(); }
   void SetByteArrayRegion(jbyteArray a, jsize start, jsize len, const jbyte* src) { std::memcpy(a->bytes.data() + start, src, (size_t)len); }

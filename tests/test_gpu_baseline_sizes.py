@@ -391,7 +391,8 @@ def test_jni_shim_replay_matches_the_reference_goldens(O, name, batch, tmp_path)
     """jni/pcoa_jni.cpp (the shim of the Scala host) compiled against tests/jni_stub/jni.h and driven
     by tests/jni_replay.cpp with the call sequence of scala/.../VariantsPcaNative.scala: direct-buffer CSR batches ->
     gramFinalize -> commInit / gramAllreduce (1 rank) -> compute.  S must equal the reference's own similarity matrix,
-    the components the oracle's within 1e-6."""
+    the components the oracle's within 1e-6; then the same records as queued PLINK rows through allocPinned /
+    accumulatePlinkBed / sync / freePinned: the same S."""
     exe = str(tmp_path / "jni_replay")
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "tests", "jni_stub"), "-I",
                            os.path.join(ROOT, "include"), os.path.join(ROOT, "jni", "pcoa_jni.cpp"),
@@ -411,6 +412,8 @@ def test_jni_shim_replay_matches_the_reference_goldens(O, name, batch, tmp_path)
     ref = O.compute_pca(g["similarity"], 2)
     lines = [l for l in res.stdout.splitlines() if l.startswith("nonzero ")]   # (RCCL prints a version banner to stdout)
     assert lines == ["nonzero %d" % ref["nonzero_rows"]]
+    # r05: the same records as PLINK .bed rows in page-locked direct buffers (allocPinned), queued through accumulatePlinkBed
+    assert "plink rows through the shim: same S" in res.stdout
     comps = np.fromfile(prefix + ".pc", dtype="<f8").reshape(2, n).T      # column-major N x 2 == pca.toArray
     lam = np.fromfile(prefix + ".lam", dtype="<f8")
     assert np.max(np.abs(lam - ref["eigenvalues"]) / np.abs(ref["eigenvalues"])) < EIG_TOL
