@@ -118,6 +118,32 @@ def one_case(seed, idx):
             check(eng, 2 * want, "bits")
             d.free()
             eng.reset()
+            # r05: the rows of a PLINK .bed on the device, exactly sized (rows ceil(N / 4) [+ pad] bytes apart start at any
+            # byte: the decode reads aligned 8-byte units around them) and from the host; carrier = heterozygous, the rest
+            # homozygous A2 (reference) or missing
+            bpv = (n + 3) // 4 + (pad % 4)
+            codes = np.where(x > 0, 2, np.where(rng.random(x.shape) < 0.2, 1, 3)).astype(np.uint8)
+            quad = np.full((v, bpv * 4), 3, dtype=np.uint8)
+            quad[:, :n] = codes
+            quad = quad.reshape(v, bpv, 4)
+            raw = (quad[:, :, 0] | (quad[:, :, 1] << 2) | (quad[:, :, 2] << 4) | (quad[:, :, 3] << 6)).astype(np.uint8)
+            d = DevBuf(raw)
+            eng._check(lib.pcoa_accumulate_plink_bed(ctx, d.ptr, v, bpv, 0, 1))
+            eng.accumulate_plink_bed(raw)
+            check(eng, 2 * want, "plink rows")
+            d.free()
+            eng.reset()
+            # r05: carrier lists in exactly-sized DEVICE arrays (the LDS scatter streams a block's entries with 16-byte loads
+            # from whatever alignment they start at)
+            rows_, cols_ = np.nonzero(x)
+            offs = np.zeros(v + 1, dtype=np.int64)
+            np.cumsum(np.bincount(rows_, minlength=v), out=offs[1:])
+            if cols_.size:
+                di, do = DevBuf(cols_.astype(np.int32)), DevBuf(offs)
+                eng._check(lib.pcoa_accumulate_calls_ex(ctx, di.ptr, do.ptr, v, L.PCOA_CALLS_DEVICE_PTR))
+                check(eng, want, "csr device arrays")
+                di.free(); do.free()
+                eng.reset()
         # CSR carrier lists (repeats = multiplicities when mult)
         eng.accumulate_callsets([list(np.repeat(np.arange(n), r)) for r in xm])
         check(eng, want, "csr")
