@@ -1369,6 +1369,7 @@ void pcoa_destroy(pcoa_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->pack_stream) (void)hipStreamSynchronize(c->pack_stream);
   if (c->gram_stream) (void)hipStreamSynchronize(c->gram_stream);
+  if (c->csr_stream) (void)hipStreamSynchronize(c->csr_stream);   // queued copies of carrier lists / .bed rows
   for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto& ev : c->pool) (void)hipEventDestroy(ev);
   for (auto& b : c->fb) {
