@@ -1038,7 +1038,8 @@ int packed_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64
       // of 128 variants x 1,024 samples
       if (c->coreside && deferrable_u8 && ps == c->pack_stream) {
         const int64_t units = (kb / 4) * ((gram_packed_npad(c->n) + 1023) / 1024);
-        if (units >= 64) ring_wgs = (int)std::max<int64_t>(1, std::min<int64_t>(c->num_cu, units / 16));
+        const int cap = debug_knobs().u8_ring_wgs > 0 ? debug_knobs().u8_ring_wgs : c->num_cu;   // (PCOA_U8_RING_WGS: harness knob)
+        if (units >= 64) ring_wgs = (int)std::max<int64_t>(1, std::min<int64_t>(cap, units / 16));
       }
       hipError_t e = launch_pack_operand(c, x_chunk, is_u8, ld, cur, dst, flag, ps, kb, ring_wgs);
       if (e != hipSuccess) return hip_fail(c, e, "operand pre-pass launch");
@@ -1261,6 +1262,7 @@ const DebugKnobs& debug_knobs() {
     k.kbits_pipe_wgs = (int)num("PCOA_KBITS_PIPE_WGS");
     if (const char* v = std::getenv("PCOA_KBITS_CORESIDE")) k.kbits_coreside = std::atoi(v) != 0;
     k.kbits_ring_wgs = (int)num("PCOA_KBITS_RING_WGS");
+    k.u8_ring_wgs = (int)num("PCOA_U8_RING_WGS");
     k.kbits_ring_prio = (int)num("PCOA_KBITS_RING_PRIO");
     k.kbits_coreside_max_npad = (int)num("PCOA_KBITS_CORESIDE_MAX_NPAD");
     k.gram_cfg = (int)num("PCOA_GRAM_I8_CFG");

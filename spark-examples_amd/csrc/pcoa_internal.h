@@ -43,6 +43,7 @@ struct DebugKnobs {
   int kbits_coreside = -1;         // PCOA_KBITS_CORESIDE = 0 | 1: fp32 pipeline with pre-pass and contraction on the SAME CUs (ring pre-pass)
   int kbits_ring_prio = 0;         // PCOA_KBITS_RING_PRIO = 1: the ring pre-pass's waves at s_setprio 3 (harness knob)
   int kbits_ring_wgs = 0;          // PCOA_KBITS_RING_WGS: workgroups of the ring pre-pass beside a contraction (default 2 per CU)
+  int u8_ring_wgs = 0;             // PCOA_U8_RING_WGS: workgroups of the uint8 ring pre-pass beside a contraction (default one per CU)
   int fork_lazy = 1;               // PCOA_FORK_LAZY = 0: a side stream waits on the ctx stream even when that is idle (r03 behaviour: a barrier packet in front of every pre-pass and contraction -- 2.26 vs 2.11 ms per fp32 step, profiles/r04w)
   int bits_pipeline = 0;           // PCOA_BITS_PIPELINE = 1: bitset tiles through the co-resident pipeline as in r03 / r04 (default: transpose and contraction in series, the contraction as the one-wave-per-SIMD kernel)
   int headstart_us = -1;           // PCOA_HEADSTART_US: the contraction's head start over the next pre-pass (default 10; 0 = none)
