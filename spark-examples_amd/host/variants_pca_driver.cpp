@@ -981,22 +981,11 @@ int main(int argc, char** argv) {
   if (sample_idx.empty()) sample_idx.push_back(0);
 
   // getSimilarityMatrix (:182-191) and computePca (:198-231) on the GPU(s)
-  // The RDD[Seq[Int]] rows go over as carrier BITSETS (pcoa_accumulate_bits) when every row is a SET: 316 B per variant
-  // at N = 2504 instead of 4 B per carrier, straight onto the MX-FP4 kernel.  A row can only repeat a callset when
-  // mergeDatasets groups a key that occurs twice inside one VCF (the group size still equals the number of sets when
-  // another set lacks the key); the reference's double loop counts such a repeat with multiplicity (:187), which a
-  // bitset cannot express, so any repeat sends the job through the CSR boundary (pcoa_accumulate_calls), as the Python
-  // mirror always does.
-  bool any_repeat = false;
-  if (data.size() > 2) {
-    std::vector<int64_t> last((size_t)n, -1);
-    for (size_t r = 0; r + 1 < row_offsets.size() && !any_repeat; ++r)
-      for (int64_t q = row_offsets[r]; q < row_offsets[r + 1]; ++q) {
-        const size_t cidx = (size_t)sample_idx[(size_t)q];
-        if (last[cidx] == (int64_t)r) { any_repeat = true; break; }
-        last[cidx] = (int64_t)r;
-      }
-  }
+  // The RDD[Seq[Int]] rows go over as what they are: carrier lists (pcoa_accumulate_calls_ex).  The device checks the
+  // range of every index and finds a list that names a callset twice -- mergeDatasets can produce one when a key occurs
+  // twice inside one VCF; the reference's double loop counts such a repeat with multiplicity (:187), and the engine then
+  // redoes that chunk on the int8 kernel.  (Until r05 the rows were re-packed into bitsets here by one host thread, ~1 us
+  // per variant of a dense cohort: the lists themselves cross the link at 37 M variants/s.)
   StreamStats stream_stats;
   std::vector<unsigned char*> blocks;  // page-locked blocks of the streaming reader, four per engine (filled by `prepare`)
   // engine g of k takes the contiguous range shard_range(g, k, rows) -- the reference's partitions (:184)
@@ -1009,24 +998,7 @@ int main(int argc, char** argv) {
     int64_t ra, rb;
     shard_range(g, k, (int64_t)row_offsets.size() - 1, &ra, &rb);
     if (rb <= ra) return;
-    if (any_repeat) {
-      std::vector<int64_t> offs(row_offsets.begin() + ra, row_offsets.begin() + rb + 1);
-      check(ctx, pcoa_accumulate_calls(ctx, sample_idx.data(), offs.data(), rb - ra), "getSimilarityMatrix");
-      return;
-    }
-    const int64_t words = ((int64_t)n + 31) / 32;
-    const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(rb - ra, ((int64_t)64 << 20) / words));
-    std::vector<uint32_t> bits((size_t)(batch * words));
-    for (int64_t r0 = ra; r0 < rb; r0 += batch) {
-      const int64_t rows = std::min(batch, rb - r0);
-      std::fill(bits.begin(), bits.begin() + (size_t)(rows * words), 0u);
-      for (int64_t r = 0; r < rows; ++r)
-        for (int64_t q = row_offsets[(size_t)(r0 + r)]; q < row_offsets[(size_t)(r0 + r + 1)]; ++q) {
-          const int32_t c = sample_idx[(size_t)q];
-          bits[(size_t)(r * words + (c >> 5))] |= 1u << (c & 31);
-        }
-      check(ctx, pcoa_accumulate_bits(ctx, bits.data(), rows, words, 0), "getSimilarityMatrix");
-    }
+    check(ctx, pcoa_accumulate_calls_ex(ctx, sample_idx.data(), row_offsets.data() + ra, rb - ra, 0), "getSimilarityMatrix");
   };
   std::string how;
   double feed_s = 0;
