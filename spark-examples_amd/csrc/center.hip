@@ -10,6 +10,7 @@
 // is evaluated in the reference's operation order with IEEE fp64 +,-,/ and no fused multiply-add,
 // so B is bit-identical to the JVM's result.  HBM-bound streaming: reads 4 (or 12) B, writes 8 B
 // per entry.
+#include <type_traits>
 #include "pcoa_internal.h"
 
 namespace pcoa {
@@ -104,36 +105,107 @@ __global__ __launch_bounds__(256) void col_means_kernel(const double* __restrict
 // second pass adds the bands in a fixed order -- deterministic, no floating-point atomics.
 constexpr int STRIP_BAND = 256;
 
-template <bool MATVEC>
+// r05: a workgroup takes 1024 columns x a band of 256 rows.  Each of its four waves walks ALL rows of the band over its own 256
+// columns, a lane owning the four columns lane + 64 q: four independent 4-byte loads per row (each wave-level load is 256
+// contiguous bytes -- any `cols`, no alignment rule), rows prefetched four deep (16 loads per lane in flight), the band's
+// v_i / rowMean_i staged in LDS once.  The r04 form (one column per thread, one load in flight per iteration, v_i and
+// rowMean_i re-read per row) streamed the strip at a fraction of the HBM rate; the additions per column happen in the same
+// order as before (rows of a band in order, bands in order): results are bit-identical.
+constexpr int STRIP_NB = 4;   // row buffers
+
+template <bool MATVEC, bool HAS64>
 __global__ __launch_bounds__(256) void strip_band_kernel(const int32_t* __restrict__ s32, const int64_t* __restrict__ s64,
                                                          int32_t n, int32_t col0, int32_t cols, const double* __restrict__ v,
                                                          const double* __restrict__ means, double mmean,
                                                          double* __restrict__ partial /* [bands][cols] */) {
 #pragma clang fp contract(off)
-  const int jj = blockIdx.x * 256 + threadIdx.x;
+  __shared__ double vs[STRIP_BAND], ms[STRIP_BAND];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int band = blockIdx.y;
   const int i0 = band * STRIP_BAND, i1 = min(n, i0 + STRIP_BAND);
-  if (jj >= cols) return;
+  const int rows = i1 - i0;
   if constexpr (MATVEC) {
-    const double row_mean = means[col0 + jj];   // the strip's column j is row j of the symmetric matrix
-    double acc = 0.0;
-    for (int i = i0; i < i1; ++i) {
-      const int64_t idx = (int64_t)i * cols + jj;
-      const double data = (double)((int64_t)s32[idx] + (s64 ? s64[idx] : 0));
-      double t = data - row_mean;
-      t = t - means[i];
-      t = t + mmean;
-      acc += t * v[i];
+    for (int r = threadIdx.x; r < STRIP_BAND; r += 256) {
+      vs[r] = r < rows ? v[i0 + r] : 0.0;
+      ms[r] = r < rows ? means[i0 + r] : 0.0;
     }
-    partial[(int64_t)band * cols + jj] = acc;
-  } else {
-    int64_t acc = 0;
-    for (int i = i0; i < i1; ++i) {
-      const int64_t idx = (int64_t)i * cols + jj;
-      acc += (int64_t)s32[idx] + (s64 ? s64[idx] : 0);
-    }
-    reinterpret_cast<int64_t*>(partial)[(int64_t)band * cols + jj] = acc;
+    __syncthreads();
   }
+  const int jbase = (blockIdx.x * 4 + wave) * 256 + lane;   // this lane's columns: jbase + 64 q
+  if (jbase - lane >= cols) return;                         // (wave-uniform: the whole wave lies beyond the strip)
+  // FULL: all 256 columns of the wave lie inside the strip (wave-uniform): no masks in the row loop
+  auto run = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    bool ok[4];
+    double mj[4], acc[4];
+    int64_t iacc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = jbase + 64 * q;
+      ok[q] = FULL || j < cols;
+      mj[q] = (MATVEC && ok[q]) ? means[col0 + j] : 0.0;   // the strip's column j is row j of the symmetric matrix
+      acc[q] = 0.0;
+      iacc[q] = 0;
+    }
+    const int64_t base = (int64_t)i0 * cols + jbase;
+    // (the buffers hold what was LOADED -- a value converted at load time would be waited for at once)
+    struct Row { int32_t lo[4]; int64_t hi[HAS64 ? 4 : 1]; };
+    auto load_row = [&](int r, Row& b) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t idx = base + (int64_t)r * cols + 64 * q;
+        b.lo[q] = (FULL || ok[q]) ? s32[idx] : 0;
+        if constexpr (HAS64) b.hi[q] = (FULL || ok[q]) ? s64[idx] : 0;
+      }
+    };
+    auto use_row = [&](int r, const Row& b) {
+      if constexpr (MATVEC) {
+        const double vi = vs[r], mi = ms[r];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double data = HAS64 ? (double)((int64_t)b.lo[q] + b.hi[HAS64 ? q : 0]) : (double)b.lo[q];
+          double t = data - mj[q];
+          t = t - mi;
+          t = t + mmean;
+          acc[q] += t * vi;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) iacc[q] += (int64_t)b.lo[q] + (HAS64 ? b.hi[HAS64 ? q : 0] : 0);
+      }
+    };
+    Row buf[STRIP_NB];
+#pragma unroll
+    for (int b = 0; b < STRIP_NB; ++b)
+      if (b < rows) load_row(b, buf[b]);
+    int k = 0;
+    for (; k + 2 * STRIP_NB <= rows; k += STRIP_NB) {
+#pragma unroll
+      for (int b = 0; b < STRIP_NB; ++b) {
+        use_row(k + b, buf[b]);
+        load_row(k + b + STRIP_NB, buf[b]);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < STRIP_NB; ++b)
+      if (k + b < rows) {
+        use_row(k + b, buf[b]);
+        if (k + b + STRIP_NB < rows) load_row(k + b + STRIP_NB, buf[b]);
+      }
+    k += STRIP_NB;
+#pragma unroll
+    for (int b = 0; b < STRIP_NB; ++b)
+      if (k + b < rows) use_row(k + b, buf[b]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (!ok[q]) continue;
+      const int64_t o = (int64_t)band * cols + jbase + 64 * q;
+      if constexpr (MATVEC) partial[o] = acc[q];
+      else reinterpret_cast<int64_t*>(partial)[o] = iacc[q];
+    }
+  };
+  if (jbase - lane + 256 <= cols) run(std::true_type{});
+  else run(std::false_type{});
 }
 
 template <bool MATVEC>
@@ -162,20 +234,28 @@ int64_t strip_ws_doubles(int32_t n, int32_t cols) {
 hipError_t launch_strip_col_sums(const int32_t* s32, const int64_t* s64_or_null, int32_t n, int32_t cols, double* ws,
                                  hipStream_t stream) {
   const int bands = (n + STRIP_BAND - 1) / STRIP_BAND;
-  const dim3 grid((unsigned)((cols + 255) / 256), (unsigned)bands);
-  hipLaunchKernelGGL(strip_band_kernel<false>, grid, dim3(256), 0, stream, s32, s64_or_null, n, 0, cols, nullptr, nullptr, 0.0,
-                     ws + cols);
-  hipLaunchKernelGGL(strip_finish_kernel<false>, dim3(grid.x), dim3(256), 0, stream, ws + cols, cols, bands, ws);
+  const dim3 grid((unsigned)((cols + 1023) / 1024), (unsigned)bands);
+  if (s64_or_null)
+    hipLaunchKernelGGL((strip_band_kernel<false, true>), grid, dim3(256), 0, stream, s32, s64_or_null, n, 0, cols, nullptr, nullptr,
+                       0.0, ws + cols);
+  else
+    hipLaunchKernelGGL((strip_band_kernel<false, false>), grid, dim3(256), 0, stream, s32, s64_or_null, n, 0, cols, nullptr, nullptr,
+                       0.0, ws + cols);
+  hipLaunchKernelGGL(strip_finish_kernel<false>, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, stream, ws + cols, cols, bands, ws);
   return hipGetLastError();
 }
 
 hipError_t launch_strip_matvec(const int32_t* s32, const int64_t* s64_or_null, int32_t n, int32_t col0, int32_t cols,
                                const double* v, const double* means, double matrix_mean, double* ws, hipStream_t stream) {
   const int bands = (n + STRIP_BAND - 1) / STRIP_BAND;
-  const dim3 grid((unsigned)((cols + 255) / 256), (unsigned)bands);
-  hipLaunchKernelGGL(strip_band_kernel<true>, grid, dim3(256), 0, stream, s32, s64_or_null, n, col0, cols, v, means,
-                     matrix_mean, ws + cols);
-  hipLaunchKernelGGL(strip_finish_kernel<true>, dim3(grid.x), dim3(256), 0, stream, ws + cols, cols, bands, ws);
+  const dim3 grid((unsigned)((cols + 1023) / 1024), (unsigned)bands);
+  if (s64_or_null)
+    hipLaunchKernelGGL((strip_band_kernel<true, true>), grid, dim3(256), 0, stream, s32, s64_or_null, n, col0, cols, v, means,
+                       matrix_mean, ws + cols);
+  else
+    hipLaunchKernelGGL((strip_band_kernel<true, false>), grid, dim3(256), 0, stream, s32, s64_or_null, n, col0, cols, v, means,
+                       matrix_mean, ws + cols);
+  hipLaunchKernelGGL(strip_finish_kernel<true>, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, stream, ws + cols, cols, bands, ws);
   return hipGetLastError();
 }
 
