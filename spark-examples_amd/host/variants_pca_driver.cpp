@@ -72,7 +72,7 @@ struct Conf {  // PcaConf / GenomicsConf (GenomicsConf.scala:31-101), same flag 
   std::string reduce = "auto";        // --reduce auto|rccl|peer: all-reduce over RCCL / peer copies + int64 adds
   std::string plink_decode = "device";  // --plink-decode device|host: where the 2-bit codes become carrier bits
   long stream_rows = 131072;          // --stream-rows: variants per block of the streaming PLINK reader (four blocks are page-locked: 328 MB at N = 2504)
-  bool no_stream = false;             // --no-stream: PLINK through the in-memory path of r03 (carrier lists)
+  bool no_stream = false;             // --no-stream: a single PLINK fileset / VCF through the in-memory path (whole data set, then carrier lists)
 };
 
 [[noreturn]] void die(const std::string& m) {
@@ -388,8 +388,11 @@ std::string set_id_of(const std::string& path, size_t ordinal, std::set<std::str
   return stem;
 }
 
+// sink: called with every block's parsed records instead of keeping them (a single VCF is fed block by block, r05);
+// header_only: stop behind the #CHROM line (ids / names only).
 Dataset load_vcf(const std::string& path, const std::string& stem, const std::vector<Region>& regions, int32_t index_base,
-                 bool debug, int n_threads) {
+                 bool debug, int n_threads, const std::function<void(std::vector<ParsedLine>&)>* sink = nullptr,
+                 bool header_only = false) {
   Dataset d;
   BlockReader in(path);
   std::string block;
@@ -422,6 +425,7 @@ Dataset load_vcf(const std::string& path, const std::string& stem, const std::ve
             }
           }
           header = true;
+          if (header_only) return d;
         }
         continue;
       }
@@ -444,12 +448,16 @@ Dataset load_vcf(const std::string& path, const std::string& stem, const std::ve
       for (size_t t = 0; t < nt; ++t) pool.emplace_back(work, t);
       for (auto& th : pool) th.join();
     }
+    g_ingest_parse_s += now_s() - t0;
+    if (sink) {
+      (*sink)(parsed);
+      continue;
+    }
     for (auto& pl : parsed) {
       if (!pl.keep) continue;
       if (debug) std::fputs(pl.debug.c_str(), stdout);
       d.variants.push_back(std::move(pl.v));
     }
-    g_ingest_parse_s += now_s() - t0;
   }
   if (!header) die("no #CHROM header in " + path);
   return d;
@@ -897,6 +905,15 @@ int main(int argc, char** argv) {
     ids = plink.ids;
     names = plink.names;
   }
+  // A single VCF is streamed as well (r05): the header gives the callsets, then every 16-MiB block is parsed by the thread
+  // pool, filtered (--references, --min-allele-frequency) and handed to the engine as carrier lists while the next one is
+  // read -- the records of the whole file are never held (VariantsRDD.compute is an iterator, rdd/VariantsRDD.scala:205-235).
+  // Joins and merges need whole data sets, --gpus k a known row count: those keep the in-memory path.
+  const bool stream_vcf = conf.input_path.size() == 1 && !is_plink_path(conf.input_path[0]) && !conf.no_stream &&
+                          !conf.parse_only && !conf.debug_datasets && conf.gpus == 1;
+  std::string stream_stem;
+  std::vector<Region> stream_regions;
+  int64_t streamed_variants = 0;
   if (conf.input_path.size() > 1) std::printf("Running PCA on %zu datasets.\n", conf.input_path.size());
   for (size_t k = 0; k < conf.input_path.size() && !stream_plink; ++k) {
     std::vector<Region> regions;
@@ -909,8 +926,13 @@ int main(int argc, char** argv) {
       data.push_back(load_plink(conf.input_path[k], set_id_of(conf.input_path[k], k, used_stems), regions, (int32_t)ids.size(),
                                 conf.plink_ref_allele == "a1"));
     } else {
-      data.push_back(load_vcf(conf.input_path[k], set_id_of(conf.input_path[k], k, used_stems), regions, (int32_t)ids.size(),
-                              conf.debug_datasets, conf.ingest_threads));
+      const std::string stem = set_id_of(conf.input_path[k], k, used_stems);
+      if (stream_vcf) {
+        stream_stem = stem;
+        stream_regions = regions;
+      }
+      data.push_back(load_vcf(conf.input_path[k], stem, regions, (int32_t)ids.size(), conf.debug_datasets, conf.ingest_threads,
+                              nullptr, stream_vcf));
     }
     ids.insert(ids.end(), data.back().ids.begin(), data.back().ids.end());
     names.insert(names.end(), data.back().names.begin(), data.back().names.end());
@@ -995,6 +1017,27 @@ int main(int argc, char** argv) {
       stream_plink_shard(conf, plink, g, k, ctx, &stream_stats, four);
       return;
     }
+    if (stream_vcf) {
+      std::vector<int32_t> idx;
+      std::vector<int64_t> offs;
+      const std::function<void(std::vector<ParsedLine>&)> sink = [&](std::vector<ParsedLine>& parsed) {
+        idx.clear();
+        offs.assign(1, 0);
+        for (auto& pl : parsed) {
+          if (!pl.keep) continue;
+          if (conf.has_maf && !(pl.v.has_af && pl.v.af >= conf.min_allele_frequency)) continue;   // filterDataset (:96-108)
+          if (pl.v.carriers.empty()) continue;                                                     // getCallsRdd (:166)
+          idx.insert(idx.end(), pl.v.carriers.begin(), pl.v.carriers.end());
+          offs.push_back((int64_t)idx.size());
+        }
+        if (offs.size() > 1) {
+          check(ctx, pcoa_accumulate_calls_ex(ctx, idx.data(), offs.data(), (int64_t)offs.size() - 1, 0), "getSimilarityMatrix");
+          streamed_variants += (int64_t)offs.size() - 1;
+        }
+      };
+      (void)load_vcf(conf.input_path[0], stream_stem, stream_regions, 0, false, conf.ingest_threads, &sink);
+      return;
+    }
     int64_t ra, rb;
     shard_range(g, k, (int64_t)row_offsets.size() - 1, &ra, &rb);
     if (rb <= ra) return;
@@ -1036,8 +1079,9 @@ int main(int argc, char** argv) {
                    plink.prefix.c_str(), feed_s, stream_stats.variants / feed_s / 1e6, how.c_str(), stream_stats.read_s,
                    stream_stats.feed_s, conf.plink_decode.c_str(), ru.ru_maxrss / 1024.0);
     else
-      std::fprintf(stderr, "getSimilarityMatrix: %zu variants in %.3f s (%s); peak RSS %.0f MB\n", row_offsets.size() - 1, feed_s,
-                   how.c_str(), ru.ru_maxrss / 1024.0);
+      std::fprintf(stderr, "getSimilarityMatrix: %zu variants in %.3f s (%s%s); peak RSS %.0f MB\n",
+                   stream_vcf ? (size_t)streamed_variants : row_offsets.size() - 1, feed_s, how.c_str(),
+                   stream_vcf ? "; the VCF streamed block by block: read + parse + feed" : "", ru.ru_maxrss / 1024.0);
   }
   if (!conf.dump_similarity.empty()) {  // all N^2 entries, as matrix.iterator emits them (:189)
     std::vector<int64_t> sim((size_t)n * (size_t)n);

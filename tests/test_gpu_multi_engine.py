@@ -65,8 +65,11 @@ def test_goldens_as_vcf_through_two_engines_give_the_reference_matrix_and_the_sa
     write_golden_vcf(g, path)
     s1, r1 = _similarity(["--input-path", path], n, tmp_path, "one")
     s2, r2 = _similarity(["--input-path", path, "--gpus", "2", "--gpu-map", "0,0"], n, tmp_path, "two")
-    assert np.array_equal(s1, g["similarity"]) and np.array_equal(s2, s1)
-    assert r1.stdout == r2.stdout            # same S, same engine for computePca: the printed coordinates are identical
+    s3, r3 = _similarity(["--input-path", path, "--no-stream"], n, tmp_path, "mem")
+    assert np.array_equal(s1, g["similarity"]) and np.array_equal(s2, s1) and np.array_equal(s3, s1)
+    assert r1.stdout == r2.stdout == r3.stdout   # same S, same engine for computePca: the printed coordinates are identical
+    # r05: one engine streams a single VCF block by block; --gpus k and --no-stream hold the data set first
+    assert "streamed block by block" in r1.stderr and "streamed block by block" not in r2.stderr + r3.stderr
 
 
 def test_more_engines_than_devices_fails_loudly(tmp_path):
