@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define PCOA_VERSION_MAJOR 0
-#define PCOA_VERSION_MINOR 4
+#define PCOA_VERSION_MINOR 5
 
 typedef struct pcoa_ctx pcoa_ctx;
 
@@ -289,7 +289,7 @@ int pcoa_accumulate_bits(pcoa_ctx* ctx, const uint32_t* bits, int64_t n_variants
  * rule of every device input), PCOA_BED_HOST_ASYNC (r05) host rows in PAGE-LOCKED memory (pcoa_host_alloc_pinned) that the
  * call only QUEUES: it returns while the copy may still be running, so a host that rotates a few blocks keeps the link busy
  * while it reads the next block.  The rows of such a call must stay unmodified until the SECOND later call of this
- * function on the same ctx has returned (host rows travel through two device slots: a call that takes a slot first waits
+ * function (with n_variants > 0) on the same ctx has returned (host rows travel through two device slots: a call that takes a slot first waits
  * for the decode of the call that used it last) or until any synchronising call (pcoa_sync, pcoa_gram_finalize, ..).
  * Replaces: the same RDD[Seq[Int]] rows (getCallsRdd, VariantsPca.scala:153-168) for a cohort stored as a PLINK fileset. */
 #define PCOA_BED_HOST_ASYNC 2

@@ -1276,7 +1276,7 @@ const DebugKnobs& debug_knobs() {
 // ================================================================================================
 extern "C" {
 
-const char* pcoa_version(void) { return "pcoa_hip 0.3 (gfx950)"; }
+const char* pcoa_version(void) { return "pcoa_hip 0.5 (gfx950)"; }
 
 static int create_impl(pcoa_ctx** out, int32_t n_samples, int32_t device_ordinal, uint32_t flags, int32_t col0, int32_t cols) {
   if (!out) return fail(nullptr, PCOA_ERR_INVALID_ARG, "out is NULL");
