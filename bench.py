@@ -128,6 +128,9 @@ def main():
                          "the contraction) or fp4 (PCOA_FLAG_OPERAND_FP4, the r01 / r02 form)")
     ap.add_argument("--config2-variants", type=int, default=40000000,
                     help="extras: variants of the configs[2] cohort accumulated on this one GPU as bitsets (0 = skip)")
+    ap.add_argument("--config3-samples", type=int, default=100000,
+                    help="extras: sample count of the configs[3] job (100,000 samples x --config3-variants on this one GPU; 0 = skip)")
+    ap.add_argument("--config3-variants", type=int, default=1000000)
     ap.add_argument("--sustained-seconds", type=float, default=2.0,
                     help="extras: length of the additional sustained run (same step, >= this many seconds of timed region)")
     args = ap.parse_args()
@@ -263,14 +266,28 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(i)
+    t_local = t_red = None
+    if world > 1:
+        # (multi-rank only) this rank's own share ends when its partial S is finalized; the reduction step is timed apart
+        eng.finalize()
+        eng.sync()
+        t_local = time.perf_counter() - t0
+    t_r0 = time.perf_counter()
     finish_job()
+    if world > 1:
+        eng.sync()
+        t_red = time.perf_counter() - t_r0
     fence()
     elapsed = time.perf_counter() - t0
+    elapsed_rank = elapsed
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         elapsed = float(tt.item())
     tim = eng.timings()
+    # what a multi-rank record needs to explain itself: per-rank elapsed, the reduction step, the communicator's own rank count
+    tele = dist.collective_telemetry(t_local if t_local is not None else elapsed_rank, t_red if t_red is not None else 0.0, tim,
+                                     native.count() if native is not None else None, device=dev if world > 1 else None)
 
     out = None
     if rank == 0:
@@ -422,6 +439,16 @@ def main():
                        "gram_kernel": kdesc, "gram_kernel_mode": args.gram_kernel, "operand": args.operand,
                        "fp4_fallback_chunks": int(tim["fp4_fallbacks"])},
             "roofline": roofline, "roofline_other": roofline_other,
+            # multi-GPU telemetry (present at N = 1 too, so that the line has one shape): did RCCL see N ranks, what did the
+            # collective cost, how uneven were the ranks, and the per-GPU rate to hold against the N = 1 line
+            "rccl_ranks": tele["rccl_ranks"], "allreduce_ms": tele["allreduce_ms"] if world > 1 else None,
+            "allreduce_event_ms": tele["allreduce_event_ms"], "allreduce_int32_in_place": tele["allreduce_int32_in_place"],
+            "rank_elapsed_s": tele["rank_elapsed_s"], "rank_elapsed_min_s": tele["rank_elapsed_min_s"],
+            "rank_elapsed_max_s": tele["rank_elapsed_max_s"], "n1_equivalent_value": value / world,
+            "multi_gpu_note": "rank_elapsed_s = each rank's time to its finalized partial S; allreduce_ms = wall of the reduction "
+                              "step (max over ranks), allreduce_event_ms = the collective's HIP-event time on rank 0's stream; "
+                              "rccl_ranks = ncclCommCount of the library's communicator (None with --allreduce torch); "
+                              "n1_equivalent_value = value / n_gpus",
             "step_hbm_frac": step_hbm_frac,
             "step_hbm_note": "SURVEY 8(d) algorithmic bytes of a step (4*N per variant, X read once) / ms_per_step / 8 TB/s",
             "pipeline": info,
@@ -666,6 +693,13 @@ def main():
             out["parity_vs_cpu_sample"] = bool(np.array_equal(eng.gram(), s_ref))
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not args.no_extras and args.config3_samples > 0:
+            # BASELINE configs[3] at FULL size on this one GPU, by wall-clock (the reference cannot hold N > 46,340 at all,
+            # VariantsPca.scala:176-177, :185).  Last of the extras: the resident fp32 batches are released first (S alone is 40 GB).
+            x1 = None   # (a view of the resident batches)
+            del x, x_store
+            torch.cuda.empty_cache()
+            out["config3_one_gpu"] = config3_one_gpu(P, synth, torch, dev, local_rank, args.config3_samples, args.config3_variants)
         print(json.dumps(out), flush=True)
     if native is not None:
         native.close()
@@ -674,6 +708,103 @@ def main():
         td.destroy_process_group()
     eng.close()
     return 0
+
+
+def config3_one_gpu(P, synth, torch, dev, local_rank, n, v):
+    """BASELINE configs[3]: synthetic 100,000 samples x 10^6 variants (seed 1004), Gram + eig on ONE GPU, timed as WALL from the
+    first accumulate call to the finalized S, then pcoa_compute(2).  The genotypes are generated on the device inside the
+    timed region (the fp32 input would be 400 GB; pcoa_accumulate_synthetic writes the k-bits operand directly); the model's
+    thresholds (20 MB of parameters) are made on the host before it.  No CPU oracle can hold this job: the checks are the ones of
+    tools/config4_biobank.py -- the top-left 2504 x 2504 block against an INDEPENDENT N = 2504 engine fed the same variants
+    restricted to those samples, a far off-diagonal block against its mirror, the diagonal dominating its rows -- and the
+    engine's own on-device residual test of the eigenpairs; tests/test_gpu_baseline_sizes.py holds blocks of S at this N to the
+    CPU oracle at 65,536 variants and runs this job at full size."""
+    seed = 1004
+    now = time.perf_counter
+    free0, total = torch.cuda.mem_get_info(dev)
+    need = 4.0 * n * n + 16e9
+    if free0 < need:
+        return {"skipped": "needs %.0f GB of free HBM (S = %.0f GB int32 + operand buffers + workspaces), %.0f GB are free"
+                           % (need / 1e9, 4.0 * n * n / 1e9, free0 / 1e9)}
+    offs = synth.pop_offsets(n)
+    n_small = min(2504, int(offs[1]))
+    t = now()
+    thr = synth.thresholds(seed, 0, v)
+    t_thr = now() - t
+    t = now()
+    eng = P.PcoaEngine(n, device=local_rank)
+    t_create = now() - t
+    t = now()
+    eng.reserve(1 << 20, 2)
+    t_reserve = now() - t
+    t = now()
+    eng.accumulate_synthetic(seed, offs, thr[:4096], 0); eng.finalize(); eng.compute(2); eng.reset(); eng.reset_timings(); eng.sync()
+    t_warm = now() - t
+    chunk = 1 << 17
+    t0 = now()
+    for v0 in range(0, v, chunk):
+        eng.accumulate_synthetic(seed, offs, thr[v0:v0 + chunk], v0)
+    t_queued = now() - t0
+    eng.finalize()
+    eng.sync()
+    wall = now() - t0
+    tim = eng.timings()
+    free1, _ = torch.cuda.mem_get_info(dev)
+    t1 = now()
+    comps, lam, nz = eng.compute(2)
+    t_pcoa = now() - t1
+    t1 = now()
+    comps, lam, nz = eng.compute(2)
+    t_pcoa2 = now() - t1
+    tim2 = eng.timings()
+    # ---- checks (outside the timed region)
+    with P.PcoaEngine(n_small, device=local_rank) as small:
+        offs_small = np.array([0, n_small], dtype=np.int32)
+        thr0 = np.ascontiguousarray(thr[:, :1])
+        for v0 in range(0, v, chunk):
+            small.accumulate_synthetic(seed, offs_small, thr0[v0:v0 + chunk], v0)
+        ok_block = bool(np.array_equal(eng.gram_block(0, 0, n_small, n_small), small.gram()))
+    a = eng.gram_block(10, n - 300, 200, 256)
+    b = eng.gram_block(n - 300, 10, 256, 200)
+    ok_mirror = bool(np.array_equal(a, b.T)) and int(a.sum()) > 0
+    dg = eng.gram_block(n - 64, n - 64, 64, 64)
+    ok_diag = bool(np.array_equal(dg, dg.T)) and bool((np.diag(dg) >= dg.max(axis=1)).all())
+    # one mat-vec of the eigensolver on this S (pcoa_debug_centred_matvec: the vector crosses PCIe, 0.8 MB each way)
+    mv_s = None
+    if n % 4 == 0 and not tim2["gram_i64_live"]:
+        xv = np.random.default_rng(1).standard_normal(n)
+        eng.debug_centred_matvec(xv, 1)
+        tm = now()
+        for _ in range(3):
+            eng.debug_centred_matvec(xv, 1)
+        mv_s = (now() - tm) / 3.0
+    gk = tim["gram_kernel_seconds"]
+    issued = 2.0 * v * n * n / gk / 1e12 * issued_fraction(n, 256, diag=w4_diag_share()) if gk > 0 else 0.0
+    res = {"workload": "configs[3]: synthetic %d samples x %d variants (seed %d), 1x MI355X (Gram + eig on one GPU), generated on "
+                       "the device inside the timed region" % (n, v, seed),
+           "gram_wall_s": wall, "variants_per_s_wall": v / wall, "pcoa_wall_s": min(t_pcoa, t_pcoa2), "pcoa_wall_s_all": [t_pcoa, t_pcoa2],
+           "gram_plus_pcoa_wall_s": wall + min(t_pcoa, t_pcoa2),
+           "wall_breakdown_s": {"contraction_kernels": gk, "generation_kernels": tim["synth_seconds"], "pre_pass_kernels": tim["pack_seconds"],
+                                "finalize_kernels": tim["finalize_seconds"], "calls_returned_after": t_queued,
+                                "unaccounted": wall - gk - tim["synth_seconds"] - tim["pack_seconds"] - tim["finalize_seconds"]},
+           "outside_the_timed_region_s": {"thresholds_on_host": t_thr, "create_engine_40GB_S": t_create, "reserve": t_reserve,
+                                          "first_use_warm_up": t_warm},
+           "contraction": {"bound": "mfma", "kernel": "gram_kbits_w4_kernel<4, 0, 69> (banded split-K)", "launches": int(tim["gram_kernel_launches"]),
+                           "achieved": issued, "peak": PEAK_FP4_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": issued / PEAK_FP4_MFMA_TFLOPS,
+                           "algorithmic_pflops": 2.0 * v * n * n / gk / 1e15 if gk > 0 else None,
+                           "convention": "issued matrix-core work (upper-triangular 256 x 256 tiles)"},
+           "matvec": None if mv_s is None else {"bound": "hbm", "seconds_incl_pcie_of_the_vector": mv_s, "bytes": 2.0 * n * n,
+                                                "achieved": 2.0 * n * n / mv_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                                "frac": 2.0 * n * n / mv_s / 1e9 / PEAK_HBM_GBS,
+                                                "kernel": "symv_sym_tiles_kernel (upper-triangular 1024 x 1024 tiles of S, 2 N^2 bytes)"},
+           "pcoa_method": {1: "lanczos (verified residual)", 2: "householder"}.get(tim2["eig_method"], "?"),
+           "lanczos_steps": int(tim2["lanczos_steps"]), "matvec_form": int(tim2["matvec_form"]),
+           "eigenvalues": [float(t) for t in lam], "nonzero_rows": int(nz),
+           "unit_norm": [float(np.linalg.norm(comps[:, c])) for c in range(2)], "orthogonality": float(abs(comps[:, 0] @ comps[:, 1])),
+           "hbm_in_use_gb": (total - free1) / 1e9, "hbm_total_gb": total / 1e9,
+           "check_block_vs_independent_engine": ok_block, "check_mirror": ok_mirror, "check_diagonal": ok_diag}
+    eng.close()
+    return res
 
 
 def config2_one_gpu_bits(P, synth, torch, dev, local_rank, n, v, operand):

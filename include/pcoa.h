@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define PCOA_VERSION_MAJOR 0
-#define PCOA_VERSION_MINOR 5
+#define PCOA_VERSION_MINOR 6
 
 typedef struct pcoa_ctx pcoa_ctx;
 
@@ -117,6 +117,21 @@ typedef struct pcoa_timings {
   double csr_wait_seconds;      /* carrier lists: HOST seconds spent waiting for the device's check of a call     */
   int64_t csr_fast_chunks;      /* chunks (<= 8 M entries) scattered by the device-validated path                */
   int64_t csr_redo_chunks;      /* of those: redone on the int8 kernel because a list repeated a callset           */
+  /* ---- r06 ---- */
+  double allreduce_seconds;     /* pcoa_gram_allreduce_rccl: HIP-event time of the collective(s) on the ctx stream (agreement
+                                   words + the S all-reduce), summed over calls                                            */
+  int64_t allreduce_calls;
+  int32_t comm_ranks;           /* ncclCommCount of the communicator of the last pcoa_gram_allreduce_rccl (0 = never called) */
+  int32_t allreduce_int32;      /* 1 = that call reduced the int32 partial in place (4 N^2 bytes), 0 = the int64 branch     */
+  int32_t matvec_form;          /* of the last pcoa_compute's Lanczos: 0 = one wave per row over all N^2 entries, 1 = upper-
+                                   triangular tiles (N >= 16,384, no int64 part), 2 = materialised B                        */
+  int32_t gram_i64_live;        /* 1 = S currently has an int64 part (counts beyond int32), 0 = S lives in the int32 matrix  */
+  int64_t reduce_int32_calls;   /* pcoa_gram_reduce_from calls that took the int32 path (peer copy of 4 N^2 bytes)           */
+  int64_t narrowed_to_int32;    /* times an int64 S handed in (import / load / int64 reductions) was found to fit int32 and
+                                   moved back into the int32 matrix, which keeps the large-N upper-triangle forms available  */
+  int32_t lanczos_block_steps;  /* band-Lanczos fallback (clustered leading eigenvalues): basis vectors built by the last
+                                   pcoa_compute / pcoa_lanczos_with_matvec, 0 = the single-vector iteration sufficed         */
+  int32_t reserved_r06;
 } pcoa_timings;
 #define PCOA_TIMINGS_R03_BYTES 192  /* offsetof(pcoa_timings, csr_stage_seconds): what pcoa_get_timings writes */
 
@@ -334,6 +349,9 @@ int pcoa_comm_runtime(char* path_out, int32_t path_cap, int32_t* version_out);
 int pcoa_comm_init(pcoa_ctx* ctx, const uint8_t id[128], int32_t rank, int32_t n_ranks,
                    void** comm_out);
 int pcoa_comm_destroy(void* nccl_comm);
+/* Number of ranks of a communicator (ncclCommCount) -- what a bench line or a host log prints to show that the collective
+ * really spans the GPUs it was launched on.  *count_out = ranks. */
+int pcoa_comm_count(void* nccl_comm, int32_t* count_out);
 
 /* Page-locked host memory for input blocks a host fills and hands to the accumulate calls (hipHostMalloc): the DMA engine
  * reads it at link speed, pageable memory goes through the runtime's staging copy at a third of that.  Process-wide, not tied
@@ -343,8 +361,11 @@ int pcoa_host_free_pinned(void* p);
 
 /* dst.S += src.S for two engines of the SAME process (r04): what a host with one ctx per GPU -- k host threads, no
  * collective runtime -- calls after the accumulation (host/variants_pca_driver --gpus k; a Spark executor with several GPUs).
- * Both ctxs are synchronised; src's total crosses by hipMemcpyPeerAsync (xGMI on a node; the ctxs may also share a device) and
- * is added into dst's int64 matrix; src is unchanged.  Integer sums: order and grouping of the reductions do not matter.
+ * Both ctxs are synchronised; src's total crosses by hipMemcpyPeerAsync (xGMI on a node; the ctxs may also share a device).
+ * r06: when neither engine has an int64 part and the summed variant weights stay below 2^31 (the test pcoa_gram_allreduce_rccl
+ * applies) the int32 matrices are added in place -- 4 N^2 bytes cross, nothing is widened, and the large-N upper-triangle
+ * forms of computePca stay available on dst; otherwise src's total leaves as int64 and is added into dst's int64 matrix.
+ * src is unchanged.  Integer sums: order and grouping of the reductions do not matter.
  * Replaces: reduceByKey(_ + _, conf.numReducePartitions()) (VariantsPca.scala:190, GenomicsConf.scala:42-45) inside one JVM. */
 int pcoa_gram_reduce_from(pcoa_ctx* dst, pcoa_ctx* src);
 

@@ -70,6 +70,16 @@ class PcoaTimings(ctypes.Structure):
         ("csr_wait_seconds", ctypes.c_double),
         ("csr_fast_chunks", ctypes.c_int64),
         ("csr_redo_chunks", ctypes.c_int64),
+        ("allreduce_seconds", ctypes.c_double),
+        ("allreduce_calls", ctypes.c_int64),
+        ("comm_ranks", ctypes.c_int32),
+        ("allreduce_int32", ctypes.c_int32),
+        ("matvec_form", ctypes.c_int32),
+        ("gram_i64_live", ctypes.c_int32),
+        ("reduce_int32_calls", ctypes.c_int64),
+        ("narrowed_to_int32", ctypes.c_int64),
+        ("lanczos_block_steps", ctypes.c_int32),
+        ("reserved_r06", ctypes.c_int32),
     ]
 
 
@@ -125,6 +135,7 @@ _SIGNATURES = [
     ("pcoa_comm_unique_id", ctypes.c_int, [_vp]),
     ("pcoa_comm_init", ctypes.c_int, [_vp, _vp, _i32, _i32, ctypes.POINTER(_vp)]),
     ("pcoa_comm_destroy", ctypes.c_int, [_vp]),
+    ("pcoa_comm_count", ctypes.c_int, [_vp, ctypes.POINTER(_i32)]),
     ("pcoa_gram_export_device_i64", ctypes.c_int, [_vp, _vp]),
     ("pcoa_gram_import_device_i64", ctypes.c_int, [_vp, _vp]),
     ("pcoa_gram_read_i64", ctypes.c_int, [_vp, _vp]),

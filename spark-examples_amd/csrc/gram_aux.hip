@@ -125,6 +125,57 @@ __global__ __launch_bounds__(256) void synth_fill_kernel(uint64_t seed, const ui
   }
 }
 
+// The same model written straight into the k-bits operand K1[blk][npad][4 words] (gram_kbits.inl): the fp32 tile -- 400 GB
+// for configs[3]'s 100,000 samples x 10^6 variants -- is never written or read back (r06; r05: synth_fill_kernel into a staging
+// tile + pack_kbits_kernel, 0.14 + 0.07 s of that job).  One thread = (block of 128 variants, 4 samples): 128 Philox calls,
+// whose word t decides sample 4 g + t exactly as synth_fill_kernel's does (same key, same counter, same thresholds), 64
+// contiguous bytes out.  thr_s: the block's thresholds [128][n_pops]; rows beyond nv get threshold 0 (no carrier).
+__global__ __launch_bounds__(256) void synth_kbits_kernel(uint64_t seed, const uint32_t* __restrict__ thr,
+                                                          const int32_t* __restrict__ sample_pop, int32_t n_pops,
+                                                          int64_t first_variant, int64_t nv, int32_t n, int32_t npad,
+                                                          uint32_t* __restrict__ p) {
+  extern __shared__ uint32_t thr_s[];
+  const int64_t blk = blockIdx.y;
+  const int64_t left = nv - blk * 128;
+  const int rows = left >= 128 ? 128 : (left > 0 ? (int)left : 0);
+  for (int t = threadIdx.x; t < 128 * n_pops; t += 256) thr_s[t] = (t / n_pops < rows) ? thr[blk * 128 * n_pops + t] : 0u;
+  __syncthreads();
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g * 4 >= npad) return;
+  int pop[4];
+  uint32_t live[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int i = g * 4 + t;
+    live[t] = i < n ? 0xffffffffu : 0u;
+    pop[t] = i < n ? sample_pop[i] : 0;
+  }
+  uint32_t w[4][4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+#pragma unroll 2
+    for (int b = 0; b < 32; ++b) {
+      const int vl = c * 32 + b;
+      const uint64_t v = (uint64_t)(first_variant + blk * 128 + vl);
+      uint32_t x[4];
+      philox4x32_10((uint32_t)v, (uint32_t)(v >> 32), (uint32_t)g, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+      const uint32_t* tv = thr_s + vl * n_pops;
+      acc0 |= (uint32_t)(x[0] < tv[pop[0]]) << b;
+      acc1 |= (uint32_t)(x[1] < tv[pop[1]]) << b;
+      acc2 |= (uint32_t)(x[2] < tv[pop[2]]) << b;
+      acc3 |= (uint32_t)(x[3] < tv[pop[3]]) << b;
+    }
+    w[0][c] = acc0 & live[0];
+    w[1][c] = acc1 & live[1];
+    w[2][c] = acc2 & live[2];
+    w[3][c] = acc3 & live[3];
+  }
+  uint4* dst = reinterpret_cast<uint4*>(p + ((size_t)blk * npad + (size_t)g * 4) * 4);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) dst[t] = make_uint4(w[t][0], w[t][1], w[t][2], w[t][3]);
+}
+
 inline unsigned grid_for(int64_t count, int block, int64_t cap) {
   int64_t g = (count + block - 1) / block;
   if (g > cap) g = cap;
@@ -162,6 +213,58 @@ __global__ __launch_bounds__(256) void add_i64_kernel(int64_t* __restrict__ dst,
 
 hipError_t launch_add_i64(int64_t* dst, const int64_t* src, int64_t count, hipStream_t stream) {
   hipLaunchKernelGGL(add_i64_kernel, dim3(grid_for(count, 256, 8192)), dim3(256), 0, stream, dst, src, count);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void add_i32_kernel(int32_t* __restrict__ dst, const int32_t* __restrict__ src, int64_t count) {
+  const int64_t quads = count >> 2;
+  int4* d4 = reinterpret_cast<int4*>(dst);
+  const int4* s4 = reinterpret_cast<const int4*>(src);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (int64_t)gridDim.x * blockDim.x) {
+    int4 a = d4[i];
+    const int4 b = s4[i];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    d4[i] = a;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (count & 3)) dst[quads * 4 + threadIdx.x] += src[quads * 4 + threadIdx.x];
+}
+
+// dst += src for two finalized int32 partials whose sum is known to stay inside int32 (pcoa_gram_reduce_from, r06)
+hipError_t launch_add_i32(int32_t* dst, const int32_t* src, int64_t count, hipStream_t stream) {
+  // (hipMalloc / the guard allocator hand out 16-byte aligned buffers; N x N or N x cols from their start)
+  hipLaunchKernelGGL(add_i32_kernel, dim3(grid_for((count + 3) / 4, 256, 8192)), dim3(256), 0, stream, dst, src, count);
+  return hipGetLastError();
+}
+
+// int64 total -> int32 matrix where every entry fits (narrow_s64, pcoa_capi.hip): flag[0] is raised by an entry that does
+// not, the 64-bit word at flag + 2 receives max |entry|
+__global__ __launch_bounds__(256) void narrow_i64_kernel(const int64_t* __restrict__ s64, int32_t* __restrict__ s32, int64_t count,
+                                                         int32_t* __restrict__ flag) {
+  __shared__ unsigned long long red[4];
+  unsigned long long mx = 0;
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = s64[i];
+    const unsigned long long a = (unsigned long long)(v < 0 ? -v : v);
+    mx = a > mx ? a : mx;
+    bad = bad || a >= 0x7fffffffull;
+    s32[i] = (int32_t)v;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long other = __shfl_down(mx, o, 64);
+    mx = other > mx ? other : mx;
+  }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  const bool any_bad = __syncthreads_or(bad ? 1 : 0) != 0;
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) mx = red[w] > mx ? red[w] : mx;
+    atomicMax(reinterpret_cast<unsigned long long*>(flag + 2), mx);
+    if (any_bad) atomicOr(flag, 1);
+  }
+}
+
+hipError_t launch_narrow_i64_to_i32(const int64_t* s64, int32_t* s32, int64_t count, int32_t* flag, hipStream_t stream) {
+  hipLaunchKernelGGL(narrow_i64_kernel, dim3(grid_for(count, 256, 8192)), dim3(256), 0, stream, s64, s32, count, flag);
   return hipGetLastError();
 }
 
@@ -234,6 +337,17 @@ hipError_t launch_synth_fill_f32(uint64_t seed, const uint32_t* thresholds_dev, 
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(synth_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, seed, thresholds_dev,
                      sample_pop_dev, n_pops, first_variant, nv, n, ngroups, x_dev, ld, vec_ok);
+  return hipGetLastError();
+}
+
+hipError_t launch_synth_kbits(uint64_t seed, const uint32_t* thresholds_dev, const int32_t* sample_pop_dev, int32_t n_pops,
+                              int64_t first_variant, int64_t nv, int32_t n, int32_t npad, int8_t* p, int64_t nblk_out,
+                              hipStream_t stream) {
+  if (nblk_out <= 0) return hipSuccess;
+  if (nblk_out > 65535 || n_pops <= 0 || n_pops > 64) return hipErrorInvalidValue;
+  const unsigned gx = (unsigned)((npad / 4 + 255) / 256);
+  hipLaunchKernelGGL(synth_kbits_kernel, dim3(gx, (unsigned)nblk_out), dim3(256), (size_t)(128 * n_pops) * sizeof(uint32_t), stream,
+                     seed, thresholds_dev, sample_pop_dev, n_pops, first_variant, nv, n, npad, reinterpret_cast<uint32_t*>(p));
   return hipGetLastError();
 }
 

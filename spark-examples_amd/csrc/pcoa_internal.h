@@ -48,6 +48,8 @@ struct DebugKnobs {
   int bits_pipeline = 0;           // PCOA_BITS_PIPELINE = 1: bitset tiles through the co-resident pipeline as in r03 / r04 (default: transpose and contraction in series, the contraction as the one-wave-per-SIMD kernel)
   int headstart_us = -1;           // PCOA_HEADSTART_US: the contraction's head start over the next pre-pass (default 10; 0 = none)
   int kbits_coreside_max_npad = 0; // PCOA_KBITS_CORESIDE_MAX_NPAD: largest padded sample count the co-resident pipeline is used for
+  int synth_tile = 0;              // PCOA_SYNTH_TILE = 1: pcoa_accumulate_synthetic through the fp32 staging tile + pre-pass (r05 path) instead of generating the k-bits operand directly
+  int no_narrow = 0;               // PCOA_NO_NARROW = 1: an int64 S that fits int32 stays int64 and pcoa_gram_reduce_from always widens (r05 behaviour; tests of the int64 kernels)
 };
 const DebugKnobs& debug_knobs();
 
@@ -144,9 +146,18 @@ hipError_t launch_export_i64(const int32_t* s32, const int64_t* s64_or_null, int
 hipError_t launch_plink_bed_to_bits(const uint8_t* bed, int64_t row_bytes, int64_t nv, int32_t n, int64_t words, int ref_a1,
                                     uint32_t* bits, hipStream_t stream);
 hipError_t launch_add_i64(int64_t* dst, const int64_t* src, int64_t count, hipStream_t stream);
+hipError_t launch_add_i32(int32_t* dst, const int32_t* src, int64_t count, hipStream_t stream);
+// s32[i] = (int32) s64[i] where it fits; flag[0] != 0 if some entry does not; ((int64*)flag)[1] = max |entry| (flag: 16 zeroed bytes)
+hipError_t launch_narrow_i64_to_i32(const int64_t* s64, int32_t* s32, int64_t count, int32_t* flag, hipStream_t stream);
 hipError_t launch_synth_fill_f32(uint64_t seed, const uint32_t* thresholds_dev, const int32_t* sample_pop_dev,
                                  int32_t n_pops, int64_t first_variant, int64_t nv, int32_t n, float* x_dev,
                                  int64_t ld, hipStream_t stream);
+
+// the same genotypes straight into the k-bits operand (nblk_out blocks of 128 variants, the tail beyond nv zero; n_pops <= 64,
+// nblk_out <= 65,535); thresholds_dev: [nv][n_pops] of exactly this range
+hipError_t launch_synth_kbits(uint64_t seed, const uint32_t* thresholds_dev, const int32_t* sample_pop_dev, int32_t n_pops,
+                              int64_t first_variant, int64_t nv, int32_t n, int32_t npad, int8_t* p, int64_t nblk_out,
+                              hipStream_t stream);
 
 // ---- centring (center.hip) --------------------------------------------------------------------
 // s = s32 + (s64 ? s64 : 0).  row_sums[n] (fp64), stats[0] = matrix sum, stats[1] = matrix mean,

@@ -96,10 +96,41 @@ class NativeComm(object):
     def allreduce(self):
         self.engine.allreduce_rccl(self.comm)
 
+    def count(self):
+        """ncclCommCount of the communicator (pcoa_comm_count): the rank count RCCL itself reports."""
+        return self.engine.comm_count(self.comm)
+
     def close(self):
         if self.comm is not None:
             self.engine.comm_destroy(self.comm)
             self.comm = None
+
+
+def collective_telemetry(elapsed_local_s, allreduce_wall_s, timings=None, rccl_ranks=None, group=None, device=None):
+    """What a multi-rank record must carry to explain itself: the per-rank elapsed times (all-gathered),
+    their min / max, the wall time of the reduction step (max over ranks), the collective's own HIP-event time when the
+    library ran it (pcoa_timings.allreduce_seconds), and the rank count the communicator reports.  Works on any backend
+    (gloo in the CPU tests); without an initialised process group it describes the single rank."""
+    import torch
+    import torch.distributed as dist
+    world, rank = 1, 0
+    per_rank = [float(elapsed_local_s)]
+    red = float(allreduce_wall_s)
+    if dist.is_available() and dist.is_initialized():
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
+        mine = torch.tensor([float(elapsed_local_s), float(allreduce_wall_s)], dtype=torch.float64, device=dev)
+        got = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine, group=group)
+        per_rank = [float(g[0]) for g in got]
+        red = max(float(g[1]) for g in got)
+    t = timings or {}
+    return {"world_size": world, "rank": rank,
+            "rccl_ranks": int(rccl_ranks) if rccl_ranks is not None else (int(t.get("comm_ranks", 0)) or None),
+            "allreduce_ms": 1e3 * red,
+            "allreduce_event_ms": 1e3 * float(t.get("allreduce_seconds", 0.0)) if t.get("allreduce_calls", 0) else None,
+            "allreduce_int32_in_place": bool(t.get("allreduce_int32", 0)) if t.get("allreduce_calls", 0) else None,
+            "rank_elapsed_s": per_rank, "rank_elapsed_min_s": min(per_rank), "rank_elapsed_max_s": max(per_rank)}
 
 
 def allreduce_gram_numpy(s_local, group=None):

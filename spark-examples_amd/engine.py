@@ -380,6 +380,11 @@ class PcoaEngine(object):
     def comm_destroy(self, comm):
         self._check(self._lib.pcoa_comm_destroy(comm))
 
+    def comm_count(self, comm):
+        n = ctypes.c_int32(0)
+        self._check(self._lib.pcoa_comm_count(comm, ctypes.byref(n)))
+        return int(n.value)
+
     def allreduce_rccl(self, comm):
         self._check(self._lib.pcoa_gram_allreduce_rccl(self._ctx, comm))
 
@@ -443,7 +448,7 @@ class PcoaEngine(object):
     def timings(self):
         t = L.PcoaTimings()
         self._check(self._lib.pcoa_get_timings_sized(self._ctx, ctypes.byref(t), ctypes.sizeof(t)))
-        return dict((f[0], getattr(t, f[0])) for f in L.PcoaTimings._fields_ if f[0] != "reserved")
+        return dict((f[0], getattr(t, f[0])) for f in L.PcoaTimings._fields_ if not f[0].startswith("reserved"))
 
     def reset_timings(self):
         self._check(self._lib.pcoa_reset_timings(self._ctx))
