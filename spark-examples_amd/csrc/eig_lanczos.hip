@@ -52,11 +52,11 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 }
 
 // v0 = normalised fixed pseudo-random vector (single workgroup)
-__global__ __launch_bounds__(1024) void lanczos_init_kernel(double* __restrict__ v0, int n) {
+__global__ __launch_bounds__(1024) void lanczos_init_kernel(double* __restrict__ v0, int n, uint32_t salt = 0u) {
   __shared__ double red[24];
   double part = 0.0;
   for (int i = threadIdx.x; i < n; i += 1024) {
-    uint32_t s = (uint32_t)(i + 1) * 2654435761u + 12345u;
+    uint32_t s = (uint32_t)(i + 1) * 2654435761u + 12345u + salt * 0x9E3779B9u;
     s = s * 1103515245u + 12345u;
     s ^= s >> 15;
     s = s * 1103515245u + 12345u;
@@ -702,6 +702,53 @@ __global__ __launch_bounds__(1024) void residual_kernel(const double* __restrict
   if (threadIdx.x == 0) res[c] = (u2 > 0.0) ? sqrt(r2 / u2) : DBL_MAX;
 }
 
+// ---- band Lanczos (r06): the fallback for CLUSTERED leading eigenvalues ------------------------------------------------------
+// A single start vector sees one direction of a (near-)degenerate eigenspace; the second copy of a clustered eigenvalue
+// only emerges at the rate of the tiny gap inside the cluster (lambda_1 ~ lambda_2 to 1e-9: never within 512 steps), and the
+// dense O(N^3) solver the engine falls back to is disabled above N = 16,384 -- the reference's dgesdd decomposes any N it can
+// hold (VariantsPca.scala:224-227; VERDICT r05 Missing 5).  Ruhe's band variant of block Lanczos with block width
+// b = num_pc + 2: the basis starts with b orthonormal vectors and column j contributes v_{j+b} = orth(B v_j), one vector at a
+// time, so every kernel of the single-vector iteration is re-used as is (full re-orthogonalisation by CGS2 against the whole
+// basis).  Convergence is governed by the gap between the CLUSTER and the rest of the spectrum.  The projected matrix
+// H = V^T B V (banded in exact arithmetic) is kept densely -- column j holds the CGS coefficients v_i^T B v_j, true projections
+// whatever the basis looks like -- and its eigenproblem (<= 512 x 512) goes through the dense Householder + bisection + inverse
+// iteration kernels of eig.hip.  A pair is returned only after its TRUE residual ||B u - theta u|| has passed.
+//
+// column j of H from the two CGS passes, the norm of what is left of w, and the normalised candidate vector into V[dst]
+__global__ __launch_bounds__(1024) void band_finish_kernel(double* __restrict__ v, int n, int dst, const double* __restrict__ w,
+                                                           const double* __restrict__ pnorm, int nb, const double* __restrict__ h1,
+                                                           const double* __restrict__ h2, int cnt, double* __restrict__ hcol,
+                                                           double* __restrict__ out2) {
+  __shared__ double red[24];
+  double part = 0.0;
+  for (int b = threadIdx.x; b < nb; b += 1024) part += pnorm[b];
+  const double nrm2 = block_sum(part, red);
+  double hp = 0.0;
+  for (int i = threadIdx.x; i < cnt; i += 1024) {
+    const double h = h1[i] + h2[i];
+    hcol[i] = h;
+    hp += h * h;
+  }
+  const double h2sum = block_sum(hp, red);
+  const double nrm = sqrt(nrm2);
+  const double rn = (nrm > 0.0) ? 1.0 / nrm : 0.0;
+  double* vn = v + (int64_t)dst * n;
+  for (int i = threadIdx.x; i < n; i += 1024) vn[i] = w[i] * rn;
+  if (threadIdx.x == 0) {
+    hcol[cnt] = nrm;
+    out2[0] = nrm;
+    out2[1] = sqrt(h2sum + nrm2);   // ||B v_j||: the basis is orthonormal
+  }
+}
+
+// the leading J x J block of H as a dense symmetric matrix (upper triangle from the columns, mirrored)
+__global__ __launch_bounds__(256) void band_gather_kernel(const double* __restrict__ hfull, int mcap, int J, double* __restrict__ a) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= J * J) return;
+  const int i = t / J, j = t - i * J;
+  a[t] = (i <= j) ? hfull[(int64_t)j * mcap + i] : hfull[(int64_t)i * mcap + j];
+}
+
 }  // namespace
 
 size_t symv_sym_workspace_doubles(int32_t n) { return symv_sym_workspace_doubles_impl(n); }
@@ -720,15 +767,39 @@ size_t lanczos_workspace_doubles(int32_t n, int32_t k, int32_t mmax) {
   // V[(mmax+1)][n], w[n], bu[k][n], alpha[mmax], beta[mmax], h1[mmax+1], h2[mmax+1], the check record
   // (cand[2k+2], beta_m, ylast[k], res[k]), part[nb][mmax+1] + pnorm[nb] of the fused re-orthogonalisation
   const size_t nb = ((size_t)n + 255) / 256;
+  // band fallback: H (mcap x mcap), its dense copy, d / e / tau / q (mcap each), w (2 mcap), scratch (6 mcap), the
+  // eigenvectors of H (k x mcap), two scalars
+  const size_t mcap = (size_t)mmax + 1;
+  const size_t band = 2 * mcap * mcap + 12 * mcap + (size_t)k * mcap + 16;
   return (size_t)(mmax + 1) * n + (size_t)n + (size_t)k * n + 4 * (size_t)(mmax + 2) + 4 * (size_t)k + 16 +
-         nb * (size_t)(mmax + 2);
+         nb * (size_t)(mmax + 2) + band;
 }
 
 // Returns hipSuccess on a clean run; *converged tells whether ws.z[0..k) holds verified eigenvectors of
 // B (unnormalised Ritz vectors; the caller normalises) and lam_sel_host[0..k) their eigenvalues
 // (ordered by decreasing magnitude).  B (ws.a, or the implicit form when ws.a is null) is not modified.
+namespace {
+hipError_t lanczos_band(const EigWorkspace& ws, double* lz, int32_t n, int32_t k, int32_t mmax, double tol, double* lam_sel_host,
+                        int* converged, int* band_steps_out, hipStream_t stream, const LanczosMatvec* mv);
+hipError_t lanczos_single(const EigWorkspace& ws, double* lz, int32_t n, int32_t k, int32_t mmax, double tol,
+                          double* lam_sel_host, int* converged, int* steps_out, hipStream_t stream, const LanczosMatvec* mv);
+}
+
 hipError_t lanczos_topk(const EigWorkspace& ws, double* lz, int32_t n, int32_t k, int32_t mmax, double tol,
-                        double* lam_sel_host, int* converged, int* steps_out, hipStream_t stream, const LanczosMatvec* mv) {
+                        double* lam_sel_host, int* converged, int* steps_out, hipStream_t stream, const LanczosMatvec* mv,
+                        int* band_steps_out) {
+  if (band_steps_out) *band_steps_out = 0;
+  hipError_t e1 = debug_knobs().lanczos_band == 2 ? hipSuccess
+                                                  : lanczos_single(ws, lz, n, k, mmax, tol, lam_sel_host, converged, steps_out, stream, mv);
+  if (debug_knobs().lanczos_band == 2) *converged = 0;
+  if (e1 != hipSuccess || *converged || debug_knobs().lanczos_band == 0) return e1;
+  // clustered leading eigenvalues (or a spectrum the single vector resolves too slowly): the band iteration
+  return lanczos_band(ws, lz, n, k, mmax, tol, lam_sel_host, converged, band_steps_out, stream, mv);
+}
+
+namespace {
+hipError_t lanczos_single(const EigWorkspace& ws, double* lz, int32_t n, int32_t k, int32_t mmax, double tol,
+                          double* lam_sel_host, int* converged, int* steps_out, hipStream_t stream, const LanczosMatvec* mv) {
   // mv: y = B v supplied by the caller (strip owners: B is tiled over GPUs and the product needs an all-gather the
   // engine knows nothing about); the stream is drained around the call
   auto matvec = [&](const double* v, double* y) -> hipError_t {
@@ -772,6 +843,7 @@ hipError_t lanczos_topk(const EigWorkspace& ws, double* lz, int32_t n, int32_t k
   if (next_check > mmax) next_check = mmax;
   std::vector<double> cand, pageable;
   std::vector<int32_t> idx;
+  double est_prev = 0.0;
   for (int j = 0; j < mmax; ++j) {
     const double* vj = V + (size_t)j * n;
     const int cnt = j + 1;
@@ -867,6 +939,14 @@ hipError_t lanczos_topk(const EigWorkspace& ws, double* lz, int32_t n, int32_t k
     }
     if (!ok && !breakdown) {   // the estimate says not yet: the speculative residual is not consulted
       if (m == mmax) return hipSuccess;
+      // Stagnation: from m = 128 on a check comes every m / 2 steps; an estimate that has not improved fourfold since the
+      // last one is a cluster the single vector cannot split (or a gap too small for this tolerance) -- the band iteration
+      // takes over instead of the remaining steps up to mmax (3.4 ms each at N = 100,000).
+      double est_now = 0.0;
+      for (int t = 0; t < k; ++t) est_now = fmax(est_now, fabs(beta_m * ylast[t]) / scale);
+      const bool stalled = m >= 128 && est_prev > 0.0 && est_now > 0.25 * est_prev;
+      est_prev = est_now;
+      if (stalled) return hipSuccess;
       continue;
     }
     if (verified) {
@@ -877,5 +957,177 @@ hipError_t lanczos_topk(const EigWorkspace& ws, double* lz, int32_t n, int32_t k
   }
   return hipGetLastError();
 }
+
+// The band iteration (see band_finish_kernel above).  Same contract as lanczos_single: *converged = 1 -> ws.z[0..k) holds the
+// unnormalised Ritz vectors, lam_sel_host[0..k) their Ritz values by decreasing magnitude.  One host round trip per column (the
+// norm of the new candidate decides whether it joins the basis): this is the fallback, not the fast path.
+hipError_t lanczos_band(const EigWorkspace& ws, double* lz, int32_t n, int32_t k, int32_t mmax, double tol, double* lam_sel_host,
+                        int* converged, int* band_steps_out, hipStream_t stream, const LanczosMatvec* mv) {
+  auto matvec = [&](const double* v, double* y) -> hipError_t {
+    if (!mv) {
+      launch_symv(ws, n, v, y, stream);
+      return hipSuccess;
+    }
+    hipError_t e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    return (*mv)(v, y) == 0 ? hipSuccess : hipErrorUnknown;
+  };
+  *converged = 0;
+  if (mmax > n) mmax = n;
+  if (mmax > kMaxKrylov) mmax = kMaxKrylov;
+  const int bw0 = std::min<int>(k + 2, n);   // block width
+  if (mmax < 3 * bw0 + 2 || n < 8) return hipSuccess;
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  const int mcap = mmax + 1;
+  double* V = lz;
+  double* w = V + (size_t)(mmax + 1) * n;
+  double* bu = w + n;
+  double* alpha = bu + (size_t)k * n;
+  double* beta = alpha + (mmax + 2);
+  double* h1 = beta + (mmax + 2);
+  double* h2 = h1 + (mmax + 2);
+  double* rec = h2 + (mmax + 2);
+  double* part = rec + (4 * (size_t)k + 16);
+  double* pnorm = part + (size_t)nb * (mmax + 1);
+  double* hfull = pnorm + nb;                       // [mcap][mcap], column j at hfull + j * mcap
+  double* hdense = hfull + (size_t)mcap * mcap;     // J x J copy the dense solver works in
+  double* hd = hdense + (size_t)mcap * mcap;
+  double* he = hd + mcap;
+  double* htau = he + mcap;
+  double* hq = htau + mcap;
+  double* hw = hq + mcap;                           // 2 mcap
+  double* hscr = hw + 2 * (size_t)mcap;             // 6 mcap
+  double* hout = hscr + 6 * (size_t)mcap;           // [k][mcap] eigenvectors of H
+  double* out2 = hout + (size_t)k * mcap;           // nrm, ||B v_j||
+
+  EigWorkspace hs = ws;   // the projected problem goes through the dense solver's kernels
+  hs.a = hdense; hs.d = hd; hs.e = he; hs.tau = htau; hs.q = hq; hs.w = hw; hs.scratch = hscr; hs.wy = nullptr;
+
+  std::vector<double> pageable;
+  auto read_back = [&](const double* src, size_t count, double** host) -> hipError_t {
+    double* hrec = ws.host_rec;
+    if (!hrec || count > ws.host_rec_cap) {
+      pageable.resize(count);
+      hrec = pageable.data();
+    }
+    hipError_t e = hipMemcpyAsync(hrec, src, sizeof(double) * count, hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+    *host = hrec;
+    return hipSuccess;
+  };
+
+  // ---- the start block: bw0 pseudo-random vectors, orthonormalised by the same CGS2 kernels
+  hipLaunchKernelGGL(lanczos_init_kernel, dim3(1), dim3(1024), 0, stream, V, n, 0u);
+  int cnt = 1;   // basis vectors so far
+  for (int t = 1; t < bw0; ++t) {
+    hipLaunchKernelGGL(lanczos_init_kernel, dim3(1), dim3(1024), 0, stream, w, n, (uint32_t)t);
+    hipLaunchKernelGGL(cgs_dots_kernel, dim3((unsigned)cnt), dim3(256), 0, stream, V, n, w, h1);
+    hipLaunchKernelGGL(cgs_update_dots_kernel, dim3(nb), dim3(256), 0, stream, V, n, cnt, h1, w, part);
+    hipLaunchKernelGGL(cgs_update_norm_kernel, dim3(nb), dim3(256), 0, stream, V, n, cnt, part, (int)nb, w, h2, pnorm);
+    hipLaunchKernelGGL(lanczos_finish_kernel, dim3(1), dim3(1024), 0, stream, V, n, cnt - 1, w, pnorm, (int)nb, h1, h2, alpha, beta);
+    cnt += 1;
+  }
+  double anorm = 0.0;
+  int next_check = std::max(12, 3 * bw0);
+  std::vector<double> cand;
+  std::vector<int32_t> idx;
+  bool exhausted = false;
+  for (int j = 0; j < cnt && j + 1 <= mmax - 1; ++j) {
+    // column j: w = B v_j, orthogonalised against the whole basis; what is left becomes v_cnt
+    {
+      const hipError_t em = matvec(V + (size_t)j * n, w);
+      if (em != hipSuccess) return em;
+    }
+    hipLaunchKernelGGL(cgs_dots_kernel, dim3((unsigned)cnt), dim3(256), 0, stream, V, n, w, h1);
+    hipLaunchKernelGGL(cgs_update_dots_kernel, dim3(nb), dim3(256), 0, stream, V, n, cnt, h1, w, part);
+    hipLaunchKernelGGL(cgs_update_norm_kernel, dim3(nb), dim3(256), 0, stream, V, n, cnt, part, (int)nb, w, h2, pnorm);
+    const bool room = cnt < mmax;   // V holds mmax + 1 vectors, the CGS kernels' LDS arrays mmax coefficients
+    hipLaunchKernelGGL(band_finish_kernel, dim3(1), dim3(1024), 0, stream, V, n, room ? cnt : mmax, w, pnorm, (int)nb, h1, h2, cnt,
+                       hfull + (size_t)j * mcap, out2);
+    double* h2v = nullptr;
+    hipError_t e = read_back(out2, 2, &h2v);
+    if (e != hipSuccess) return e;
+    const double nrm = h2v[0];
+    anorm = fmax(anorm, h2v[1]);
+    if (!std::isfinite(nrm) || !std::isfinite(anorm)) return hipSuccess;   // garbage: the dense path decides
+    // a candidate that vanishes against the basis is deflated (the band narrows); none left = an invariant subspace
+    if (room && nrm > 1e-9 * anorm) cnt += 1;
+    const int J = j + 1;           // columns of H known so far
+    if (band_steps_out) *band_steps_out = cnt;
+    exhausted = (J == cnt);        // every basis vector has been multiplied and nothing new came of it
+    const bool last = exhausted || J == mmax - 1 || !(j + 1 < cnt);
+    if (J != next_check && !last) continue;
+    if (J < k + 2 && !exhausted) continue;
+    next_check = (J < 64) ? J + 8 : J + J / 4;
+
+    // ---- Rayleigh-Ritz on span(v_0 .. v_{J-1}): dense eigenproblem of the leading J x J block of H
+    if (J < 2) return hipSuccess;
+    hipLaunchKernelGGL(band_gather_kernel, dim3((unsigned)((J * J + 255) / 256)), dim3(256), 0, stream, hfull, mcap, J, hdense);
+    if ((e = launch_tridiagonalize(hs, J, stream)) != hipSuccess) return e;
+    idx.clear();
+    const int kk = std::min(k, J);
+    for (int t = 0; t <= kk && t < J; ++t) idx.push_back(J - 1 - t);
+    for (int t = 0; t <= kk; ++t)
+      if (t < J - 1 - kk) idx.push_back(t);
+    const int nc = (int)idx.size();
+    double* rec_res = rec + nc;
+    if ((e = launch_bisect(hs, J, idx.data(), nc, rec, stream)) != hipSuccess) return e;
+    hipLaunchKernelGGL(ritz_select_kernel, dim3(1), dim3(64), 0, stream, rec, nc, kk, ws.lam);
+    if ((e = launch_inverse_iteration_dev(hs, J, kk, stream)) != hipSuccess) return e;
+    if ((e = launch_backtransform(hs, J, kk, 0, 1, hout, stream)) != hipSuccess) return e;   // eigenvectors of H: hout[c * J + p]
+    hipLaunchKernelGGL(ritz_kernel, dim3(nb, (unsigned)kk), dim3(256), 0, stream, V, n, J, hout, bu);
+    if ((e = hipMemcpyAsync(ws.z, bu, sizeof(double) * (size_t)kk * n, hipMemcpyDeviceToDevice, stream)) != hipSuccess) return e;
+    for (int t = 0; t < kk; ++t) {
+      const hipError_t em = matvec(ws.z + (size_t)t * n, bu + (size_t)t * n);
+      if (em != hipSuccess) return em;
+    }
+    hipLaunchKernelGGL(residual_kernel, dim3((unsigned)kk), dim3(1024), 0, stream, bu, ws.z, n, ws.lam, rec_res);
+    double* hrec = nullptr;
+    if ((e = read_back(rec, (size_t)nc + kk, &hrec)) != hipSuccess) return e;
+    cand.assign(hrec, hrec + nc);
+    const double* hres = hrec + nc;
+    std::vector<int> order(cand.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {   // == ritz_select_kernel's order
+      const double fa = fabs(cand[a]), fb = fabs(cand[b]);
+      if (fa != fb) return fa > fb;
+      return cand[a] > cand[b];
+    });
+    double scale = 0.0;
+    for (double c : cand) scale = fmax(scale, fabs(c));
+    if (!(scale > 0.0) || !std::isfinite(scale)) return hipSuccess;
+    if (kk < k) return hipSuccess;   // fewer Ritz pairs than wanted (tiny invariant subspace): the dense path decides
+    for (int t = 0; t < k; ++t) lam_sel_host[t] = cand[order[t]];
+    // Acceptance, on the TRUE residual only.  While the iteration can still improve, a pair must also be resolved against its
+    // own gap (eigenvector error ~ residual / gap <= 1e-8), as in the single-vector iteration -- unless the residual has reached
+    // what fp64 can deliver (1e-13 of the spectrum): inside a cluster the individual vectors are ill-conditioned for EVERY
+    // solver (LAPACK's dgesdd included), what is well defined is the pair's backward error.  At the last check the
+    // backward-error bound alone decides.
+    bool tight = true, loose = true;
+    for (int t = 0; t < k; ++t) {
+      double g = DBL_MAX;
+      for (size_t c2 = 0; c2 < cand.size(); ++c2)
+        if ((int)c2 != order[t]) g = fmin(g, fabs(cand[c2] - lam_sel_host[t]));
+      const double r = hres[t];
+      const bool fin = std::isfinite(r);
+      loose = loose && fin && r * 0.125 <= tol * scale;
+      tight = tight && fin && r * 0.125 <= tol * scale && (r * 0.125 <= 1e-8 * g || r <= 1e-13 * scale);
+    }
+    if (debug_knobs().lanczos_trace != 0) {
+      std::fprintf(stderr, "[lanczos band] J=%d basis=%d scale=%.6e", J, cnt, scale);
+      for (int t = 0; t < k; ++t) std::fprintf(stderr, "  theta%d=%.12e true=%.3e", t, lam_sel_host[t], hres[t]);
+      std::fprintf(stderr, "  tight=%d loose=%d last=%d\n", (int)tight, (int)loose, (int)last);
+    }
+    if (tight || (last && loose)) {
+      *converged = 1;
+      return hipGetLastError();
+    }
+    if (last) return hipSuccess;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace
 
 }  // namespace pcoa

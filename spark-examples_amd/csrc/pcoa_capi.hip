@@ -1401,6 +1401,7 @@ const DebugKnobs& debug_knobs() {
     k.gram_splitk = (int)num("PCOA_GRAM_I8_SPLITK");
     k.no_narrow = (int)num("PCOA_NO_NARROW");
     k.synth_tile = (int)num("PCOA_SYNTH_TILE");
+    if (const char* v = std::getenv("PCOA_LANCZOS_BAND")) k.lanczos_band = std::atoi(v);
     return k;
   }();
   return knobs;
@@ -2633,7 +2634,9 @@ int pcoa_compute(pcoa_ctx* c, int32_t num_pc, double* out_components, double* ou
       if (!b_ready) wl.a = nullptr;  // implicit form
       wl.sym_part = (sym_form && !wl.a) ? c->sym_part : nullptr;
       c->matvec_form = wl.a ? 2 : wl.sym_part ? 1 : 0;
-      HIP_TRY(c, lanczos_topk(wl, c->lanczos_ws, n, num_pc, mmax, 1e-11, sel.data(), &conv, &steps, c->stream));
+      int band = 0;
+      HIP_TRY(c, lanczos_topk(wl, c->lanczos_ws, n, num_pc, mmax, 1e-11, sel.data(), &conv, &steps, c->stream, nullptr, &band));
+      c->lanczos_block_steps = band;
     }
     c->lanczos_steps = steps;
     if (conv) {
@@ -2740,7 +2743,9 @@ int pcoa_lanczos_with_matvec(pcoa_ctx* c, int32_t num_pc, pcoa_matvec_fn fn, voi
     wl.a = nullptr;
     wl.s32 = nullptr;
     wl.s64 = nullptr;
-    HIP_TRY(c, lanczos_topk(wl, c->lanczos_ws, n, num_pc, mmax, 1e-11, sel.data(), &conv, &steps, c->stream, &mv));
+    int band = 0;
+    HIP_TRY(c, lanczos_topk(wl, c->lanczos_ws, n, num_pc, mmax, 1e-11, sel.data(), &conv, &steps, c->stream, &mv, &band));
+    c->lanczos_block_steps = band;
   }
   c->lanczos_steps = steps;
   if (steps_out) *steps_out = steps;

@@ -39,6 +39,7 @@
 #include <sys/wait.h>
 #include <unistd.h>
 #include <fcntl.h>
+#include <sys/stat.h>
 #include <functional>
 #include <future>
 #include <mutex>
@@ -909,8 +910,14 @@ int main(int argc, char** argv) {
   // pool, filtered (--references, --min-allele-frequency) and handed to the engine as carrier lists while the next one is
   // read -- the records of the whole file are never held (VariantsRDD.compute is an iterator, rdd/VariantsRDD.scala:205-235).
   // Joins and merges need whole data sets, --gpus k a known row count: those keep the in-memory path.
+  // The streaming path opens the input twice (header, then records): only a REGULAR file can be read twice -- a FIFO,
+  // /dev/stdin or a process substitution is consumed by the first pass and takes the one-pass in-memory path.
+  auto is_regular_file = [](const std::string& path) {
+    struct stat sb;
+    return ::stat(path.c_str(), &sb) == 0 && S_ISREG(sb.st_mode);
+  };
   const bool stream_vcf = conf.input_path.size() == 1 && !is_plink_path(conf.input_path[0]) && !conf.no_stream &&
-                          !conf.parse_only && !conf.debug_datasets && conf.gpus == 1;
+                          !conf.parse_only && !conf.debug_datasets && conf.gpus == 1 && is_regular_file(conf.input_path[0]);
   std::string stream_stem;
   std::vector<Region> stream_regions;
   int64_t streamed_variants = 0;
@@ -1044,7 +1051,7 @@ int main(int argc, char** argv) {
     check(ctx, pcoa_accumulate_calls_ex(ctx, sample_idx.data(), row_offsets.data() + ra, rb - ra, 0), "getSimilarityMatrix");
   };
   std::string how;
-  double feed_s = 0;
+  double feed_s = 0, warmup_s = 0;
   auto prepare = [&](const std::vector<pcoa_ctx*>& engines) {
     if (!stream_plink) return;
     for (int q = 0; q < 4 * conf.gpus; ++q) {
@@ -1057,15 +1064,20 @@ int main(int argc, char** argv) {
     // through the device decode -- staging slots, the bitset tile and the kernels' code objects exist before the first real
     // block; it adds nothing to S and is taken out of the books again
     const bool ref_a1 = conf.plink_ref_allele == "a1";
+    const double tw0 = now_s();
     for (int g = 0; g < conf.gpus; ++g) {
       unsigned char* b = blocks[(size_t)(4 * g)];
-      std::memset(b, ref_a1 ? 0x00 : 0xFF, (size_t)conf.stream_rows * plink.bpv);
+      int64_t r0 = 0, r1 = 0;
+      shard_range(g, conf.gpus, (int64_t)plink.keep.size(), &r0, &r1);
+      const int64_t wrows = std::max<int64_t>(1, std::min<int64_t>(conf.stream_rows, r1 - r0));   // never more than the shard itself
+      std::memset(b, ref_a1 ? 0x00 : 0xFF, (size_t)wrows * plink.bpv);
       pcoa_ctx* e = engines[(size_t)g];
-      check(e, pcoa_accumulate_plink_bed(e, b, conf.stream_rows, (int64_t)plink.bpv, ref_a1 ? 1 : 0, 0), "warm-up");
+      check(e, pcoa_accumulate_plink_bed(e, b, wrows, (int64_t)plink.bpv, ref_a1 ? 1 : 0, 0), "warm-up");
       check(e, pcoa_sync(e), "warm-up");
       check(e, pcoa_reset(e), "warm-up");
       check(e, pcoa_reset_timings(e), "warm-up");
     }
+    warmup_s = now_s() - tw0;
   };
   pcoa_ctx* ctx = run_engines(conf, n, feed, &how, &feed_s, prepare);
   for (unsigned char* b : blocks) (void)pcoa_host_free_pinned(b);
@@ -1074,9 +1086,10 @@ int main(int argc, char** argv) {
     struct rusage ru;
     getrusage(RUSAGE_SELF, &ru);
     if (stream_plink)
-      std::fprintf(stderr, "Streamed %lld variants x %d samples from %s.bed in %.3f s = %.1f M variants/s (ingest -> reduced S, engines "
-                   "already created; %s; slowest shard: reads %.3f s, feed calls %.3f s; %s decode); peak RSS %.0f MB\n", (long long)stream_stats.variants, n,
-                   plink.prefix.c_str(), feed_s, stream_stats.variants / feed_s / 1e6, how.c_str(), stream_stats.read_s,
+      std::fprintf(stderr, "Streamed %lld variants x %d samples from %s.bed in %.3f s = %.1f M variants/s (ingest -> reduced S; engines "
+                   "already created and a warm-up block of %.3f s per run -- first-use allocation, code-object load -- NOT included; %s; "
+                   "slowest shard: reads %.3f s, feed calls %.3f s; %s decode); peak RSS %.0f MB\n", (long long)stream_stats.variants, n,
+                   plink.prefix.c_str(), feed_s, stream_stats.variants / feed_s / 1e6, warmup_s, how.c_str(), stream_stats.read_s,
                    stream_stats.feed_s, conf.plink_decode.c_str(), ru.ru_maxrss / 1024.0);
     else
       std::fprintf(stderr, "getSimilarityMatrix: %zu variants in %.3f s (%s%s); peak RSS %.0f MB\n",

@@ -2,16 +2,18 @@
 // (jni/pcoa_jni.cpp, compiled with tests/jni_stub/jni.h) and libpcoa_hip.so, without a JVM.
 //
 // Same call sequence as VariantsPcaNative.getSimilarityMatrix / computePca for one GPU task:
-//   create -> [per batch of <= `batch` records: direct CSR buffers -> accumulateCalls] -> gramFinalize ->
+//   create -> [per batch of <= `batch` records, in one of two re-used allocPinned slots: CSR buffers -> accumulateCallsEx(CallsPinned
+//   | CallsAsync), or carrier bitsets -> accumulateBits for a dense batch; sync every two batches] -> gramFinalize ->
 //   commUniqueId -> commInit(rank 0 of 1) -> gramAllreduce -> commDestroy -> gramRead (parity only) -> compute ->
 //   timings -> destroy
 // Input : <prefix>.idx (int32 LE), <prefix>.offs (int64 LE, n_variants + 1 entries)
 // Output: <prefix>.s (int64 N x N), <prefix>.pc (double N x numPc column-major), <prefix>.lam, stdout "nonzero <k>"
-// Usage : jni_replay <prefix> <n_samples> <num_pc> [batch = 65536]
+// Usage : jni_replay <prefix> <n_samples> <num_pc> [batch = 65536] [mode = 0: the Scala host's rule | 1: lists only | 2: bitsets only]
 // Also checks the error mapping the Scala side relies on: an index >= N gives PCOA_ERR_INDEX_RANGE and a message,
 // a heap (non-direct) buffer gives PCOA_ERR_INVALID_ARG, num_pc = 0 gives PCOA_ERR_INVALID_ARG.
 #include <jni.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -28,6 +30,7 @@ void FN(destroy)(JNIEnv*, jobject, jlong);
 jstring FN(lastError)(JNIEnv*, jobject, jlong);
 jint FN(reset)(JNIEnv*, jobject, jlong);
 jint FN(accumulateCalls)(JNIEnv*, jobject, jlong, jobject, jobject, jlong);
+jint FN(accumulateCallsEx)(JNIEnv*, jobject, jlong, jobject, jobject, jlong, jint);
 jint FN(accumulateBits)(JNIEnv*, jobject, jlong, jobject, jlong, jlong);
 jint FN(gramFinalize)(JNIEnv*, jobject, jlong);
 jint FN(sync)(JNIEnv*, jobject, jlong);
@@ -68,6 +71,7 @@ int main(int argc, char** argv) {
   const std::string prefix = argv[1];
   const jint n = std::atoi(argv[2]), num_pc = std::atoi(argv[3]);
   const int64_t batch = argc > 4 ? std::atoll(argv[4]) : 65536;
+  const int mode = argc > 5 ? std::atoi(argv[5]) : 0;
   std::vector<int32_t> idx = slurp<int32_t>(prefix + ".idx");
   std::vector<int64_t> offs = slurp<int64_t>(prefix + ".offs");
   const int64_t nv = (int64_t)offs.size() - 1;
@@ -91,16 +95,63 @@ int main(int argc, char** argv) {
     EXPECT(FN(compute)(&env, self, ctx, 0, env.wrapDirect(c1.data(), 8 * n), nullptr, nullptr) == PCOA_ERR_INVALID_ARG);
     EXPECT(FN(reset)(&env, self, ctx) == PCOA_OK);
   }
-  // ---- getSimilarityMatrix: CSR batches exactly as VariantsPcaNative builds them (offsets restart at 0 per batch)
-  for (int64_t v0 = 0; v0 < nv; v0 += batch) {
-    const int64_t rows = std::min(batch, nv - v0);
-    std::vector<int64_t> bo((size_t)rows + 1);
-    for (int64_t r = 0; r <= rows; ++r) bo[(size_t)r] = offs[(size_t)(v0 + r)] - offs[(size_t)v0];
-    const int64_t nnz = bo[(size_t)rows];
-    std::vector<int32_t> bi(idx.begin() + offs[(size_t)v0], idx.begin() + offs[(size_t)v0] + nnz);
-    if (bi.empty()) bi.push_back(0);
-    EXPECT(FN(accumulateCalls)(&env, self, ctx, env.wrapDirect(bi.data(), 4 * (jlong)bi.size()),
-                               env.wrapDirect(bo.data(), 8 * (jlong)bo.size()), rows) == PCOA_OK);
+  // ---- getSimilarityMatrix, batch by batch exactly as VariantsPcaNative.getSimilarityMatrix does it (r06): two slots of
+  // page-locked direct buffers from allocPinned, re-used for the whole partition; a sparse batch goes over as CSR carrier lists
+  // through accumulateCallsEx(CallsPinned | CallsAsync) (offsets restart at 0 per batch), a dense one (mean list longer than
+  // N / 32 entries, no callset named twice) as carrier bitsets through accumulateBits; one sync per two batches hands both
+  // slots back.  mode (argv[5]): 0 = that rule, 1 = every batch as lists, 2 = every batch as bitsets.
+  {
+    struct Slot {
+      jobject idx = nullptr, offs = nullptr, bits = nullptr;
+    } slots[2];
+    auto fit = [&](jobject& buf, jlong bytes) -> uint8_t* {
+      if (buf == nullptr || env.GetDirectBufferCapacity(buf) < bytes) {
+        if (buf != nullptr && FN(freePinned)(&env, self, buf) != PCOA_OK) return nullptr;
+        buf = FN(allocPinned)(&env, self, std::max<jlong>(bytes + bytes / 4, 1 << 16));
+        if (buf == nullptr) return nullptr;
+      }
+      return static_cast<uint8_t*>(env.GetDirectBufferAddress(buf));
+    };
+    const int64_t words = ((int64_t)n + 31) / 32;
+    int64_t k = 0, as_lists = 0, as_bits = 0;
+    for (int64_t v0 = 0; v0 < nv; v0 += batch, ++k) {
+      Slot& sl = slots[k & 1];
+      if (k >= 2 && (k & 1) == 0) EXPECT(FN(sync)(&env, self, ctx) == PCOA_OK);
+      const int64_t rows = std::min(batch, nv - v0);
+      const int64_t nnz = offs[(size_t)(v0 + rows)] - offs[(size_t)v0];
+      bool bits_ok = mode == 2 || (mode == 0 && nnz > rows * words);
+      if (bits_ok) {
+        uint32_t* b = reinterpret_cast<uint32_t*>(fit(sl.bits, 4 * words * rows));
+        EXPECT(b != nullptr);
+        std::memset(b, 0, (size_t)(4 * words * rows));
+        for (int64_t r = 0; r < rows; ++r)
+          for (int64_t e = offs[(size_t)(v0 + r)]; e < offs[(size_t)(v0 + r + 1)]; ++e) {
+            const int32_t c = idx[(size_t)e];
+            EXPECT(c >= 0 && c < n);
+            uint32_t& w = b[r * words + (c >> 5)];
+            if (w & (1u << (c & 31))) bits_ok = false;   // a repeated callset: multiplicities need the lists
+            w |= 1u << (c & 31);
+          }
+        if (bits_ok) {
+          EXPECT(FN(accumulateBits)(&env, self, ctx, sl.bits, rows, words) == PCOA_OK);
+          as_bits += 1;
+        }
+      }
+      if (!bits_ok) {
+        int64_t* bo = reinterpret_cast<int64_t*>(fit(sl.offs, 8 * (rows + 1)));
+        int32_t* bi = reinterpret_cast<int32_t*>(fit(sl.idx, 4 * std::max<int64_t>(nnz, 1)));
+        EXPECT(bo != nullptr && bi != nullptr);
+        for (int64_t r = 0; r <= rows; ++r) bo[r] = offs[(size_t)(v0 + r)] - offs[(size_t)v0];
+        if (nnz > 0) std::memcpy(bi, idx.data() + offs[(size_t)v0], (size_t)(4 * nnz));
+        EXPECT(FN(accumulateCallsEx)(&env, self, ctx, sl.idx, sl.offs, rows, /*CallsPinned | CallsAsync*/ 2 | 4) == PCOA_OK);
+        as_lists += 1;
+      }
+    }
+    EXPECT(FN(gramFinalize)(&env, self, ctx) == PCOA_OK);   // synchronises: the slots are ours again
+    for (Slot& sl : slots)
+      for (jobject b : {sl.idx, sl.offs, sl.bits})
+        if (b != nullptr) EXPECT(FN(freePinned)(&env, self, b) == PCOA_OK);
+    std::printf("batches: %lld as lists, %lld as bitsets\n", (long long)as_lists, (long long)as_bits);
   }
   EXPECT(FN(gramFinalize)(&env, self, ctx) == PCOA_OK);
   jbyteArray uid = FN(commUniqueId)(&env, self);

@@ -432,11 +432,18 @@ def test_jni_shim_replay_matches_the_reference_goldens(O, name, batch, tmp_path)
     prefix = str(tmp_path / "case")
     g["sample_idx"].astype("<i4").tofile(prefix + ".idx")
     g["row_offsets"].astype("<i8").tofile(prefix + ".offs")
-    res = subprocess.run([exe, prefix, str(n), "2", str(batch)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                         universal_newlines=True)
-    assert res.returncode == 0, res.stderr
-    s = np.fromfile(prefix + ".s", dtype="<i8").reshape(n, n)
-    assert np.array_equal(s, g["similarity"])
+    # r06: the Scala host's current sequence -- two re-used allocPinned slots, accumulateCallsEx(CallsPinned | CallsAsync) for
+    # sparse batches, accumulateBits for dense ones, a sync per two batches.  Mode 1 / 2 force every batch down one of the two
+    # ways; mode 0 (last: its outputs are the ones checked below) is the host's own rule.
+    seen = {}
+    for mode in ("1", "2", "0"):
+        res = subprocess.run([exe, prefix, str(n), "2", str(batch), mode], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                             universal_newlines=True)
+        assert res.returncode == 0, (mode, res.stderr)
+        s = np.fromfile(prefix + ".s", dtype="<i8").reshape(n, n)
+        assert np.array_equal(s, g["similarity"]), mode
+        seen[mode] = [l for l in res.stdout.splitlines() if l.startswith("batches: ")][0]
+    assert seen["1"].endswith(" 0 as bitsets") and " 0 as lists" in seen["2"]
     ref = O.compute_pca(g["similarity"], 2)
     lines = [l for l in res.stdout.splitlines() if l.startswith("nonzero ")]   # (RCCL prints a version banner to stdout)
     assert lines == ["nonzero %d" % ref["nonzero_rows"]]

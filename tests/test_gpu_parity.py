@@ -1080,3 +1080,119 @@ def test_bench_emits_one_json_line_with_the_contract_fields(P):
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert d["parity_vs_cpu_sample"] is True
     assert d["dtype"].startswith("fp4") and d["pcoa_wall_ms"] > 0
+
+
+# ---- r06: band Lanczos, the fallback for clustered leading eigenvalues (VERDICT r05 Missing 5 / Next 4) -----------------------
+def _block_constant_similarity(n, pops, within, across, bump):
+    """S[i, j] = within (+ bump inside population 0) if i and j belong to the same population, else across: the centred matrix
+    has the between-population contrasts as its only non-zero eigen-directions, (len(pops) - 1) of them in one cluster that
+    `bump` splits by a relative ~ bump / (within - across)."""
+    offs = np.concatenate([[0], np.cumsum(pops)])
+    s = np.full((n, n), across, dtype=np.int64)
+    for p in range(len(pops)):
+        s[offs[p]:offs[p + 1], offs[p]:offs[p + 1]] = within + (bump if p == 0 else 0)
+    return s, offs
+
+
+def _reduced_eigenvalues(pops, within, across, bump):
+    """Eigenvalues of B = J S J for a block-constant S from the len(pops)-dimensional problem on the normalised population
+    indicators (exact structure, long double arithmetic)."""
+    sz = np.asarray(pops, dtype=np.longdouble)
+    nn = sz.sum()
+    k = len(pops)
+    sr = np.empty((k, k), dtype=np.longdouble)
+    for p in range(k):
+        for q in range(k):
+            val = (within + (bump if p == 0 else 0)) if p == q else across
+            sr[p, q] = np.longdouble(val) * np.sqrt(sz[p] * sz[q])
+    root = np.sqrt(sz)
+    jr = np.eye(k, dtype=np.longdouble) - np.outer(root, root) / nn
+    br = (jr @ sr @ jr).astype(np.float64)
+    return np.sort(np.linalg.eigvalsh(br))[::-1]
+
+
+def test_clustered_leading_eigenvalues_at_n_20000_return_residual_verified_pairs(P):
+    """N = 20,000 > 16,384, where the dense fallback is disabled: S loaded through pcoa_gram_load_i64 whose centred matrix has
+    THREE leading eigenvalues within a relative 1e-9 of each other.  A single-vector Krylov space holds one direction of that
+    cluster; r05 answered PCOA_ERR_NOT_CONVERGED where the reference's dgesdd returns an answer (VariantsPca.scala:224-227).
+    The band iteration (block width num_pc + 2) returns pairs whose true residual passed on the device; here they are checked
+    again on the host: residual, eigenvalues against the exact 4 x 4 reduced problem, orthonormality."""
+    n = 20000
+    pops = [5000, 5000, 5000, 5000]
+    within, across, bump = 2000000000, 1000000000, 3
+    s, offs = _block_constant_similarity(n, pops, within, across, bump)
+    lam_ref = _reduced_eigenvalues(pops, within, across, bump)
+    assert abs(lam_ref[0] - lam_ref[2]) < 1e-8 * lam_ref[0] and lam_ref[0] > lam_ref[1]   # the cluster
+    with P.PcoaEngine(n) as eng:
+        eng.load_gram(s)
+        comps, lam, nz = eng.compute(2)
+        t = eng.timings()
+    assert t["eig_method"] == 1 and t["lanczos_block_steps"] > 0, t
+    assert t["gram_i64_live"] == 0 and t["matvec_form"] == 1          # the loaded counts fit int32: upper-triangle mat-vec
+    assert nz == n
+    assert np.max(np.abs(lam - lam_ref[:2]) / lam_ref[:2]) < 1e-11
+    sf = s.astype(np.float64)
+    del s
+    rs = sf.sum(axis=1)
+    mean = rs / n
+    mm = rs.sum() / n / n
+    for c in range(2):
+        u = comps[:, c]
+        bu = sf @ u - mean * u.sum() - (mean @ u) + mm * u.sum()      # B u = (S - m 1^T - 1 m^T + mm 1 1^T) u
+        assert np.linalg.norm(bu - lam[c] * u) <= 1e-9 * abs(lam[c])
+        assert abs(np.linalg.norm(u) - 1.0) < 1e-12
+    assert abs(comps[:, 0] @ comps[:, 1]) < 1e-9
+
+
+def test_band_iteration_alone_matches_the_oracle_on_ordinary_spectra(tmp_path):
+    """PCOA_LANCZOS_BAND=2: only the band iteration runs (planted populations, unstructured genotypes with gaps of a fraction of
+    a percent, a rank-7 matrix).  Eigenvalues and -- where the gaps allow -- eigenvectors against the oracle."""
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import importlib
+from conftest import load_oracle, planted_callsets, align_sign
+P = importlib.import_module("spark-examples_amd"); O = load_oracle()
+rng = np.random.default_rng(19)
+out = {}
+for tag, n, x in (("planted", 700, planted_callsets(rng, 700, 3000, k=4)),
+                  ("flat", 200, (rng.random((5000, 200)) < 0.3).astype(np.float32)),
+                  ("rank7", 100, (rng.random((7, 100)) < 0.4).astype(np.float32))):
+    s = O.similarity_from_dense(x, n)
+    b = O.center_matrix(s)[0]
+    ref = O.compute_pca(s, 2)
+    with P.PcoaEngine(n, eig="lanczos") as eng:
+        eng.accumulate_dense(x)
+        comps, lam, _ = eng.compute(2)
+        t = eng.timings()
+    res = max(np.linalg.norm(b @ comps[:, c] - lam[c] * comps[:, c]) / abs(lam[c]) for c in range(2))
+    got = align_sign(comps, ref["components"])
+    out[tag] = [t["lanczos_block_steps"], float(np.max(np.abs(lam - ref["eigenvalues"]) / np.abs(ref["eigenvalues"]))), float(res),
+                float(max(np.linalg.norm(got[:, c] - ref["components"][:, c]) for c in range(2)))]
+np.savez(sys.argv[1], **out)
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    out = str(tmp_path / "band.npz")
+    subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, PCOA_LANCZOS_BAND="2"))
+    r = np.load(out)
+    for tag in ("planted", "flat", "rank7"):
+        steps, dlam, res, dvec = r[tag]
+        assert steps > 0 and dlam < 1e-9 and res < 1e-8, (tag, r[tag])
+    assert r["planted"][3] < 1e-6      # clear gaps: the vectors themselves at the north_star tolerance
+
+
+def test_caller_supplied_operator_with_a_degenerate_leading_pair(P):
+    """pcoa_lanczos_with_matvec (the strip-owner path: no dense fallback at all): a diagonal operator whose two leading
+    eigenvalues differ by a relative 1e-9 and a third copy 1e-7 below -- r05 returned PCOA_ERR_NOT_CONVERGED."""
+    import torch
+    n = 4096
+    d = torch.linspace(0.0, 0.9, n, dtype=torch.float64, device="cuda:0")
+    d[17], d[1900], d[4000] = 1.0, 1.0 - 1e-9, 1.0 - 1e-7
+    with P.PcoaEngine(n) as eng:
+        comps, lam = eng.lanczos(lambda v: d * v, 2)
+        t = eng.timings()
+    assert t["lanczos_block_steps"] > 0
+    assert abs(lam[0] - 1.0) < 1e-12 and abs(lam[1] - (1.0 - 1e-9)) < 1e-12
+    dd = d.cpu().numpy()
+    for c in range(2):
+        assert np.linalg.norm(dd * comps[:, c] - lam[c] * comps[:, c]) < 1e-10
+    assert abs(comps[:, 0] @ comps[:, 1]) < 1e-9
