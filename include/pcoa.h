@@ -64,6 +64,14 @@ typedef enum pcoa_status {
 #define PCOA_FLAG_NO_SIGN_NORM   0x10u /* keep the eigensolver's native sign instead of sign-normalising */
 #define PCOA_FLAG_EIG_HOUSEHOLDER 0x20u /* always use the dense Householder + bisection eigensolver        */
 #define PCOA_FLAG_EIG_LANCZOS    0x40u /* Lanczos only: PCOA_ERR_NOT_CONVERGED instead of falling back      */
+#define PCOA_FLAG_EIG_BAND       0x200u /* Lanczos as the BAND iteration from the start (block width num_pc + 2) instead of the
+                                           single-vector one.  The default runs the single vector first (0.5 ms at N = 2504) and
+                                           the band iteration only when that does not verify: clusters of eigenvalues down to a
+                                           relative ~1e-12 are resolved either way, but an eigenvalue of EXACT multiplicity m > 1
+                                           (a cohort with an exact symmetry: duplicated samples, mirrored populations) shows a
+                                           single start vector one direction of its eigenspace only -- the pair that comes back
+                                           is verified, yet a twin of the same eigenvalue can be missing from the top num_pc.
+                                           This flag finds multiplicities up to num_pc + 2 (~3 ms instead of 0.5 at N = 2504). */
 #define PCOA_FLAG_NO_PIPELINE    0x80u /* device tiles: pre-pass and contraction strictly one after the other on the ctx
                                            stream (the default runs the pre-pass of one fp32 / uint8 operand buffer beside
                                            the contraction of the previous one, on two side streams, for N = 1,025 .. 16,384;

@@ -30,6 +30,7 @@ PCOA_FLAG_EIG_HOUSEHOLDER = 0x20
 PCOA_FLAG_EIG_LANCZOS = 0x40
 PCOA_FLAG_NO_PIPELINE = 0x80
 PCOA_FLAG_OPERAND_FP4 = 0x100
+PCOA_FLAG_EIG_BAND = 0x200
 MATVEC_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
 PCOA_BED_HOST_ASYNC = 2
 PCOA_CALLS_DEVICE_PTR = 1

@@ -557,16 +557,17 @@ __global__ __launch_bounds__(THREADS) void densify_csr_kbits_lds_kernel(const in
   const int64_t e0 = nrows > 0 ? offs[r0] : 0;
   if (tid <= 128) {
     const int64_t d = nrows > 0 ? offs[r0 + (tid < nrows ? tid : nrows)] - e0 : 0;
-    // (a block of sane lists has <= 128 * N entries; offsets that are not, e.g. garbage behind a device pointer, are
-    // reported as an index error instead of being followed)
-    rel[tid] = (d < 0 || d > (int64_t)0x7fffffff) ? -1 : (int32_t)d;
+    // (a block of sane lists has <= 128 * N entries -- a list names a callset at most a few times, and the loop below advances
+    // an int by THREADS * 4 per trip: the cap keeps `q` far from overflow; offsets beyond it, e.g. garbage behind a device
+    // pointer, are reported as an offsets error (flag[2] = -2) instead of being followed)
+    rel[tid] = (d < 0 || d > (int64_t)0x3fffffff) ? -1 : (int32_t)d;
   }
   __syncthreads();
   int total = rel[128];
   bool bad = total < 0;
   if (tid <= 127 && !bad) bad = rel[tid] < 0 || rel[tid] > rel[tid + 1];
   if (__syncthreads_or(bad)) {
-    if (tid == 0) { atomicOr(flag, 1); flag[2] = -1; }
+    if (tid == 0) { atomicOr(flag, 1); flag[2] = -2; }   // -2: the row offsets themselves are bad (csr_validate names them)
     total = 0;
   }
   const int32_t* src = idx + (e0 - offs_base);
@@ -1151,13 +1152,27 @@ hipError_t launch_densify_csr_kbits(const int32_t* idx_dev, const int64_t* offs_
     return v && std::atoi(v) != 0;
   }();
   const size_t lds = (size_t)npad * 16 + 132 * sizeof(int32_t);
-  if (!force_global && lds <= 128 * 1024 && nblk_out > 0 && nblk_out <= 0x7fffffffLL) {
-    constexpr int T = 512;
-    if (lds > 64 * 1024) {  // opt in to more than 64 KiB of dynamic LDS (per device: cheap enough to repeat)
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(densify_csr_kbits_lds_kernel<T>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-      if (e != hipSuccess) return e;
+  // what the device lets ONE workgroup have (sharedMemPerBlockOptin; 160 KiB on gfx950): asked once per device
+  static thread_local int lds_dev = -1;
+  static thread_local size_t lds_optin = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess && dev != lds_dev) {
+    int v = 0;
+    lds_optin = (hipDeviceGetAttribute(&v, hipDeviceAttributeSharedMemPerBlockOptin, dev) == hipSuccess && v > 0) ? (size_t)v : (size_t)64 * 1024;
+    lds_dev = dev;
+    (void)hipGetLastError();
+  }
+  bool use_lds = !force_global && lds <= 128 * 1024 && lds <= lds_optin && nblk_out > 0 && nblk_out <= 0x7fffffffLL;
+  constexpr int T = 512;
+  if (use_lds && lds > 64 * 1024) {  // opt in to more than 64 KiB of dynamic LDS (per device: cheap enough to repeat)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(densify_csr_kbits_lds_kernel<T>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (e != hipSuccess) {   // the global-atomic form below still works
+      (void)hipGetLastError();
+      use_lds = false;
     }
+  }
+  if (use_lds) {
     hipLaunchKernelGGL(densify_csr_kbits_lds_kernel<T>, dim3((unsigned)nblk_out), dim3(T), lds, stream, idx_dev, offs_dev, nv,
                        offs_base, reinterpret_cast<uint32_t*>(p), npad, n, flag);
     return hipGetLastError();

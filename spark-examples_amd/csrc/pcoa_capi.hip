@@ -1754,9 +1754,19 @@ int pcoa_accumulate_plink_bed(pcoa_ctx* c, const uint8_t* bed_rows, int64_t n_va
     return fail(c, PCOA_ERR_INVALID_ARG, "the PLINK boundary needs a packed-operand engine (not PCOA_FLAG_GRAM_F32_MFMA)");
   if (is_device_ptr != 0 && is_device_ptr != 1 && is_device_ptr != PCOA_BED_HOST_ASYNC)
     return fail(c, PCOA_ERR_INVALID_ARG, "is_device_ptr must be 0, 1 or PCOA_BED_HOST_ASYNC");
-  const bool host_async = is_device_ptr == PCOA_BED_HOST_ASYNC;
+  bool host_async = is_device_ptr == PCOA_BED_HOST_ASYNC;
   if (host_async) is_device_ptr = 0;
   if (n_variants == 0) return PCOA_OK;
+  if (host_async) {
+    // the queued form is only safe for page-locked rows: pageable memory goes through the runtime's staging copy, whose
+    // timing the "second later call" rule does not cover -- such rows are consumed before the call returns
+    hipPointerAttribute_t attr;
+    const hipError_t pe = hipPointerGetAttributes(&attr, bed_rows);
+    if (pe != hipSuccess || attr.type != hipMemoryTypeHost) {
+      (void)hipGetLastError();
+      host_async = false;
+    }
+  }
   const int64_t words = ((int64_t)c->n + 31) / 32;
   const int64_t rows_cap = std::min<int64_t>(n_variants, (int64_t)1 << 17);
   int rc = ensure(c, &c->tile, &c->tile_elems, rows_cap * words);
@@ -2019,9 +2029,14 @@ int csr_validate(pcoa_ctx* c) {
   HIP_TRY(c, hipStreamSynchronize(s));
   if (flag & 1) {
     char msg[256];
-    std::snprintf(msg, sizeof(msg), "callset index %d outside [0, %d) in a carrier list (found by the device-side check); S is "
-                  "unchanged by the calls since the last synchronising call that reported no error", bad_index, c->n);
-    return fail(c, PCOA_ERR_INDEX_RANGE, msg);
+    if (bad_index == -2)
+      std::snprintf(msg, sizeof(msg), "row_offsets of a carrier-list call are not non-decreasing or run beyond 2^30 entries per 128 "
+                    "variants (found by the device-side check); S is unchanged by the calls since the last synchronising call that "
+                    "reported no error");
+    else
+      std::snprintf(msg, sizeof(msg), "callset index %d outside [0, %d) in a carrier list (found by the device-side check); S is "
+                    "unchanged by the calls since the last synchronising call that reported no error", bad_index, c->n);
+    return fail(c, bad_index == -2 ? PCOA_ERR_INVALID_ARG : PCOA_ERR_INDEX_RANGE, msg);
   }
   if (c->packed_mode == 3)
     return fail(c, PCOA_ERR_INVALID_ARG,
@@ -2634,6 +2649,7 @@ int pcoa_compute(pcoa_ctx* c, int32_t num_pc, double* out_components, double* ou
       if (!b_ready) wl.a = nullptr;  // implicit form
       wl.sym_part = (sym_form && !wl.a) ? c->sym_part : nullptr;
       c->matvec_form = wl.a ? 2 : wl.sym_part ? 1 : 0;
+      wl.band_only = (c->flags & PCOA_FLAG_EIG_BAND) != 0;
       int band = 0;
       HIP_TRY(c, lanczos_topk(wl, c->lanczos_ws, n, num_pc, mmax, 1e-11, sel.data(), &conv, &steps, c->stream, nullptr, &band));
       c->lanczos_block_steps = band;
@@ -2743,6 +2759,7 @@ int pcoa_lanczos_with_matvec(pcoa_ctx* c, int32_t num_pc, pcoa_matvec_fn fn, voi
     wl.a = nullptr;
     wl.s32 = nullptr;
     wl.s64 = nullptr;
+    wl.band_only = (c->flags & PCOA_FLAG_EIG_BAND) != 0;
     int band = 0;
     HIP_TRY(c, lanczos_topk(wl, c->lanczos_ws, n, num_pc, mmax, 1e-11, sel.data(), &conv, &steps, c->stream, &mv, &band));
     c->lanczos_block_steps = band;

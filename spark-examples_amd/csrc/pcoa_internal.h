@@ -204,6 +204,7 @@ struct EigWorkspace {
   // large N: workspace of the symmetric mat-vec that reads only the upper triangle of S (symv_sym_workspace_doubles(n)
   // doubles: 1024 row sums + 1024 column sums per upper-triangular 1024 x 1024 tile), or nullptr: one wave per row
   double* sym_part = nullptr;
+  bool band_only = false;   // PCOA_FLAG_EIG_BAND: skip the single-vector iteration (eigenvalues of multiplicity > 1)
 };
 size_t symv_sym_workspace_doubles(int32_t n);
 // exact row sums of a finalized (symmetric) int32 S from its upper-triangular tiles: half the bytes of launch_center's row

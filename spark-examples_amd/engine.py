@@ -30,7 +30,8 @@ class PcoaEngine(object):
                  pipeline=True, operand=None):
         """gram_kernel: None/"auto" (MX-FP4 MFMA for binary tiles, int8 MFMA for multiplicities; both exact),
         "fp4", "i8" (force one of them) or "f32" (fp32-MFMA path).
-        eig: None/"auto" (Lanczos with verified residual, Householder fallback), "householder", "lanczos".
+        eig: None/"auto" (Lanczos with verified residual -- single vector, then the band iteration --, Householder fallback),
+        "householder", "lanczos" (no dense fallback), "band" (Lanczos as the band iteration from the start, PCOA_FLAG_EIG_BAND).
         strip: None, or (col0, cols): a strip owner holding S[:, col0:col0+cols] (pcoa_create_strip; see strips.py).
         pipeline=False: PCOA_FLAG_NO_PIPELINE (fp32 pre-pass and contraction strictly serial; measurements).
         operand: None/"bits" (binary tiles are re-laid out to 1 bit per genotype and expanded to MX-FP4 inside the
@@ -45,8 +46,10 @@ class PcoaEngine(object):
             flags |= L.PCOA_FLAG_EIG_HOUSEHOLDER
         elif eig == "lanczos":
             flags |= L.PCOA_FLAG_EIG_LANCZOS
+        elif eig == "band":   # Lanczos only, as the band iteration from the start (eigenvalues of exact multiplicity > 1)
+            flags |= L.PCOA_FLAG_EIG_LANCZOS | L.PCOA_FLAG_EIG_BAND
         elif eig not in (None, "auto"):
-            raise ValueError("eig must be 'auto', 'householder' or 'lanczos'")
+            raise ValueError("eig must be 'auto', 'householder', 'lanczos' or 'band'")
         if gram_kernel == "f32":
             flags |= L.PCOA_FLAG_GRAM_F32_MFMA
         elif gram_kernel == "i8":

@@ -1111,37 +1111,94 @@ def _reduced_eigenvalues(pops, within, across, bump):
     return np.sort(np.linalg.eigvalsh(br))[::-1]
 
 
+def _centred_matvec_host(sf, u):
+    """B u = (S - m 1^T - 1 m^T + mm 1 1^T) u for a float64 S, without forming B."""
+    n = sf.shape[0]
+    rs = sf.sum(axis=1)
+    mean = rs / n
+    mm = rs.sum() / n / n
+    return sf @ u - mean * u.sum() - (mean @ u) + mm * u.sum()
+
+
 def test_clustered_leading_eigenvalues_at_n_20000_return_residual_verified_pairs(P):
     """N = 20,000 > 16,384, where the dense fallback is disabled: S loaded through pcoa_gram_load_i64 whose centred matrix has
-    THREE leading eigenvalues within a relative 1e-9 of each other.  A single-vector Krylov space holds one direction of that
-    cluster; r05 answered PCOA_ERR_NOT_CONVERGED where the reference's dgesdd returns an answer (VariantsPca.scala:224-227).
-    The band iteration (block width num_pc + 2) returns pairs whose true residual passed on the device; here they are checked
-    again on the host: residual, eigenvalues against the exact 4 x 4 reduced problem, orthonormality."""
+    THREE leading eigenvalues within a relative 2e-9 of each other on top of a full-rank bulk (a random symmetric +-2
+    perturbation of a block-constant matrix; bulk eigenvalues of a few hundred against 5e12).  r05 answered
+    PCOA_ERR_NOT_CONVERGED in such a case where the reference's dgesdd returns an answer (VariantsPca.scala:224-227).  The
+    pairs that come back passed their true residual on the device; here they are checked again on the host: residual,
+    eigenvalues against the exact 4 x 4 reduced problem (the perturbation moves them by O(1)), orthonormality.  Both the
+    default path (single vector first) and the band iteration alone."""
     n = 20000
     pops = [5000, 5000, 5000, 5000]
     within, across, bump = 2000000000, 1000000000, 3
     s, offs = _block_constant_similarity(n, pops, within, across, bump)
+    rng = np.random.default_rng(8)
+    for r0 in range(0, n, 2000):                       # s += E + E^T, E in {-1, 0, 1}: full rank, symmetric, int32-sized
+        e = rng.integers(-1, 2, size=(2000, n), dtype=np.int8)
+        s[r0:r0 + 2000, :] += e
+        s[:, r0:r0 + 2000] += e.T
     lam_ref = _reduced_eigenvalues(pops, within, across, bump)
     assert abs(lam_ref[0] - lam_ref[2]) < 1e-8 * lam_ref[0] and lam_ref[0] > lam_ref[1]   # the cluster
-    with P.PcoaEngine(n) as eng:
-        eng.load_gram(s)
-        comps, lam, nz = eng.compute(2)
-        t = eng.timings()
-    assert t["eig_method"] == 1 and t["lanczos_block_steps"] > 0, t
-    assert t["gram_i64_live"] == 0 and t["matvec_form"] == 1          # the loaded counts fit int32: upper-triangle mat-vec
-    assert nz == n
-    assert np.max(np.abs(lam - lam_ref[:2]) / lam_ref[:2]) < 1e-11
     sf = s.astype(np.float64)
-    del s
-    rs = sf.sum(axis=1)
-    mean = rs / n
-    mm = rs.sum() / n / n
+    for eig in (None, "band"):
+        with P.PcoaEngine(n, eig=eig) as eng:
+            eng.load_gram(s)
+            comps, lam, nz = eng.compute(2)
+            t = eng.timings()
+        assert t["eig_method"] == 1, t
+        if eig == "band":
+            assert t["lanczos_block_steps"] > 0
+        assert t["gram_i64_live"] == 0 and t["matvec_form"] == 1      # the loaded counts fit int32: upper-triangle mat-vec
+        assert nz == n
+        assert np.max(np.abs(lam - lam_ref[:2]) / lam_ref[:2]) < 1e-11
+        for c in range(2):
+            u = comps[:, c]
+            assert np.linalg.norm(_centred_matvec_host(sf, u) - lam[c] * u) <= 1e-9 * abs(lam[c])
+            assert abs(np.linalg.norm(u) - 1.0) < 1e-12
+        assert abs(comps[:, 0] @ comps[:, 1]) < 1e-9
+
+
+def test_exactly_degenerate_leading_eigenvalue_needs_and_gets_the_band_iteration(P):
+    """Three populations of equal size and equal structure: the leading eigenvalue of B has multiplicity 2 EXACTLY.  A single
+    start vector sees one direction of that eigenspace (the documented limit of the default path, pcoa.h PCOA_FLAG_EIG_BAND);
+    the band iteration (eig='band') returns two orthonormal vectors of the eigenspace, both with the leading eigenvalue."""
+    n = 1536
+    pops = [512, 512, 512]
+    s, _ = _block_constant_similarity(n, pops, 900, 100, 0)
+    lam_ref = _reduced_eigenvalues(pops, 900, 100, 0)
+    assert abs(lam_ref[0] - lam_ref[1]) < 1e-9 * lam_ref[0] and lam_ref[2] < 1e-6 * lam_ref[0]
+    sf = s.astype(np.float64)
+    with P.PcoaEngine(n, eig="band") as eng:
+        eng.load_gram(s)
+        comps, lam, _ = eng.compute(2)
+        t = eng.timings()
+    assert t["eig_method"] == 1 and t["lanczos_block_steps"] > 0
+    assert np.max(np.abs(lam - lam_ref[:2]) / lam_ref[:2]) < 1e-12
     for c in range(2):
-        u = comps[:, c]
-        bu = sf @ u - mean * u.sum() - (mean @ u) + mm * u.sum()      # B u = (S - m 1^T - 1 m^T + mm 1 1^T) u
-        assert np.linalg.norm(bu - lam[c] * u) <= 1e-9 * abs(lam[c])
-        assert abs(np.linalg.norm(u) - 1.0) < 1e-12
-    assert abs(comps[:, 0] @ comps[:, 1]) < 1e-9
+        assert np.linalg.norm(_centred_matvec_host(sf, comps[:, c]) - lam[c] * comps[:, c]) <= 1e-10 * abs(lam[c])
+    assert abs(comps[:, 0] @ comps[:, 1]) < 1e-10
+
+
+def test_device_side_check_of_row_offsets_names_them(P):
+    """Carrier lists as device arrays are validated on the device: row offsets that decrease are reported as what they are
+    (PCOA_ERR_INVALID_ARG, r06: r05 reported 'callset index -1'), S unchanged."""
+    import torch
+    n = 300
+    rng = np.random.default_rng(2)
+    x = planted_callsets(rng, n, 400)
+    idx, offs = _csr_of(x)
+    with P.PcoaEngine(n) as eng:
+        eng.accumulate_calls(idx, offs)
+        before = eng.gram()
+        bad = offs.copy()
+        bad[200] = bad[199] - 3
+        ti = torch.from_numpy(idx).cuda()
+        to = torch.from_numpy(bad).cuda()
+        with pytest.raises(P.PcoaError) as err:
+            eng.accumulate_calls_tensors(ti, to)
+            eng.sync()
+        assert err.value.code == -1 and "row_offsets" in str(err.value)
+        assert np.array_equal(eng.gram(), before)
 
 
 def test_band_iteration_alone_matches_the_oracle_on_ordinary_spectra(tmp_path):
