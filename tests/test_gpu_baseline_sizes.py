@@ -292,11 +292,16 @@ def test_vcf_through_both_hosts_gives_the_reference_similarity_matrix(P, name, t
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "spark-examples_amd", "host")])
     dump_c = str(tmp_path / "s_cpp.bin")
-    res = subprocess.run([exe, "--input-path", path, "--dump-similarity", dump_c], stdout=subprocess.PIPE,
-                         stderr=subprocess.PIPE, universal_newlines=True)
-    assert res.returncode == 0, res.stderr
-    s_cpp = np.fromfile(dump_c, dtype="<i8").reshape(n, n)
-    assert np.array_equal(s_cpp, g["similarity"])
+    # r06: rows cross as carrier bitsets when a block is dense (mean list longer than N / 32) and as carrier lists when it is
+    # sparse (--carrier-format auto); both forms forced as well, streamed and in memory
+    for extra, want in (([], None), (["--carrier-format", "lists"], "0 rows as carrier bitsets"),
+                        (["--carrier-format", "bits"], " 0 as carrier lists"), (["--carrier-format", "bits", "--no-stream"], " 0 as carrier lists")):
+        res = subprocess.run([exe, "--input-path", path, "--dump-similarity", dump_c] + extra, stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, universal_newlines=True)
+        assert res.returncode == 0, res.stderr
+        s_cpp = np.fromfile(dump_c, dtype="<i8").reshape(n, n)
+        assert np.array_equal(s_cpp, g["similarity"]), extra
+        assert want is None or want in res.stderr, (extra, res.stderr)
     vp = load_pkg("variants_pca")
     dump_p = str(tmp_path / "s_py.bin")
     assert vp.main(["--input-path", path, "--dump-similarity", dump_p]) == 0
