@@ -1188,6 +1188,7 @@ hipError_t launch_densify_csr_kbits(const int32_t* idx_dev, const int64_t* offs_
 // fails with hipErrorInvalidValue where the shape does not fit `num_cu`), 4 = even split over `num_cu` workgroups.
 hipError_t launch_gram_kbits(const int8_t* p, int64_t nv, int32_t n, int32_t* s32, int num_cu, hipStream_t stream, int mode,
                              const int32_t* skip, GramStrip strip) {
+  if (mode == 5) mode = 4;   // (the XCD k-segment split exists in the one-wave-per-SIMD kernel only)
   if (nv <= 0) return hipSuccess;
   const int cus = num_cu > 0 ? num_cu : 256;
   const int npad = (int)gram_packed_npad(n);

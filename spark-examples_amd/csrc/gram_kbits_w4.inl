@@ -447,10 +447,22 @@ __global__ __launch_bounds__(256, 1) void gram_kbits_w4_kernel(const int8_t* __r
 #endif
 
   int64_t u, u_end;
-  if (xcd_map == 4) {
+  // xcd_map 5 (r06): every XCD takes its own EIGHTH of the k-range -- segment [seg_off, seg_off + seg_len) -- for ALL tiles and
+  // splits that by cost over its 32 workgroups: the workgroups of one L2 then stream the same 1 / 8 of the operand (tile after
+  // tile, at most 1 / 8 of the k-range apart) instead of 32 unrelated (tile, k) positions of the whole operand
+  int64_t seg_len = nstages, seg_off = 0;
+  if (xcd_map == 4 || xcd_map == 5) {
+    int64_t nwg = gridDim.x;
+    int64_t slot = (nwg % kNumXcd == 0) ? (int64_t)(b & 7) * (nwg / kNumXcd) + (b >> 3) : (int64_t)b;
+    if (xcd_map == 5) {   // (the launcher makes gridDim.x a multiple of 8 and nstages >= 8)
+      const int xcd = b & 7;
+      seg_off = nstages * xcd / kNumXcd;
+      seg_len = nstages * (xcd + 1) / kNumXcd - seg_off;
+      nwg = gridDim.x / kNumXcd;
+      slot = b >> 3;
+    }
+    const int64_t nstages = seg_len;   // the split below works on the segment (shadows the kernel argument on purpose)
     const int64_t nwork = (int64_t)ntri * nstages;
-    const int64_t nwg = gridDim.x;
-    const int64_t slot = (nwg % kNumXcd == 0) ? (int64_t)(b & 7) * (nwg / kNumXcd) + (b >> 3) : (int64_t)b;
     if (wdiag > 0 && wdiag < 16 && strip.cols == 0 && ntile <= BAND) {
       // a stage of a diagonal tile costs wdiag / 16 of a stage of any other (wave roles, w4_has_mfma): equal shares of the COST.
       // Tiles are in row-major order here (tile_coords, one band) and the first tile of a row is the diagonal one.
@@ -514,10 +526,11 @@ __global__ __launch_bounds__(256, 1) void gram_kbits_w4_kernel(const int8_t* __r
   }
 
   while (u < u_end) {  // workgroup-uniform
-    const int tile = (int)(u / nstages);
-    const int64_t st_begin = u - (int64_t)tile * nstages;
+    const int tile = (int)(u / seg_len);
+    const int64_t st_rel = u - (int64_t)tile * seg_len;
     const int64_t left = u_end - u;
-    const int ns = (int)((nstages - st_begin < left) ? (nstages - st_begin) : left);
+    const int ns = (int)((seg_len - st_rel < left) ? (seg_len - st_rel) : left);
+    const int64_t st_begin = seg_off + st_rel;
     u += ns;
 
     int row_blk, col_blk;
@@ -638,11 +651,13 @@ hipError_t launch_gram_kbits_w4(const int8_t* p, int64_t nv, int32_t n, int32_t*
     stages_per = (nstages + splitk - 1) / splitk;
     nblocks = (int64_t)per * kNumXcd;
     xcd_map = 2;
-  } else if (mode == 4) {
+  } else if (mode == 4 || mode == 5) {
     const int64_t nwork = (int64_t)ntri * nstages;
     nblocks = std::max<int64_t>(1, std::min<int64_t>(cus, nwork / 8));
     if (nblocks >= kNumXcd) nblocks = nblocks / kNumXcd * kNumXcd;
     xcd_map = 4;
+    // one eighth of the k-range per XCD: needs whole XCDs of workgroups and a k-range worth cutting
+    if (mode == 5 && nblocks >= kNumXcd && nstages >= 64 * kNumXcd && strip.cols == 0) xcd_map = 5;
   } else {
     const int64_t target = (int64_t)cus * 4;
     splitk = (target + ntri - 1) / ntri;

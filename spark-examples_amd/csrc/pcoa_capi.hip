@@ -682,6 +682,7 @@ int fp4_setup(pcoa_ctx* c) {
     const int64_t ntri = c->is_strip ? ntile * ((c->s_cols + 255) / 256 + 1) : ntile * (ntile + 1) / 2;
     c->kbits_mode = (ntri <= 4 * (int64_t)c->num_cu) ? 4 : 0;
     if (k.kbits_mode == 0 || k.kbits_mode == 4) c->kbits_mode = k.kbits_mode;
+    if (k.kbits_mode == 5 && c->kbits_mode == 4) c->kbits_mode = 5;   // even split per XCD k-segment (gram_kbits_w4.inl, xcd_map 5)
     if (k.kbits_mode == 2 && !c->is_strip && ls > 0) c->kbits_mode = 2;
   }
   // fp32 pipeline: the contraction of one operand buffer beside the pre-pass of the next, on two side streams.
@@ -794,7 +795,7 @@ int fp4_launch(pcoa_ctx* c, int bi, bool overlapped, int side_kind = 1) {
         e = launch(0);
       } else if (e == hipSuccess) {
         if (mode == 2) c->lockstep_launches += 1;
-        if (mode == 4) c->evensplit_launches += 1;
+        if (mode == 4 || mode == 5) c->evensplit_launches += 1;
         if (side) c->pipeline_launches += 1;
       }
     } else {
@@ -1723,22 +1724,45 @@ int pcoa_accumulate_bits(pcoa_ctx* c, const uint32_t* bits, int64_t n_variants, 
     return fail(c, PCOA_ERR_INVALID_ARG, "the bit-packed boundary needs a packed-operand engine (not PCOA_FLAG_GRAM_F32_MFMA)");
   if (n_variants == 0) return PCOA_OK;
   if (is_device_ptr) return gram_device_bits(c, bits, n_variants, ld_words, true);
-  // host bitsets: staged densely (ceil(N/32) words per row) through the tile buffer, at most 256 MiB at a time
-  const int64_t rows_cap = std::max<int64_t>(1, std::min<int64_t>(n_variants, ((int64_t)64 << 20) / need_words));
-  int rc = ensure(c, &c->tile, &c->tile_elems, rows_cap * need_words);
-  if (rc != PCOA_OK) return rc;
-  uint32_t* stage = reinterpret_cast<uint32_t*>(c->tile);
+  // host bitsets: dense rows (ceil(N/32) words each) through two device slots on the copy stream, <= 2^17 rows at a time
+  // (r06: the copy of chunk k + 1 runs beside the transpose and the contraction of chunk k, as the .bed rows of
+  // pcoa_accumulate_plink_bed do; r05 staged 64-MiB-word chunks on the ctx stream, copy and kernels in series)
+  const int64_t rows_cap = std::max<int64_t>(1, std::min<int64_t>(n_variants, (int64_t)1 << 17));
+  if (!c->csr_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->csr_stream, hipStreamNonBlocking));
+  for (auto& sl : c->bs)
+    if (!sl.copied) {
+      HIP_TRY(c, hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
+      HIP_TRY(c, hipEventCreateWithFlags(&sl.freed, hipEventDisableTiming));
+    }
+  pcoa_ctx::BedSlot* last = nullptr;
   for (int64_t v0 = 0; v0 < n_variants; v0 += rows_cap) {
     const int64_t rows = std::min(rows_cap, n_variants - v0);
+    pcoa_ctx::BedSlot* sl = &c->bs[c->bed_k++ & 1];
+    if (sl->used) HIP_TRY(c, hipEventSynchronize(sl->freed));  // the transpose that read this slot is done
+    const int64_t need_bytes = rows * need_words * 4;
+    if (need_bytes > sl->cap) {
+      if (sl->raw) dev_free(sl->raw);
+      sl->raw = nullptr;
+      sl->cap = 0;
+      HIP_TRY(c, dev_alloc((void**)&sl->raw, (size_t)(rows_cap * need_words * 4), c->device));
+      sl->cap = rows_cap * need_words * 4;
+    }
+    uint32_t* stage = reinterpret_cast<uint32_t*>(sl->raw);
     if (ld_words == need_words)   // dense rows: one linear copy (the strided form crosses the link at ~30 GB/s, this one at ~55)
-      HIP_TRY(c, hipMemcpyAsync(stage, bits + v0 * ld_words, (size_t)rows * (size_t)need_words * 4, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(c, hipMemcpyAsync(stage, bits + v0 * ld_words, (size_t)need_bytes, hipMemcpyHostToDevice, c->csr_stream));
     else
       HIP_TRY(c, hipMemcpy2DAsync(stage, (size_t)need_words * 4, bits + v0 * ld_words, (size_t)ld_words * 4,
-                                  (size_t)need_words * 4, (size_t)rows, hipMemcpyHostToDevice, c->stream));
-    rc = gram_device_bits(c, stage, rows, need_words, false);
+                                  (size_t)need_words * 4, (size_t)rows, hipMemcpyHostToDevice, c->csr_stream));
+    HIP_TRY(c, hipEventRecord(sl->copied, c->csr_stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, sl->copied, 0));
+    int rc = gram_device_bits(c, stage, rows, need_words, false);   // (its transpose runs on the ctx stream, behind the wait)
     if (rc != PCOA_OK) return rc;
+    HIP_TRY(c, hipEventRecord(sl->freed, c->stream));
+    sl->used = true;
+    last = sl;
   }
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  // host rows are consumed once their copy is done (copies complete in order on the copy stream); the kernels are queued
+  if (last) HIP_TRY(c, hipEventSynchronize(last->copied));
   return PCOA_OK;
 }
 

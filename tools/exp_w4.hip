@@ -162,7 +162,7 @@ int main(int argc, char** argv) {
       g_w4_epilogue_cost = ep;
       for (int mode : modes) {
         if (mode == 2 && gram_lockstep_splitk(cn, num_cu) == 0) continue;
-        if (mode == 4 && ntri > 4 * num_cu) continue;
+        if ((mode == 4 || mode == 5) && ntri > 4 * num_cu) continue;
         if (!timeit && mode == 0 && cv > (1 << 16)) continue;
         CK(hipMemset(s_new, 0, (size_t)sbytes));
         CK(launch_gram_kbits_w4(k1, cv, cn, s_new, num_cu, 0, mode, nullptr, GramStrip{}, wd));
