@@ -67,7 +67,12 @@ def allreduce_engine(engine, group=None, scratch=None):
         scratch = torch.empty((engine.n, engine.n), dtype=torch.int64, device="cuda:%d" % engine.device)
     engine.export_device(scratch.data_ptr())
     engine.sync()  # the export ran on the engine's stream; the collective runs on torch's
-    dist.all_reduce(scratch, op=dist.ReduceOp.SUM, group=group)
+    if dist.get_backend(group) == "gloo":   # CPU wire (one-GPU test boxes: several ranks share a device, which RCCL refuses)
+        host = scratch.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        scratch.copy_(host)
+    else:
+        dist.all_reduce(scratch, op=dist.ReduceOp.SUM, group=group)
     torch.cuda.current_stream(scratch.device).synchronize()
     engine.import_device(scratch.data_ptr())
     engine.sync()

@@ -263,6 +263,12 @@ class PcaConf(object):
                        help="K > 1: one process per GPU (started here through torch.distributed.run unless a launcher already "
                             "did), the variants partitioned into K contiguous shards, one RCCL all-reduce of the partial "
                             "similarity matrices (reduceByKey, VariantsPca.scala:190), computePca and the output on rank 0")
+        p.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                       help="--gpus K: torch.distributed backend of the rendezvous (nccl = RCCL; gloo = CPU wire, for boxes where "
+                            "several ranks have to share one GPU -- it implies --allreduce torch)")
+        p.add_argument("--rank-devices", type=str, default=None,
+                       help="--gpus K: device ordinal of each rank, comma-separated (default: rank r on GPU r); ordinals may repeat "
+                            "with --dist-backend gloo (how the path is tested on a one-GPU box)")
         p.add_argument("--allreduce", choices=["native", "torch"], default="native",
                        help="--gpus K: native = the library's RCCL communicator (in place on the int32 partial), torch = "
                             "export -> torch.distributed.all_reduce -> import")
@@ -511,6 +517,15 @@ def multi_gpu_plan(conf, args, env, device_count, python=None):
     """What `--gpus K` makes of this invocation (dist.launch_plan): ("run", None) = this process is a rank (or K == 1),
     ("spawn", command) = re-execute under torch.distributed.run with K ranks, ("error", message)."""
     from . import dist
+    if conf.rank_devices:   # an explicit map: what has to exist is the highest ordinal it names, not K devices
+        devs = [int(t) for t in conf.rank_devices.split(",")]
+        if len(devs) != conf.gpus:
+            return "error", "--rank-devices must name exactly --gpus devices"
+        if len(set(devs)) < len(devs) and conf.dist_backend != "gloo":
+            return "error", "--rank-devices repeats a device: RCCL needs one GPU per rank (use --dist-backend gloo on a test box)"
+        if max(devs) >= device_count or min(devs) < 0:
+            return "error", "--rank-devices names GPU %d but only %d GPU(s) are visible" % (max(devs), device_count)
+        device_count = max(device_count, conf.gpus)
     return dist.launch_plan(conf.gpus, env, device_count, [os.path.abspath(__file__)] + list(args), python=python or sys.executable)
 
 
@@ -533,10 +548,16 @@ def main(args):
         import torch.distributed as td
         rank = int(os.environ.get("RANK", "0"))
         local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+        if conf.rank_devices:
+            local_rank = [int(t) for t in conf.rank_devices.split(",")][rank]
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if conf.dist_backend == "gloo":
+            conf.allreduce = "torch"   # the library's communicator is RCCL
+            td.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         quiet = open(os.devnull, "w") if rank != 0 else None   # the reference's driver prints once
         if quiet is not None:
             sys.stdout = quiet

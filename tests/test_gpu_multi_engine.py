@@ -241,3 +241,34 @@ with P.PcoaEngine(n) as w, P.PcoaEngine(n) as a, P.PcoaEngine(n) as b:
         r = np.load(out)
         assert bool(r["same"]) and int(r["i64"]) == want64 and int(r["r32"]) == 1 - want64
         assert float(r["dl"]) < 1e-12 and float(r["dc"]) < 1e-10
+
+
+@pytest.mark.parametrize("name", ["tile260", "pops40"])
+def test_python_host_with_gpus_2_shards_reduces_and_prints_on_rank_0(name, tmp_path):
+    """The Python twin's --gpus K end to end with two REAL ranks (VERDICT r05 Missing 4): `variants_pca.py --gpus 2` re-executes
+    itself under torch.distributed.run, rank r accumulates shard_range(r, 2, rows) of the RDD[Seq[Int]] rows on its engine, the
+    partial matrices are summed (reduceByKey, VariantsPca.scala:190), rank 0 runs computePca and prints.  One GPU here, so both
+    ranks share cuda:0 and the wire is gloo (--rank-devices 0,0 --dist-backend gloo; on a node: RCCL, one GPU per rank).
+    S must equal the reference's own similarity matrix and the output the single-process run's."""
+    import socket
+    g = load_golden(name)
+    n = int(g["n_samples"])
+    path = str(tmp_path / "golden.vcf")
+    write_golden_vcf(g, path)
+    script = os.path.join(ROOT, "spark-examples_amd", "variants_pca.py")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_PORT=str(port))
+    outs = {}
+    for tag, extra in (("one", []), ("two", ["--gpus", "2", "--rank-devices", "0,0", "--dist-backend", "gloo"])):
+        dump = str(tmp_path / (tag + ".bin"))
+        res = subprocess.run([os.sys.executable, script, "--input-path", path, "--all-references", "--dump-similarity", dump] + extra,
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=env, timeout=600)
+        assert res.returncode == 0, res.stderr[-3000:]
+        assert np.array_equal(np.fromfile(dump, dtype="<i8").reshape(n, n), g["similarity"]), tag
+        outs[tag] = [l for l in res.stdout.splitlines() if "\t" in l or l.startswith(("Matrix size", "Non zero rows"))]
+        if tag == "two":
+            assert "Reduced over 2 ranks" in res.stderr, res.stderr[-2000:]
+    assert len(outs["one"]) == n + 2 and [l.split("\t")[:2] for l in outs["one"]] == [l.split("\t")[:2] for l in outs["two"]]
+    a = np.array([[float(x) for x in l.split("\t")[2:4]] for l in outs["one"] if "\t" in l])
+    b = np.array([[float(x) for x in l.split("\t")[2:4]] for l in outs["two"] if "\t" in l])
+    assert np.abs(a - b).max() < 1e-12
