@@ -769,7 +769,9 @@ struct JoinSpill {
 
 // getCallsRdd (:153-168) for two (joinDatasets :115-128) or more (mergeDatasets :130-148) sets of one key partition
 void join_or_merge(const std::vector<std::vector<Variant>>& sets, std::vector<std::vector<int32_t>>& callsets) {
-  if (sets.size() == 2) {
+  if (sets.size() == 1) {   // one variant set: getCallsRdd takes its records as they are (:153-157)
+    for (const auto& v : sets[0]) callsets.push_back(v.carriers);
+  } else if (sets.size() == 2) {
     std::unordered_map<std::string, std::vector<const Variant*>> right;
     for (const auto& v : sets[1]) right[v.key].push_back(&v);
     for (const auto& v : sets[0]) {
@@ -1132,7 +1134,9 @@ int main(int argc, char** argv) {
                           !conf.parse_only && !conf.debug_datasets && conf.gpus == 1 && is_regular_file(conf.input_path[0]);
   // Several VCFs (join / merge) are streamed too (r06): one pass per set into hash-partitioned spill files, then one key
   // partition at a time (JoinSpill above).  --debug-datasets prints per-record lines in file order and keeps the in-memory path.
-  bool stream_join = conf.input_path.size() >= 2 && !conf.no_stream && !conf.parse_only && !conf.debug_datasets;
+  // A single VCF for SEVERAL engines (--gpus k) takes the same road with one set: the parser's one pass deals the records to
+  // the key partitions, engine g feeds partitions g, g + k, .. -- the r05 path parsed the whole file into memory first.
+  bool stream_join = (conf.input_path.size() >= 2 || conf.gpus > 1) && !conf.no_stream && !conf.parse_only && !conf.debug_datasets;
   for (const auto& pth : conf.input_path) stream_join = stream_join && !is_plink_path(pth) && is_regular_file(pth);
   JoinSpill spill;
   std::vector<std::string> join_stems;
@@ -1336,7 +1340,7 @@ int main(int argc, char** argv) {
   };
   pcoa_ctx* ctx = run_engines(conf, n, feed, &how, &feed_s, prepare);
   if (stream_join) {
-    std::fprintf(stderr, "Joined %zu variant sets through %d key partitions: %lld records, %.1f MB of spill files in %s\n",
+    std::fprintf(stderr, "%zu variant set(s) through %d key partitions: %lld records, %.1f MB of spill files in %s\n",
                  conf.input_path.size(), spill.parts, (long long)spilled_records, spill.bytes / 1e6, spill.dir.c_str());
     spill.remove_all();
   }
