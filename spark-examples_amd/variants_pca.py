@@ -27,6 +27,13 @@ import sys
 
 import numpy as np
 
+if __name__ == "__main__" and not __package__:
+    # started by path (`python spark-examples_amd/variants_pca.py ...`; torch.distributed.run starts a rank this way): load the
+    # module inside its package -- the relative imports below need one
+    import importlib
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.exit(importlib.import_module("spark-examples_amd.variants_pca").main(sys.argv[1:]))
+
 from .engine import PcoaEngine
 
 PLINK_BLOCK_ROWS = 1 << 16   # raw .bed rows handed to pcoa_accumulate_plink_bed per call (41 MB at N = 2504)
@@ -588,8 +595,4 @@ def main(args):
 
 
 if __name__ == "__main__":
-    if not __package__:   # started by path (torch.distributed.run starts a rank this way): load the module inside its package
-        import importlib
-        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        sys.exit(importlib.import_module("spark-examples_amd.variants_pca").main(sys.argv[1:]))
     sys.exit(main(sys.argv[1:]))
