@@ -137,8 +137,9 @@ typedef struct pcoa_timings {
   int64_t reduce_int32_calls;   /* pcoa_gram_reduce_from calls that took the int32 path (peer copy of 4 N^2 bytes)           */
   int64_t narrowed_to_int32;    /* times an int64 S handed in (import / load / int64 reductions) was found to fit int32 and
                                    moved back into the int32 matrix, which keeps the large-N upper-triangle forms available  */
-  int32_t lanczos_block_steps;  /* band-Lanczos fallback (clustered leading eigenvalues): basis vectors built by the last
-                                   pcoa_compute / pcoa_lanczos_with_matvec, 0 = the single-vector iteration sufficed         */
+  int32_t lanczos_block_steps;  /* band-Lanczos fallback (clustered leading eigenvalues): columns (= mat-vecs) it processed in
+                                   the last pcoa_compute / pcoa_lanczos_with_matvec, thick restarts included; 0 = the
+                                   single-vector iteration sufficed                                                          */
   int32_t reserved_r06;
 } pcoa_timings;
 #define PCOA_TIMINGS_R03_BYTES 192  /* offsetof(pcoa_timings, csr_stage_seconds): what pcoa_get_timings writes */

@@ -741,6 +741,11 @@ __global__ __launch_bounds__(1024) void band_finish_kernel(double* __restrict__ 
   }
 }
 
+// after a thick restart the first p columns of H are the kept Ritz values on the diagonal (the Ritz vectors diagonalise H)
+__global__ __launch_bounds__(64) void band_restart_h_kernel(double* __restrict__ hfull, int mcap, int p, const double* __restrict__ theta) {
+  for (int t = threadIdx.x; t < p; t += 64) hfull[(int64_t)t * mcap + t] = theta[t];
+}
+
 // the leading J x J block of H as a dense symmetric matrix (upper triangle from the columns, mirrored)
 __global__ __launch_bounds__(256) void band_gather_kernel(const double* __restrict__ hfull, int mcap, int J, double* __restrict__ a) {
   const int t = blockIdx.x * 256 + threadIdx.x;
@@ -770,7 +775,8 @@ size_t lanczos_workspace_doubles(int32_t n, int32_t k, int32_t mmax) {
   // band fallback: H (mcap x mcap), its dense copy, d / e / tau / q (mcap each), w (2 mcap), scratch (6 mcap), the
   // eigenvectors of H (k x mcap), two scalars
   const size_t mcap = (size_t)mmax + 1;
-  const size_t band = 2 * mcap * mcap + 12 * mcap + (size_t)k * mcap + 16;
+  const size_t pmax = 2 * ((size_t)k + 2);   // band_pmax(k)
+  const size_t band = 2 * mcap * mcap + 12 * mcap + 2 * pmax * mcap + 4 * pmax + 32;
   return (size_t)(mmax + 1) * n + (size_t)n + (size_t)k * n + 4 * (size_t)(mmax + 2) + 4 * (size_t)k + 16 +
          nb * (size_t)(mmax + 2) + band;
 }
@@ -781,6 +787,7 @@ size_t lanczos_workspace_doubles(int32_t n, int32_t k, int32_t mmax) {
 namespace {
 hipError_t lanczos_band(const EigWorkspace& ws, double* lz, int32_t n, int32_t k, int32_t mmax, double tol, double* lam_sel_host,
                         int* converged, int* band_steps_out, hipStream_t stream, const LanczosMatvec* mv);
+inline int band_pmax(int k) { return 2 * (k + 2); }   // Ritz vectors a thick restart of the band iteration keeps, at most
 hipError_t lanczos_single(const EigWorkspace& ws, double* lz, int32_t n, int32_t k, int32_t mmax, double tol,
                           double* lam_sel_host, int* converged, int* steps_out, hipStream_t stream, const LanczosMatvec* mv);
 }
@@ -964,6 +971,11 @@ hipError_t lanczos_single(const EigWorkspace& ws, double* lz, int32_t n, int32_t
 // The band iteration (see band_finish_kernel above).  Same contract as lanczos_single: *converged = 1 -> ws.z[0..k) holds the
 // unnormalised Ritz vectors, lam_sel_host[0..k) their Ritz values by decreasing magnitude.  One host round trip per column (the
 // norm of the new candidate decides whether it joins the basis): this is the fallback, not the fast path.
+// THICK RESTARTS: the basis holds at most mmax vectors.  When it is full and the wanted pairs have not passed, the p = 2 b Ritz
+// vectors of largest |theta| replace the processed part of the basis and the iteration goes on from the candidates that were
+// still waiting: [u_1 .. u_p, v_J .. v_cnt) is orthonormal, the projected matrix on it is diag(theta) in its first p columns
+// (Ritz vectors diagonalise H) and every later column is measured as it is processed -- so no spectrum, however slowly it
+// converges, ends in "not converged" before a budget of ~40 basis fills is spent (ARPACK's scheme on the band process).
 hipError_t lanczos_band(const EigWorkspace& ws, double* lz, int32_t n, int32_t k, int32_t mmax, double tol, double* lam_sel_host,
                         int* converged, int* band_steps_out, hipStream_t stream, const LanczosMatvec* mv) {
   auto matvec = [&](const double* v, double* y) -> hipError_t {
@@ -978,20 +990,23 @@ hipError_t lanczos_band(const EigWorkspace& ws, double* lz, int32_t n, int32_t k
   *converged = 0;
   if (mmax > n) mmax = n;
   if (mmax > kMaxKrylov) mmax = kMaxKrylov;
+  const int ma = mmax;   // what the workspace was laid out for (lanczos_workspace_doubles; the same clamps as lanczos_single)
+  if (debug_knobs().lanczos_band_mmax > 0 && debug_knobs().lanczos_band_mmax < mmax) mmax = debug_knobs().lanczos_band_mmax;   // tests: restarts
   const int bw0 = std::min<int>(k + 2, n);   // block width
-  if (mmax < 3 * bw0 + 2 || n < 8) return hipSuccess;
+  const int pk = std::min<int>(2 * bw0, band_pmax(k));   // Ritz vectors kept across a restart (the k wanted ones first)
+  if (mmax < 4 * pk + 2 || n < 8) return hipSuccess;   // (a restart copies [v_J .. v_cnt) behind the kept Ritz vectors: no overlap from here)
   const unsigned nb = (unsigned)((n + 255) / 256);
-  const int mcap = mmax + 1;
+  const int mcap = ma + 1;   // (layout of the workspace: independent of the mmax in use)
   double* V = lz;
-  double* w = V + (size_t)(mmax + 1) * n;
+  double* w = V + (size_t)(ma + 1) * n;
   double* bu = w + n;
   double* alpha = bu + (size_t)k * n;
-  double* beta = alpha + (mmax + 2);
-  double* h1 = beta + (mmax + 2);
-  double* h2 = h1 + (mmax + 2);
-  double* rec = h2 + (mmax + 2);
-  double* part = rec + (4 * (size_t)k + 16);
-  double* pnorm = part + (size_t)nb * (mmax + 1);
+  double* beta = alpha + (ma + 2);
+  double* h1 = beta + (ma + 2);
+  double* h2 = h1 + (ma + 2);
+  double* rec0 = h2 + (ma + 2);
+  double* part = rec0 + (4 * (size_t)k + 16);
+  double* pnorm = part + (size_t)nb * (ma + 1);
   double* hfull = pnorm + nb;                       // [mcap][mcap], column j at hfull + j * mcap
   double* hdense = hfull + (size_t)mcap * mcap;     // J x J copy the dense solver works in
   double* hd = hdense + (size_t)mcap * mcap;
@@ -1000,11 +1015,15 @@ hipError_t lanczos_band(const EigWorkspace& ws, double* lz, int32_t n, int32_t k
   double* hq = htau + mcap;
   double* hw = hq + mcap;                           // 2 mcap
   double* hscr = hw + 2 * (size_t)mcap;             // 6 mcap
-  double* hout = hscr + 6 * (size_t)mcap;           // [k][mcap] eigenvectors of H
-  double* out2 = hout + (size_t)k * mcap;           // nrm, ||B v_j||
+  double* hout = hscr + 6 * (size_t)mcap;           // [pk][mcap] eigenvectors of H
+  double* hz = hout + (size_t)band_pmax(k) * mcap;  // [pk][mcap] eigenvectors of the tridiagonal form (inverse iteration)
+  double* rec = hz + (size_t)band_pmax(k) * mcap;   // candidates [2 pk + 2] | residuals [k]
+  double* out2 = rec + (3 * (size_t)band_pmax(k) + 8);   // nrm, ||B v_j||
+  double* hlam = out2 + 2;                          // [pk] selected Ritz values (device)
 
   EigWorkspace hs = ws;   // the projected problem goes through the dense solver's kernels
   hs.a = hdense; hs.d = hd; hs.e = he; hs.tau = htau; hs.q = hq; hs.w = hw; hs.scratch = hscr; hs.wy = nullptr;
+  hs.z = hz; hs.lam = hlam;
 
   std::vector<double> pageable;
   auto read_back = [&](const double* src, size_t count, double** host) -> hipError_t {
@@ -1019,6 +1038,8 @@ hipError_t lanczos_band(const EigWorkspace& ws, double* lz, int32_t n, int32_t k
     *host = hrec;
     return hipSuccess;
   };
+  hipError_t e = hipMemsetAsync(hfull, 0, sizeof(double) * (size_t)mcap * mcap, stream);   // entries no column ever measured are zeros
+  if (e != hipSuccess) return e;
 
   // ---- the start block: bw0 pseudo-random vectors, orthonormalised by the same CGS2 kernels
   hipLaunchKernelGGL(lanczos_init_kernel, dim3(1), dim3(1024), 0, stream, V, n, 0u);
@@ -1035,32 +1056,39 @@ hipError_t lanczos_band(const EigWorkspace& ws, double* lz, int32_t n, int32_t k
   int next_check = std::max(12, 3 * bw0);
   std::vector<double> cand;
   std::vector<int32_t> idx;
-  bool exhausted = false;
-  for (int j = 0; j < cnt && j + 1 <= mmax - 1; ++j) {
+  const int cap = mmax - pk;          // basis vectors in use at most: pk slots stay free for the Ritz vectors of a restart
+  const int64_t budget = 40LL * mmax; // columns (= mat-vecs) in all
+  int64_t columns = 0;
+  int restarts = 0;
+  int j = 0;                          // next column to process
+  for (;;) {
     // column j: w = B v_j, orthogonalised against the whole basis; what is left becomes v_cnt
     {
       const hipError_t em = matvec(V + (size_t)j * n, w);
       if (em != hipSuccess) return em;
     }
+    columns += 1;
     hipLaunchKernelGGL(cgs_dots_kernel, dim3((unsigned)cnt), dim3(256), 0, stream, V, n, w, h1);
     hipLaunchKernelGGL(cgs_update_dots_kernel, dim3(nb), dim3(256), 0, stream, V, n, cnt, h1, w, part);
     hipLaunchKernelGGL(cgs_update_norm_kernel, dim3(nb), dim3(256), 0, stream, V, n, cnt, part, (int)nb, w, h2, pnorm);
-    const bool room = cnt < mmax;   // V holds mmax + 1 vectors, the CGS kernels' LDS arrays mmax coefficients
-    hipLaunchKernelGGL(band_finish_kernel, dim3(1), dim3(1024), 0, stream, V, n, room ? cnt : mmax, w, pnorm, (int)nb, h1, h2, cnt,
-                       hfull + (size_t)j * mcap, out2);
+    const bool room = cnt < cap;
+    hipLaunchKernelGGL(band_finish_kernel, dim3(1), dim3(1024), 0, stream, V, n, cnt, w, pnorm, (int)nb, h1, h2, cnt,
+                       hfull + (size_t)j * mcap, out2);   // (slot cnt <= cap is free either way: it is counted only with `room`)
     double* h2v = nullptr;
-    hipError_t e = read_back(out2, 2, &h2v);
-    if (e != hipSuccess) return e;
+    if ((e = read_back(out2, 2, &h2v)) != hipSuccess) return e;
     const double nrm = h2v[0];
     anorm = fmax(anorm, h2v[1]);
     if (!std::isfinite(nrm) || !std::isfinite(anorm)) return hipSuccess;   // garbage: the dense path decides
     // a candidate that vanishes against the basis is deflated (the band narrows); none left = an invariant subspace
     if (room && nrm > 1e-9 * anorm) cnt += 1;
     const int J = j + 1;           // columns of H known so far
-    if (band_steps_out) *band_steps_out = cnt;
-    exhausted = (J == cnt);        // every basis vector has been multiplied and nothing new came of it
-    const bool last = exhausted || J == mmax - 1 || !(j + 1 < cnt);
-    if (J != next_check && !last) continue;
+    j += 1;
+    if (band_steps_out) *band_steps_out = (int)std::min<int64_t>(columns, 0x7fffffff);
+    const bool exhausted = (J == cnt);        // every basis vector has been multiplied and nothing new came of it
+    const bool full = !exhausted && cnt >= cap && J + bw0 >= cnt;   // the basis is full and its last candidates are next
+    const bool out_of_budget = columns >= budget;
+    const bool last = exhausted || out_of_budget;
+    if (J != next_check && !last && !full) continue;
     if (J < k + 2 && !exhausted) continue;
     next_check = (J < 64) ? J + 8 : J + J / 4;
 
@@ -1068,24 +1096,25 @@ hipError_t lanczos_band(const EigWorkspace& ws, double* lz, int32_t n, int32_t k
     if (J < 2) return hipSuccess;
     hipLaunchKernelGGL(band_gather_kernel, dim3((unsigned)((J * J + 255) / 256)), dim3(256), 0, stream, hfull, mcap, J, hdense);
     if ((e = launch_tridiagonalize(hs, J, stream)) != hipSuccess) return e;
-    idx.clear();
     const int kk = std::min(k, J);
-    for (int t = 0; t <= kk && t < J; ++t) idx.push_back(J - 1 - t);
-    for (int t = 0; t <= kk; ++t)
-      if (t < J - 1 - kk) idx.push_back(t);
+    const int pw = full ? std::min(pk, J - 1) : kk;   // eigenpairs of H wanted now: the k to test, or the pk a restart keeps
+    idx.clear();
+    for (int t = 0; t <= pw && t < J; ++t) idx.push_back(J - 1 - t);
+    for (int t = 0; t <= pw; ++t)
+      if (t < J - 1 - pw) idx.push_back(t);
     const int nc = (int)idx.size();
     double* rec_res = rec + nc;
     if ((e = launch_bisect(hs, J, idx.data(), nc, rec, stream)) != hipSuccess) return e;
-    hipLaunchKernelGGL(ritz_select_kernel, dim3(1), dim3(64), 0, stream, rec, nc, kk, ws.lam);
-    if ((e = launch_inverse_iteration_dev(hs, J, kk, stream)) != hipSuccess) return e;
-    if ((e = launch_backtransform(hs, J, kk, 0, 1, hout, stream)) != hipSuccess) return e;   // eigenvectors of H: hout[c * J + p]
+    hipLaunchKernelGGL(ritz_select_kernel, dim3(1), dim3(64), 0, stream, rec, nc, pw, hlam);
+    if ((e = launch_inverse_iteration_dev(hs, J, pw, stream)) != hipSuccess) return e;
+    if ((e = launch_backtransform(hs, J, pw, 0, 1, hout, stream)) != hipSuccess) return e;   // eigenvectors of H: hout[c * J + p]
     hipLaunchKernelGGL(ritz_kernel, dim3(nb, (unsigned)kk), dim3(256), 0, stream, V, n, J, hout, bu);
     if ((e = hipMemcpyAsync(ws.z, bu, sizeof(double) * (size_t)kk * n, hipMemcpyDeviceToDevice, stream)) != hipSuccess) return e;
     for (int t = 0; t < kk; ++t) {
       const hipError_t em = matvec(ws.z + (size_t)t * n, bu + (size_t)t * n);
       if (em != hipSuccess) return em;
     }
-    hipLaunchKernelGGL(residual_kernel, dim3((unsigned)kk), dim3(1024), 0, stream, bu, ws.z, n, ws.lam, rec_res);
+    hipLaunchKernelGGL(residual_kernel, dim3((unsigned)kk), dim3(1024), 0, stream, bu, ws.z, n, hlam, rec_res);
     double* hrec = nullptr;
     if ((e = read_back(rec, (size_t)nc + kk, &hrec)) != hipSuccess) return e;
     cand.assign(hrec, hrec + nc);
@@ -1118,17 +1147,31 @@ hipError_t lanczos_band(const EigWorkspace& ws, double* lz, int32_t n, int32_t k
       tight = tight && fin && r * 0.125 <= tol * scale && (r * 0.125 <= 1e-8 * g || r <= 1e-13 * scale);
     }
     if (debug_knobs().lanczos_trace != 0) {
-      std::fprintf(stderr, "[lanczos band] J=%d basis=%d scale=%.6e", J, cnt, scale);
+      std::fprintf(stderr, "[lanczos band] J=%d basis=%d restarts=%d columns=%lld scale=%.6e", J, cnt, restarts, (long long)columns, scale);
       for (int t = 0; t < k; ++t) std::fprintf(stderr, "  theta%d=%.12e true=%.3e", t, lam_sel_host[t], hres[t]);
-      std::fprintf(stderr, "  tight=%d loose=%d last=%d\n", (int)tight, (int)loose, (int)last);
+      std::fprintf(stderr, "  tight=%d loose=%d last=%d full=%d\n", (int)tight, (int)loose, (int)last, (int)full);
     }
     if (tight || (last && loose)) {
       *converged = 1;
       return hipGetLastError();
     }
     if (last) return hipSuccess;
+    if (!full) continue;
+
+    // ---- thick restart: U = V_J Y (pw vectors) into the free slots, then [U, v_J .. v_cnt) becomes the basis
+    hipLaunchKernelGGL(ritz_kernel, dim3(nb, (unsigned)pw), dim3(256), 0, stream, V, n, J, hout, V + (size_t)cnt * n);   // slots cnt .. cnt + pw - 1 <= mmax
+    const int carry = cnt - J;   // candidates not yet multiplied
+    if ((e = hipMemcpyAsync(V, V + (size_t)cnt * n, sizeof(double) * (size_t)pw * n, hipMemcpyDeviceToDevice, stream)) != hipSuccess) return e;
+    if (carry > 0 &&   // (J > pw + carry: source and destination do not overlap)
+        (e = hipMemcpyAsync(V + (size_t)pw * n, V + (size_t)J * n, sizeof(double) * (size_t)carry * n, hipMemcpyDeviceToDevice, stream)) != hipSuccess)
+      return e;
+    if ((e = hipMemsetAsync(hfull, 0, sizeof(double) * (size_t)mcap * mcap, stream)) != hipSuccess) return e;
+    hipLaunchKernelGGL(band_restart_h_kernel, dim3(1), dim3(64), 0, stream, hfull, mcap, pw, hlam);
+    cnt = pw + carry;
+    j = pw;
+    restarts += 1;
+    next_check = j + std::max(8, 2 * bw0);
   }
-  return hipGetLastError();
 }
 
 }  // namespace

@@ -1403,6 +1403,7 @@ const DebugKnobs& debug_knobs() {
     k.no_narrow = (int)num("PCOA_NO_NARROW");
     k.synth_tile = (int)num("PCOA_SYNTH_TILE");
     if (const char* v = std::getenv("PCOA_LANCZOS_BAND")) k.lanczos_band = std::atoi(v);
+    k.lanczos_band_mmax = (int)num("PCOA_LANCZOS_BAND_MMAX");
     return k;
   }();
   return knobs;

@@ -48,6 +48,7 @@ struct DebugKnobs {
   int bits_pipeline = 0;           // PCOA_BITS_PIPELINE = 1: bitset tiles through the co-resident pipeline as in r03 / r04 (default: transpose and contraction in series, the contraction as the one-wave-per-SIMD kernel)
   int headstart_us = -1;           // PCOA_HEADSTART_US: the contraction's head start over the next pre-pass (default 10; 0 = none)
   int kbits_coreside_max_npad = 0; // PCOA_KBITS_CORESIDE_MAX_NPAD: largest padded sample count the co-resident pipeline is used for
+  int lanczos_band_mmax = 0;       // PCOA_LANCZOS_BAND_MMAX: basis size of the band iteration (tests: forces thick restarts)
   int lanczos_band = 1;            // PCOA_LANCZOS_BAND = 0: no band-Lanczos fallback (r05 behaviour); 2: ONLY the band iteration (tests)
   int synth_tile = 0;              // PCOA_SYNTH_TILE = 1: pcoa_accumulate_synthetic through the fp32 staging tile + pre-pass (r05 path) instead of generating the k-bits operand directly
   int no_narrow = 0;               // PCOA_NO_NARROW = 1: an int64 S that fits int32 stays int64 and pcoa_gram_reduce_from always widens (r05 behaviour; tests of the int64 kernels)
