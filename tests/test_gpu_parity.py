@@ -1279,3 +1279,47 @@ def test_caller_supplied_operator_with_a_degenerate_leading_pair(P):
         for c in range(2):
             assert np.linalg.norm(dd * comps[:, c] - lam[c] * comps[:, c]) < 1e-10
         assert abs(comps[:, 0] @ comps[:, 1]) < 1e-9
+
+
+@pytest.mark.parametrize("n,n_pops,calls", [(37, 1, (1, 127, 300)), (1001, 7, (130, 5, 4000, 129)), (2504, 5, (100000, 77)),
+                                            (4100, 64, (3000, 1029))])
+def test_synthetic_model_written_straight_into_the_operand_equals_its_host_twin(P, O, n, n_pops, calls):
+    """pcoa_accumulate_synthetic on the k-bits operand (r06: synth_kbits_kernel, no fp32 tile, no pre-pass): S equals the oracle's
+    on the host twin of the generator -- sample counts that are no multiple of 4, call lengths that end in part-filled blocks of
+    128 variants, 1 to 64 populations, several calls -- and the r05 path through the staging tile (PCOA_SYNTH_TILE=1 in a
+    child process) gives the same matrix."""
+    synth = load_pkg("synth")
+    seed = 4242 + n
+    sizes = np.linspace(1.0, 2.0, n_pops)
+    offs = synth.pop_offsets(n, sizes=sizes)
+    v_total = sum(calls)
+    thr = synth.thresholds(seed, 0, v_total, n_pops=n_pops)
+    x = synth.genotypes(seed, 0, thr, offs)
+    want = O.similarity_from_dense(x, n)
+    with P.PcoaEngine(n) as eng:
+        v0 = 0
+        for c in calls:
+            eng.accumulate_synthetic(seed, offs, thr[v0:v0 + c], v0)
+            v0 += c
+        got = eng.gram()
+        t = eng.timings()
+    assert np.array_equal(got, want)
+    assert t["pack_launches"] == 0 and t["synth_seconds"] > 0      # no staging tile, no pre-pass
+    if n == 1001:
+        code = r"""
+import sys, numpy as np, importlib
+sys.path.insert(0, %r)
+P = importlib.import_module("spark-examples_amd"); synth = importlib.import_module("spark-examples_amd.synth")
+n, n_pops, seed, calls = 1001, 7, 4242 + 1001, (130, 5, 4000, 129)
+offs = synth.pop_offsets(n, sizes=np.linspace(1.0, 2.0, n_pops)); thr = synth.thresholds(seed, 0, sum(calls), n_pops=n_pops)
+with P.PcoaEngine(n) as eng:
+    v0 = 0
+    for c in calls:
+        eng.accumulate_synthetic(seed, offs, thr[v0:v0 + c], v0); v0 += c
+    np.save(sys.argv[1], eng.gram()); assert eng.timings()["pack_launches"] > 0
+""" % ROOT
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "tile.npy")
+            subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, PCOA_SYNTH_TILE="1"))
+            assert np.array_equal(np.load(out), want)
