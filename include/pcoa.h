@@ -321,7 +321,9 @@ int pcoa_accumulate_plink_bed(pcoa_ctx* ctx, const uint8_t* bed_rows, int64_t n_
                               int is_device_ptr);
 
 /* Generates variants [first_variant, first_variant + n_variants) of the synthetic model directly
- * in HBM and accumulates them (no host tile).  params->thresholds covers exactly that range. */
+ * in HBM and accumulates them (no host tile).  params->thresholds covers exactly that range.
+ * r06: on the default engine the genotypes are written straight into the 1-bit operand (no fp32 staging tile, no pre-pass,
+ * no host synchronisation per chunk); the call returns when the thresholds have been copied, the rest is queued. */
 int pcoa_accumulate_synthetic(pcoa_ctx* ctx, const pcoa_synth_params* params, int64_t first_variant,
                               int64_t n_variants);
 
@@ -413,7 +415,12 @@ int pcoa_center_read_f64(pcoa_ctx* ctx, double* out_b_nxn, double* out_row_sums,
  *   out_eigenvalues: num_pc eigenvalues of B, ordered by decreasing magnitude -- the order of the
  *                    singular values of Cov that MLlib's SVD sorts by (s = lambda^2/(N-1)). May be NULL.
  *   out_nonzero_rows: rowSums.filter(_ > 0).size (VariantsPca.scala:207). May be NULL.
- * 0 < num_pc <= N, else PCOA_ERR_INVALID_ARG (MLlib: require(k > 0 && k <= n)). */
+ * 0 < num_pc <= N, else PCOA_ERR_INVALID_ARG (MLlib: require(k > 0 && k <= n)).
+ * Solver: Lanczos on the centred matrix (never materialised), a pair returned only after its TRUE residual
+ * ||B u - theta u|| passed on the device; if the single-vector iteration does not verify (clustered leading eigenvalues,
+ * slow spectra) the band iteration with thick restarts takes over (r06), then -- up to N = 16,384 -- the dense Householder
+ * solver.  PCOA_ERR_NOT_CONVERGED is what is left when all of them fail (pcoa_timings.eig_method / lanczos_block_steps
+ * tell which one answered). */
 int pcoa_compute(pcoa_ctx* ctx, int32_t num_pc, double* out_components, double* out_eigenvalues,
                  int32_t* out_nonzero_rows);
 
