@@ -580,6 +580,24 @@ def main():
                 "avg_launch_ms": 1e3 * f32_s,
                 "note": "gram_kernel=f32 (PCOA_FLAG_GRAM_F32_MFMA) on the first %d variants of the batch; not the default path" % vf}
         if world == 1 and not args.no_extras:
+            # the int8-MFMA path (tiles with carrier multiplicities; forced here on the binary cohort: same kernels, same bytes):
+            # r06 runs the pre-pass of chunk k + 1 on a stream of its own beside the contraction of chunk k
+            with P.PcoaEngine(n, device=local_rank, gram_kernel="i8") as e8:
+                xb = x[:min(v, resident)]
+                for _ in range(2):
+                    e8.accumulate_dense(xb)
+                e8.finalize(); e8.sync(); e8.reset(); e8.reset_timings(); e8.sync()
+                t1 = time.perf_counter()
+                for _ in range(steps):
+                    e8.accumulate_dense(xb)
+                e8.finalize(); e8.sync()
+                dti = time.perf_counter() - t1
+                ti8 = e8.timings()
+            out["int8_path"] = {"value": xb.shape[0] * steps / dti, "unit": "variants/s", "ms_per_step": 1e3 * dti / steps,
+                                "pack_ms_per_step": 1e3 * ti8["pack_seconds"] / steps, "gram_ms_per_step": 1e3 * ti8["gram_kernel_seconds"] / steps,
+                                "note": "PCOA_FLAG_GRAM_I8_MFMA on the same fp32 batch: pack fp32 -> int8 (HBM-bound) + v_mfma_i32_32x32x32_i8; "
+                                        "pack + gram > step means the two overlapped (two workspaces, pre-pass on its own stream)"}
+        if world == 1 and not args.no_extras:
             # the production input format (one byte per genotype): same contraction, 4x cheaper pre-pass
             x1 = x[:min(v, resident)]          # the extras below work on the first resident batch
             x8 = x1.to(torch.uint8)
