@@ -581,7 +581,8 @@ def main():
                 "note": "gram_kernel=f32 (PCOA_FLAG_GRAM_F32_MFMA) on the first %d variants of the batch; not the default path" % vf}
         if world == 1 and not args.no_extras:
             # the int8-MFMA path (tiles with carrier multiplicities; forced here on the binary cohort: same kernels, same bytes):
-            # r06 runs the pre-pass of chunk k + 1 on a stream of its own beside the contraction of chunk k
+            # pre-pass and contraction in series (r06 tried the pre-pass on a stream of its own with two workspaces: the two
+            # kernels do not co-reside -- the contraction's waves hold every register of a CU -- and the step stayed the sum)
             with P.PcoaEngine(n, device=local_rank, gram_kernel="i8") as e8:
                 xb = x[:min(v, resident)]
                 for _ in range(2):
@@ -596,7 +597,7 @@ def main():
             out["int8_path"] = {"value": xb.shape[0] * steps / dti, "unit": "variants/s", "ms_per_step": 1e3 * dti / steps,
                                 "pack_ms_per_step": 1e3 * ti8["pack_seconds"] / steps, "gram_ms_per_step": 1e3 * ti8["gram_kernel_seconds"] / steps,
                                 "note": "PCOA_FLAG_GRAM_I8_MFMA on the same fp32 batch: pack fp32 -> int8 (HBM-bound) + v_mfma_i32_32x32x32_i8; "
-                                        "pack + gram > step means the two overlapped (two workspaces, pre-pass on its own stream)"}
+                                        "in series on the ctx stream (pcoa.h: this path is not pipelined)"}
         if world == 1 and not args.no_extras:
             # the production input format (one byte per genotype): same contraction, 4x cheaper pre-pass
             x1 = x[:min(v, resident)]          # the extras below work on the first resident batch

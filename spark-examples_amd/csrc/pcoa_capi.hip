@@ -304,19 +304,8 @@ struct pcoa_ctx {
   int64_t reduce_i32_calls = 0, narrowed = 0, allreduce_calls = 0;
   int32_t comm_ranks = 0, allreduce_int32 = 0, matvec_form = 0, lanczos_block_steps = 0;
   int64_t* coll = nullptr;         // 2 int64: {variants in S32, has-S64 flag} agreed across ranks
-  int8_t* pack_buf = nullptr;      // k-blocked int8 workspace of the i8 path: carrier lists with repeats (lazy)
+  int8_t* pack_buf = nullptr;      // k-blocked int8 workspace of the i8 path (lazy)
   int64_t pack_cap = 0;            // bytes
-  // int8 path of dense tiles (r06): two workspaces and a stream of its own -- the pre-pass of chunk k + 1 runs beside the
-  // contraction of chunk k (r05: both on the ctx stream, in series: 225 M variants/s)
-  struct I8Buf {
-    int8_t* p = nullptr; int64_t cap = 0;
-    hipEvent_t packed = nullptr, consumed = nullptr;
-    bool used = false;
-  };
-  I8Buf i8[2];
-  int i8_k = 0;
-  hipStream_t i8_stream = nullptr;
-  hipEvent_t ev_i8 = nullptr;
   bool use_i8 = true;              // packed-operand Gram (FP4 / int8) or fp32-MFMA Gram
   int packed_mode = 0;             // 0 auto (FP4 for binary tiles, int8 otherwise), 2 int8 only, 3 FP4 only
   // Form of the binary-tile operand in HBM: 2 = k-bits (1 bit per genotype, expanded to MX-FP4 in registers by the
@@ -436,7 +425,6 @@ void drain_events(pcoa_ctx* c, bool wait) {
     (void)hipStreamSynchronize(c->stream);
     if (c->pack_stream) (void)hipStreamSynchronize(c->pack_stream);
     if (c->gram_stream) (void)hipStreamSynchronize(c->gram_stream);
-    if (c->i8_stream) (void)hipStreamSynchronize(c->i8_stream);
   }
   size_t keep = 0;
   for (size_t i = 0; i < c->pending.size(); ++i) {
@@ -663,7 +651,7 @@ int fork_to(pcoa_ctx* c, hipStream_t side) {
   return PCOA_OK;
 }
 
-int int8_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64_t ld, bool staged = true);
+int int8_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64_t ld);
 int csr_validate(pcoa_ctx* c);
 
 // Lazily creates what the FP4 path needs besides the operand memory: the buffer flags (device + pinned host), the
@@ -861,7 +849,7 @@ int fp4_resolve(pcoa_ctx* c, int bi, bool redo = true) {
       std::vector<pcoa_ctx::Fp4Chunk> chunks;
       chunks.swap(b.chunks);
       for (const auto& ch : chunks)
-        if ((rc = int8_chunk(c, ch.x, ch.is_u8, ch.nv, ch.ld, /*staged=*/false)) != PCOA_OK) break;   // caller device tiles
+        if ((rc = int8_chunk(c, ch.x, ch.is_u8, ch.nv, ch.ld)) != PCOA_OK) break;
     }
   }
   b.chunks.clear();
@@ -1020,58 +1008,32 @@ void fp4_commit(pcoa_ctx* c, int64_t kb, int64_t vars) {
   c->strip_centering_set = false;
 }
 
-// int8 path of one chunk: pre-pass into a workspace, then the contraction.  The pre-pass reports the largest carrier
-// multiplicity m it met; one variant adds at most m^2 to an entry of S, so the launch is cut into pieces of
-// < 2^31 / m^2 variants (int32 accumulators and partials) and the books carry the weight m^2.
-// r06: the pre-pass runs on a stream of its own into one of TWO workspaces, the contraction on the ctx stream behind it --
-// while the host waits for chunk k + 1's pre-pass (it needs m before it can cut the launches) the contraction of chunk k is
-// still running: pre-pass (HBM-bound) and contraction (matrix cores) overlap instead of alternating.
-// staged: x_chunk is the library's staging tile, filled by a copy on the ctx stream that the pre-pass has to wait for; a
-// caller's device tile (valid until the next synchronising call) needs no such order.
-int int8_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64_t ld, bool staged) {
+// int8 path of one chunk: pre-pass into the workspace and contraction at once, on the ctx stream.  The pre-pass
+// reports the largest carrier multiplicity m it met; one variant adds at most m^2 to an entry of S, so the launch is
+// cut into pieces of < 2^31 / m^2 variants (int32 accumulators and partials) and the books carry the weight m^2.
+int int8_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64_t ld) {
   int rc = PCOA_OK;
-  // Everything the FP4 side has in flight is resolved BEFORE this chunk starts: resolving a buffer whose pre-pass met a
-  // multiplicity re-enters this function (fp4_resolve -> redo), and a redo between this chunk's pre-pass and its
-  // contraction -- the int64 fold inside the launch loop below used to trigger one -- would take the workspace this
-  // chunk is about to read.  After this point nothing is launched or flagged, so the fold below cannot re-enter.
+  // Everything the FP4 side has in flight is resolved BEFORE this chunk touches the shared int8 workspace: resolving a
+  // buffer whose pre-pass met a multiplicity re-enters this function (fp4_resolve -> redo), and a redo between this
+  // chunk's pre-pass and its contraction -- the int64 fold inside the launch loop below used to trigger one -- would
+  // overwrite pack_buf, or reallocate it, under the contraction that is about to read it.  After this
+  // point nothing is launched or flagged, so the fold below cannot re-enter.
   if ((rc = fp4_quiesce(c)) != PCOA_OK) return rc;
-  if (!c->i8_stream) {
-    HIP_TRY(c, hipStreamCreateWithFlags(&c->i8_stream, hipStreamNonBlocking));
-    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_i8, hipEventDisableTiming));
-    for (auto& q : c->i8) {
-      HIP_TRY(c, hipEventCreateWithFlags(&q.packed, hipEventDisableTiming));
-      HIP_TRY(c, hipEventCreateWithFlags(&q.consumed, hipEventDisableTiming));
-    }
-  }
-  pcoa_ctx::I8Buf& b = c->i8[c->i8_k++ & 1];
   const int64_t need = (int64_t)gram_packed_workspace_bytes(c->n, cur);
-  if (need > b.cap) {
-    if (b.used) HIP_TRY(c, hipEventSynchronize(b.consumed));   // its last contraction may still read the old buffer
-    if (b.p) dev_free(b.p);
-    b.p = nullptr;
-    b.cap = 0;
-    HIP_TRY(c, dev_alloc((void**)&b.p, (size_t)need, c->device));
-    b.cap = need;
-  }
-  hipStream_t ps = c->i8_stream;
-  if (b.used) HIP_TRY(c, hipStreamWaitEvent(ps, b.consumed, 0));   // the contraction that read this workspace last
-  if (staged) {   // the staging tile was filled on the ctx stream (and is overwritten there next)
-    HIP_TRY(c, hipEventRecord(c->ev_i8, c->stream));
-    HIP_TRY(c, hipStreamWaitEvent(ps, c->ev_i8, 0));
-  }
-  HIP_TRY(c, hipMemsetAsync(c->err_flag + 1, 0, sizeof(int32_t), ps));
+  if ((rc = ensure(c, &c->pack_buf, &c->pack_cap, need)) != PCOA_OK) return rc;
+  HIP_TRY(c, hipMemsetAsync(c->err_flag + 1, 0, sizeof(int32_t), c->stream));
   {
-    ScopedTimer t(c, T_PACK, ps);
-    hipError_t e = is_u8 ? launch_pack_u8_i8(static_cast<const uint8_t*>(x_chunk), ld, cur, c->n, b.p, c->err_flag, ps)
-                         : launch_pack_f32_i8(static_cast<const float*>(x_chunk), ld, cur, c->n, b.p, c->err_flag, ps);
+    ScopedTimer t(c, T_PACK);
+    hipError_t e = is_u8 ? launch_pack_u8_i8(static_cast<const uint8_t*>(x_chunk), ld, cur, c->n, c->pack_buf,
+                                             c->err_flag, c->stream)
+                         : launch_pack_f32_i8(static_cast<const float*>(x_chunk), ld, cur, c->n, c->pack_buf,
+                                              c->err_flag, c->stream);
     if (e != hipSuccess) return hip_fail(c, e, "pack(i8) kernel launch");
     c->pack_launches += 1;
     c->pack_bytes += (is_u8 ? 1.0 : 4.0) * (double)cur * (double)c->n + (double)need;
   }
-  HIP_TRY(c, hipMemcpyAsync(&c->hw->mmax, c->err_flag + 1, sizeof(int32_t), hipMemcpyDeviceToHost, ps));
-  HIP_TRY(c, hipEventRecord(b.packed, ps));
-  HIP_TRY(c, hipStreamSynchronize(ps));   // (the ctx stream keeps running the contraction of the chunk before)
-  HIP_TRY(c, hipStreamWaitEvent(c->stream, b.packed, 0));
+  HIP_TRY(c, hipMemcpyAsync(&c->hw->mmax, c->err_flag + 1, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   const int32_t mmax = c->hw->mmax;
   const int64_t weight = (int64_t)std::max(1, mmax) * std::max(1, mmax);
   // (< 2^30 per launch on top of a partial that is folded before it passes 2^30: every int32 stays below 2^31)
@@ -1082,15 +1044,13 @@ int int8_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64_t
     if ((rc = fold_if_needed(c, part * weight)) != PCOA_OK) return rc;
     {
       ScopedTimer t(c, T_GRAM);
-      hipError_t e = launch_gram_packed(b.p + (v0 / KB_I8) * row_bytes, 0, part, c->n, c->s32, c->num_cu, c->stream,
+      hipError_t e = launch_gram_packed(c->pack_buf + (v0 / KB_I8) * row_bytes, 0, part, c->n, c->s32, c->num_cu, c->stream,
                                         nullptr, nullptr, strip_of(c));
       if (e != hipSuccess) return hip_fail(c, e, "packed gram kernel launch");
     }
     c->gram_kind = 2;
     account_gram(c, part, weight);
   }
-  HIP_TRY(c, hipEventRecord(b.consumed, c->stream));
-  b.used = true;
   return PCOA_OK;
 }
 
@@ -1165,7 +1125,7 @@ int packed_chunk(pcoa_ctx* c, const void* x_chunk, int is_u8, int64_t cur, int64
       return PCOA_OK;
     }
   }
-  return int8_chunk(c, x_chunk, is_u8, cur, ld, /*staged=*/!can_defer);
+  return int8_chunk(c, x_chunk, is_u8, cur, ld);
 }
 
 // uint8 tile resident on the device (always a packed-operand path)
@@ -1575,14 +1535,6 @@ void pcoa_destroy(pcoa_ctx* c) {
     if (sl.freed) (void)hipEventDestroy(sl.freed);
     if (sl.dev) dev_free(sl.dev);
   }
-  if (c->i8_stream) (void)hipStreamSynchronize(c->i8_stream);
-  for (auto& q : c->i8) {
-    if (q.packed) (void)hipEventDestroy(q.packed);
-    if (q.consumed) (void)hipEventDestroy(q.consumed);
-    if (q.p) dev_free(q.p);
-  }
-  if (c->ev_i8) (void)hipEventDestroy(c->ev_i8);
-  if (c->i8_stream) (void)hipStreamDestroy(c->i8_stream);
   if (c->csr_stream) (void)hipStreamDestroy(c->csr_stream);
   if (c->csr_flag) dev_free(c->csr_flag);
   if (c->csr_flag_host) (void)hipHostFree(c->csr_flag_host);
