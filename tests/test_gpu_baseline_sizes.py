@@ -419,19 +419,27 @@ def test_native_rccl_allreduce_int64_branch_and_rank_agreement_at_world_size_1(P
 
 
 # ------------------------------------------------------------------------------------------ the JNI shim, without a JVM
-@pytest.mark.parametrize("name,batch", [("pops40", 65536), ("tile260", 100), ("tile130", 777)])
-def test_jni_shim_replay_matches_the_reference_goldens(O, name, batch, tmp_path):
-    """jni/pcoa_jni.cpp (the shim of the Scala host, SURVEY 8f rank 4) compiled against tests/jni_stub/jni.h and driven
-    by tests/jni_replay.cpp with the call sequence of scala/.../VariantsPcaNative.scala: direct-buffer CSR batches ->
-    gramFinalize -> commInit / gramAllreduce (1 rank) -> compute.  S must equal the reference's own similarity matrix,
-    the components the oracle's within 1e-6; then the same records as queued PLINK rows through allocPinned /
-    accumulatePlinkBed / sync / freePinned: the same S."""
-    exe = str(tmp_path / "jni_replay")
+@pytest.fixture(scope="module")
+def jni_replay_exe(tmp_path_factory):
+    """jni/pcoa_jni.cpp + tests/jni_replay.cpp against the stub jni.h, built once per session (a cold g++ on a fresh box costs
+    minutes of page-in: r07x3 spent 179 s in the first of three identical builds)."""
+    exe = str(tmp_path_factory.mktemp("jni") / "jni_replay")
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "tests", "jni_stub"), "-I",
                            os.path.join(ROOT, "include"), os.path.join(ROOT, "jni", "pcoa_jni.cpp"),
                            os.path.join(ROOT, "tests", "jni_replay.cpp"), "-L", os.path.join(ROOT, "spark-examples_amd"),
                            "-lpcoa_hip", "-Wl,-rpath," + os.path.join(ROOT, "spark-examples_amd"), "-Wl,-rpath,/opt/rocm/lib",
                            "-o", exe])
+    return exe
+
+
+@pytest.mark.parametrize("name,batch", [("pops40", 65536), ("tile260", 100), ("tile130", 777)])
+def test_jni_shim_replay_matches_the_reference_goldens(O, name, batch, tmp_path, jni_replay_exe):
+    """jni/pcoa_jni.cpp (the shim of the Scala host, SURVEY 8f rank 4) compiled against tests/jni_stub/jni.h and driven
+    by tests/jni_replay.cpp with the call sequence of scala/.../VariantsPcaNative.scala: direct-buffer CSR batches ->
+    gramFinalize -> commInit / gramAllreduce (1 rank) -> compute.  S must equal the reference's own similarity matrix,
+    the components the oracle's within 1e-6; then the same records as queued PLINK rows through allocPinned /
+    accumulatePlinkBed / sync / freePinned: the same S."""
+    exe = jni_replay_exe
     g = load_golden(name)
     n = int(g["n_samples"])
     prefix = str(tmp_path / "case")
