@@ -1281,7 +1281,7 @@ def test_caller_supplied_operator_with_a_degenerate_leading_pair(P):
         assert abs(comps[:, 0] @ comps[:, 1]) < 1e-9
 
 
-@pytest.mark.parametrize("n,n_pops,calls", [(37, 1, (1, 127, 300)), (1001, 7, (130, 5, 4000, 129)), (2504, 5, (100000, 77)),
+@pytest.mark.parametrize("n,n_pops,calls", [(37, 1, (1, 127, 300)), (1001, 7, (130, 5, 4000, 129)), (2504, 5, (30000, 77)),
                                             (4100, 64, (3000, 1029))])
 def test_synthetic_model_written_straight_into_the_operand_equals_its_host_twin(P, O, n, n_pops, calls):
     """pcoa_accumulate_synthetic on the k-bits operand (r06: synth_kbits_kernel, no fp32 tile, no pre-pass): S equals the oracle's
