@@ -1323,3 +1323,27 @@ with P.PcoaEngine(n) as eng:
             out = os.path.join(td, "tile.npy")
             subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, PCOA_SYNTH_TILE="1"))
             assert np.array_equal(np.load(out), want)
+
+
+def test_xcd_k_segment_launch_form_of_the_contraction_stays_exact(tmp_path):
+    """PCOA_KBITS_MODE=5 (r06, measured and not the default: profiles/r07f): every XCD takes one eighth of the k-range for all
+    tiles.  The launch form stays in the kernel behind the knob, so it stays bit-exact: S against the oracle on a cohort long
+    enough for the segments to exist (>= 512 stages of 128 variants), with a ragged tail."""
+    code = r"""
+import sys, numpy as np, importlib
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from conftest import load_oracle, int_gram
+P = importlib.import_module("spark-examples_amd"); ingest = importlib.import_module("spark-examples_amd.ingest")
+rng = np.random.default_rng(6)
+n, v = 1300, 70003
+x = (rng.random((v, n)) < 0.12).astype(np.uint8)
+with P.PcoaEngine(n) as eng:
+    eng.accumulate_bits(ingest.pack_bits(x))
+    got = eng.gram()
+    t = eng.timings()
+np.savez(sys.argv[1], same=np.array_equal(got, int_gram(x)), even=t["evensplit_launches"])
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    out = str(tmp_path / "m5.npz")
+    subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, PCOA_KBITS_MODE="5"))
+    r = np.load(out)
+    assert bool(r["same"]) and int(r["even"]) >= 1
