@@ -64,6 +64,9 @@ def test_every_boundary_agrees_with_integer_matmul(P, seed):
         eng.accumulate_bits(torch.from_numpy(bits.view(np.int32)).cuda())
         eng.accumulate_callsets([list(np.nonzero(r)[0]) for r in x])
         assert np.array_equal(eng.gram(), 2 * want), ("bits + csr", n, v, kernel)
+        # the same bitsets from HOST memory (r06: through two device slots on the copy stream), padded stride included
+        eng.accumulate_bits(bits)
+        assert np.array_equal(eng.gram(), 3 * want), ("host bits", n, v, kernel)
         if kernel != "i8":
             assert eng.timings()["operand_bits"] == (4 if operand == "fp4" else 1)
 
