@@ -733,7 +733,10 @@ def main():
             x1 = None   # (a view of the resident batches)
             del x, x_store
             torch.cuda.empty_cache()
-            out["config3_one_gpu"] = config3_one_gpu(P, synth, torch, dev, local_rank, args.config3_samples, args.config3_variants)
+            try:
+                out["config3_one_gpu"] = config3_one_gpu(P, synth, torch, dev, local_rank, args.config3_samples, args.config3_variants)
+            except Exception as exc:  # noqa: BLE001 -- an extra must never take the headline line with it (e.g. HBM held by another process)
+                out["config3_one_gpu"] = {"skipped": "failed: %s: %s" % (type(exc).__name__, exc)}
         print(json.dumps(out), flush=True)
     if native is not None:
         native.close()
