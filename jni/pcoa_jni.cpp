@@ -138,6 +138,14 @@ JNIEXPORT jint JNICALL FN(commDestroy)(JNIEnv*, jobject, jlong comm) {
   return pcoa_comm_destroy(reinterpret_cast<void*>(static_cast<intptr_t>(comm)));
 }
 
+// pcoa_comm_count: ncclCommCount of the communicator, or a negative pcoa_status (what the host logs to show the collective
+// spans the GPUs it was started on)
+JNIEXPORT jint JNICALL FN(commCount)(JNIEnv*, jobject, jlong comm) {
+  int32_t n = 0;
+  const int rc = pcoa_comm_count(reinterpret_cast<void*>(static_cast<intptr_t>(comm)), &n);
+  return rc == PCOA_OK ? static_cast<jint>(n) : static_cast<jint>(rc);
+}
+
 // pcoa_gram_allreduce_rccl: reduceByKey(_ + _) over the GPUs (VariantsPca.scala:190)
 JNIEXPORT jint JNICALL FN(gramAllreduce)(JNIEnv*, jobject, jlong ctx, jlong comm) {
   return pcoa_gram_allreduce_rccl(ctx_of(ctx), reinterpret_cast<void*>(static_cast<intptr_t>(comm)));

@@ -49,6 +49,7 @@ object NativePcoa {
   @native def commUniqueId(): Array[Byte] // pcoa_comm_unique_id (128 bytes; null on failure)
   @native def commInit(ctx: Long, id: Array[Byte], rank: Int, nRanks: Int): Long // pcoa_comm_init (0 on failure)
   @native def commDestroy(comm: Long): Int // pcoa_comm_destroy
+  @native def commCount(comm: Long): Int // pcoa_comm_count: ranks of the communicator (negative: a pcoa_status)
   @native def gramAllreduce(ctx: Long, comm: Long): Int // pcoa_gram_allreduce_rccl
   @native def gramRead(ctx: Long, outNxN: ByteBuffer): Int // pcoa_gram_read_i64
   @native def gramLoad(ctx: Long, inNxN: ByteBuffer): Int // pcoa_gram_load_i64

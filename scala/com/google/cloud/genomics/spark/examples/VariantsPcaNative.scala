@@ -138,6 +138,7 @@ object VariantsPcaNative {
       if (nGpus > 1) {
         val comm = NativePcoa.commInit(ctx, uid.value, rank, nGpus)
         if (comm == 0L) throw new IllegalStateException(NativePcoa.lastError(ctx))
+        if (rank == 0) println(s"RCCL communicator over ${NativePcoa.commCount(comm)} of $nGpus ranks.")
         try NativePcoa.check(ctx, NativePcoa.gramAllreduce(ctx, comm))
         finally NativePcoa.commDestroy(comm)
       }

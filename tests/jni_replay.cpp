@@ -40,6 +40,7 @@ jint FN(accumulatePlinkBed)(JNIEnv*, jobject, jlong, jobject, jlong, jlong, jint
 jbyteArray FN(commUniqueId)(JNIEnv*, jobject);
 jlong FN(commInit)(JNIEnv*, jobject, jlong, jbyteArray, jint, jint);
 jint FN(commDestroy)(JNIEnv*, jobject, jlong);
+jint FN(commCount)(JNIEnv*, jobject, jlong);
 jint FN(gramAllreduce)(JNIEnv*, jobject, jlong, jlong);
 jint FN(gramRead)(JNIEnv*, jobject, jlong, jobject);
 jint FN(compute)(JNIEnv*, jobject, jlong, jint, jobject, jobject, jintArray);
@@ -158,6 +159,7 @@ int main(int argc, char** argv) {
   EXPECT(uid != nullptr && env.GetArrayLength(uid) == 128);
   const jlong comm = FN(commInit)(&env, self, ctx, uid, 0, 1);
   EXPECT(comm != 0);
+  EXPECT(FN(commCount)(&env, self, comm) == 1);
   EXPECT(FN(gramAllreduce)(&env, self, ctx, comm) == PCOA_OK);
   EXPECT(FN(commDestroy)(&env, self, comm) == PCOA_OK);
   std::vector<int64_t> s((size_t)n * (size_t)n);
