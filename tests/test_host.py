@@ -660,7 +660,7 @@ def _sanitizer_exe():
     return exe
 
 
-@pytest.mark.parametrize("which", ["ingest", "goldens_vcf", "goldens_plink", "plink_refusals", "same_stem", "gzip_path"])
+@pytest.mark.parametrize("which", ["ingest", "goldens_vcf", "goldens_plink", "plink_refusals", "same_stem", "gzip_path", "streamed_join"])
 def test_compiled_host_again_under_asan_and_ubsan(which, tmp_path, monkeypatch):
     """Every --parse-only test of this file once more with the sanitizer build in place of the release binary: a heap
     overrun, use-after-free, leak or undefined operation in the VCF / PLINK readers, the joins or the option parsing makes
@@ -694,6 +694,11 @@ def test_compiled_host_again_under_asan_and_ubsan(which, tmp_path, monkeypatch):
         test_plink_sex_and_mitochondrial_chromosome_codes_are_dropped_like_x_y_mt_in_a_vcf(d)
     elif which == "same_stem":
         test_variant_sets_with_the_same_file_stem_keep_distinct_callsets(tmp_path)
+    elif which == "streamed_join":   # r06: spill files, partition-wise join / merge
+        for i, (nsets, extra) in enumerate([(2, ["--min-allele-frequency", "0.1"]), (3, ["--join-partitions", "7"])]):
+            d = tmp_path / ("j%d" % i)
+            d.mkdir()
+            test_streamed_join_and_merge_equal_the_in_memory_path(d, nsets, extra)
     else:
         test_gzip_path_with_shell_metacharacters_is_just_a_path(tmp_path)
 
