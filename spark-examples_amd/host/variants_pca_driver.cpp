@@ -78,6 +78,8 @@ struct Conf {  // PcaConf / GenomicsConf (GenomicsConf.scala:31-101), same flag 
   int join_partitions = 64;             // --join-partitions P (r06): joins / merges of several VCFs are hash-partitioned on getVariantKey into P spill
                                         // files per variant set; one partition (1 / P of every set) is in memory at a time
   std::string spill_dir;                // --spill-dir: where those files go (default $TMPDIR, else /tmp)
+  bool spark_output = false;            // --spark-output-layout (r06): <output-path>-pca.tsv as the DIRECTORY saveAsTextFile leaves (part-00000 + _SUCCESS,
+                                        // VariantsPca.scala:241-245) instead of one file of that name
   std::string carrier_format = "auto";  // --carrier-format auto|lists|bits (r06): how RDD[Seq[Int]] rows cross to the engine -- auto: a block
                                         // whose mean list is longer than N / 32 entries goes over as carrier bitsets (fewer bytes), else as lists
 };
@@ -123,6 +125,7 @@ Conf parse(int argc, char** argv) {
     else if (a == "--plink-decode") c.plink_decode = one(i);
     else if (a == "--stream-rows") c.stream_rows = std::atol(one(i).c_str());
     else if (a == "--no-stream") c.no_stream = true;
+    else if (a == "--spark-output-layout") c.spark_output = true;
     else if (a == "--join-partitions") { c.join_partitions = std::atoi(one(i).c_str()); if (c.join_partitions < 1) die("--join-partitions must be >= 1"); }
     else if (a == "--spill-dir") c.spill_dir = one(i);
     else if (a == "--carrier-format") {
@@ -1397,7 +1400,13 @@ int main(int argc, char** argv) {
   for (const auto& r : rows)
     std::printf("%s\t%s\t%s\t%s\n", r.name.c_str(), r.dataset.c_str(), java_double(r.pc1).c_str(), java_double(r.pc2).c_str());
   if (!conf.output_path.empty()) {
-    std::ofstream out(conf.output_path + "-pca.tsv");
+    std::string target = conf.output_path + "-pca.tsv";
+    if (conf.spark_output) {   // what resultRDD.saveAsTextFile(outputPath) leaves (:241-245): a directory; like Spark, an existing one is an error
+      if (::mkdir(target.c_str(), 0777) != 0) die("output directory " + target + " already exists (or cannot be created)");
+      std::ofstream(target + "/_SUCCESS");
+      target += "/part-00000";
+    }
+    std::ofstream out(target);
     for (const auto& r : rows)
       out << r.name << "\t" << java_double(r.pc1) << "\t" << java_double(r.pc2) << "\t" << r.dataset << "\n";
   }

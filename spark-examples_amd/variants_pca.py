@@ -282,6 +282,9 @@ class PcaConf(object):
         p.add_argument("--plink-ref-allele", choices=["a1", "a2"], default="a2",
                        help="PLINK filesets: which .bim allele column is the reference allele (a2: written with "
                             "--keep-allele-order / plink2 --make-bed; a1: the other way round)")
+        p.add_argument("--spark-output-layout", action="store_true",
+                       help="write <output-path>-pca.tsv as the DIRECTORY Spark's saveAsTextFile leaves (part-00000 + _SUCCESS, "
+                            "VariantsPca.scala:241-245) instead of one file of that name")
         p.add_argument("--dump-similarity", type=str, default=None,
                        help="write S (N x N int64, little-endian, row-major) to this file (parity tests)")
         a = p.parse_args(list(arguments))
@@ -457,7 +460,12 @@ class VariantsPcaDriver(object):
         for (name, pc1, pc2, dataset) in rows:
             out.write("%s\t%s\t%s\t%s\n" % (name, dataset, java_double_to_string(pc1), java_double_to_string(pc2)))
         if self.conf.outputPath:
-            with open(self.conf.outputPath + "-pca.tsv", "w") as f:
+            target = self.conf.outputPath + "-pca.tsv"
+            if getattr(self.conf, "spark_output_layout", False):   # saveAsTextFile (:241-245): a directory; an existing one is an error
+                os.mkdir(target)
+                open(os.path.join(target, "_SUCCESS"), "w").close()
+                target = os.path.join(target, "part-00000")
+            with open(target, "w") as f:
                 for (name, pc1, pc2, dataset) in rows:
                     f.write("%s\t%s\t%s\t%s\n" % (name, java_double_to_string(pc1), java_double_to_string(pc2), dataset))
 

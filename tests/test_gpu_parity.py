@@ -1053,6 +1053,21 @@ def test_cpp_driver_matches_python_driver(P, tmp_path, capsys, nsets, extra):
     for r in rows_cpp:
         assert fmt(float(r[2])) == r[2] and fmt(float(r[3])) == r[3]
     assert open(str(tmp_path / "cpp") + "-pca.tsv").read().count("\n") == len(rows_cpp)
+    if nsets == 1:
+        # --spark-output-layout (r06): <output-path>-pca.tsv as the directory saveAsTextFile leaves (VariantsPca.scala:241-245)
+        flat = open(str(tmp_path / "cpp") + "-pca.tsv").read()
+        sp_args = [a if a != str(tmp_path / "py") else str(tmp_path / "spark_cpp") for a in args] + ["--spark-output-layout"]
+        r3 = subprocess.run([exe] + sp_args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+        assert r3.returncode == 0, r3.stderr
+        d = str(tmp_path / "spark_cpp") + "-pca.tsv"
+        assert sorted(os.listdir(d)) == ["_SUCCESS", "part-00000"] and open(os.path.join(d, "part-00000")).read() == flat
+        assert subprocess.run([exe] + sp_args, stdout=subprocess.PIPE, stderr=subprocess.PIPE).returncode != 0   # exists: error, as Spark
+        py_args = [a if a != str(tmp_path / "py") else str(tmp_path / "spark_py") for a in args] + ["--spark-output-layout"]
+        assert vp.main(py_args) == 0
+        capsys.readouterr()
+        dpy = str(tmp_path / "spark_py") + "-pca.tsv"
+        assert sorted(os.listdir(dpy)) == ["_SUCCESS", "part-00000"]
+        assert open(os.path.join(dpy, "part-00000")).read().count("\n") == len(rows_cpp)
     # r06: joins / merges are streamed -- every set once into hash-partitioned spill files, one key partition in memory at a
     # time (VariantsPca.scala:115-148 is a shuffle) -- and so is a single VCF for several engines; all must give the S of the
     # in-memory path, whatever the partition count
