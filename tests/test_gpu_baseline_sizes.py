@@ -413,8 +413,11 @@ def test_native_rccl_allreduce_int64_branch_and_rank_agreement_at_world_size_1(P
     with P.PcoaEngine(70) as eng:                               # control: the in-place int32 fast path
         eng.accumulate_dense(x)
         comm = eng.comm_init(eng.comm_unique_id(), 0, 1)
+        assert eng.comm_count(comm) == 1                        # r06: ncclCommCount, what a multi-rank record prints as rccl_ranks
         eng.allreduce_rccl(comm)
         assert np.array_equal(eng.gram(), want)
+        t = eng.timings()                                       # r06: the collective's own telemetry
+        assert t["allreduce_calls"] == 1 and t["comm_ranks"] == 1 and t["allreduce_int32"] == 1 and t["allreduce_seconds"] > 0
         eng.comm_destroy(comm)
 
 
