@@ -121,6 +121,11 @@ def main():
     ap.add_argument("--allreduce", choices=["native", "torch"], default="native",
                     help="N>1: native = RCCL communicator inside libpcoa_hip (in-place int32), torch = "
                          "export -> torch.distributed.all_reduce -> import")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="N>1: torch.distributed backend (nccl = RCCL; gloo = CPU wire for a box where several ranks have to share "
+                         "one GPU: it implies --allreduce torch -- the self-test of the multi-rank code path, not a measurement)")
+    ap.add_argument("--rank-devices", type=str, default=None,
+                    help="N>1: device ordinal of each rank, comma-separated (default: LOCAL_RANK); ordinals may repeat with --dist-backend gloo")
     ap.add_argument("--gram-kernel", choices=["auto", "fp4", "i8", "f32"], default="auto",
                     help="auto (default): binary tiles -> pack to MX-FP4 + v_mfma_f32_32x32x64_f8f6f4, tiles with "
                          "multiplicities -> int8; fp4 / i8: force one; f32: v_mfma_f32_32x32x2_f32")
@@ -141,7 +146,15 @@ def main():
 
     # --gpus N without a rendezvous in the environment: become the launcher of N ranks (or fail loudly) instead of
     # running one rank and reporting n_gpus = 1
-    what, detail = pkg("dist").launch_plan(args.gpus, os.environ, torch.cuda.device_count(), [os.path.abspath(__file__)] + sys.argv[1:],
+    visible = torch.cuda.device_count()
+    rank_devices = [int(t) for t in args.rank_devices.split(",")] if args.rank_devices else None
+    if rank_devices is not None:
+        if len(rank_devices) != args.gpus or min(rank_devices) < 0 or max(rank_devices) >= max(visible, 1):
+            sys.exit("bench.py: --rank-devices must name --gpus visible devices")
+        if len(set(rank_devices)) < len(rank_devices) and args.dist_backend != "gloo":
+            sys.exit("bench.py: --rank-devices repeats a device: RCCL needs one GPU per rank (use --dist-backend gloo for the self-test)")
+        visible = max(visible, args.gpus)   # the map names what exists; the rank count is what the plan checks
+    what, detail = pkg("dist").launch_plan(args.gpus, os.environ, visible, [os.path.abspath(__file__)] + sys.argv[1:],
                                            python=sys.executable)
     if what == "error":
         sys.exit("bench.py: " + detail)
@@ -153,14 +166,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if rank_devices is not None and world > 1:
+        local_rank = rank_devices[rank]
+    gloo = world > 1 and args.dist_backend == "gloo"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if gloo:
+            td.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if gloo else dev   # where the small collectives' tensors live
 
     P = pkg()
     dist = pkg("dist")
@@ -199,7 +219,7 @@ def main():
     native = None
     allreduce_mode = "none"
     if world > 1:
-        allreduce_mode = args.allreduce
+        allreduce_mode = "torch" if gloo else args.allreduce   # (the library's communicator is RCCL)
         if allreduce_mode == "native":
             # every rank must end up on the same path: agree on success before using it
             ok = 1
@@ -208,7 +228,7 @@ def main():
             except Exception as exc:  # noqa: BLE001
                 sys.stderr.write("rank %d: native RCCL communicator failed (%s); using torch.distributed\n" % (rank, exc))
                 ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            flag = torch.tensor([ok], dtype=torch.int32, device=cdev)
             td.all_reduce(flag, op=td.ReduceOp.MIN)
             if int(flag.item()) == 0:
                 if native is not None:
@@ -248,7 +268,7 @@ def main():
         except Exception as exc:  # noqa: BLE001
             sys.stderr.write("rank %d: native RCCL all-reduce failed (%s); using torch.distributed\n" % (rank, exc))
             ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        flag = torch.tensor([ok], dtype=torch.int32, device=cdev)
         td.all_reduce(flag, op=td.ReduceOp.MIN)
         if int(flag.item()) == 0:
             try:
@@ -282,13 +302,13 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed_rank = elapsed
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         elapsed = float(tt.item())
     tim = eng.timings()
     # what a multi-rank record needs to explain itself: per-rank elapsed, the reduction step, the communicator's own rank count
     tele = dist.collective_telemetry(t_local if t_local is not None else elapsed_rank, t_red if t_red is not None else 0.0, tim,
-                                     native.count() if native is not None else None, device=dev if world > 1 else None)
+                                     native.count() if native is not None else None, device=cdev if world > 1 else None)
 
     out = None
     if rank == 0:
@@ -448,7 +468,7 @@ def main():
                        "n_samples": n, "row_pitch_floats": ld, "variants_per_step_per_gpu": v if args.scaling == "weak" else resident // steps,
                        "resident_variants_per_gpu": resident, "seed": SEED,
                        "parallelism": "variant-sharded x%d" % world,
-                       "allreduce": allreduce_mode,
+                       "allreduce": allreduce_mode, "dist_backend": args.dist_backend if world > 1 else None,
                        "gram_kernel": kdesc, "gram_kernel_mode": args.gram_kernel, "operand": args.operand,
                        "fp4_fallback_chunks": int(tim["fp4_fallbacks"])},
             "roofline": roofline, "roofline_other": roofline_other,

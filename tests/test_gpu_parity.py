@@ -1362,3 +1362,29 @@ np.savez(sys.argv[1], same=np.array_equal(got, int_gram(x)), even=t["evensplit_l
     subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, PCOA_KBITS_MODE="5"))
     r = np.load(out)
     assert bool(r["same"]) and int(r["even"]) >= 1
+
+
+def test_bench_with_two_ranks_runs_its_multi_rank_path_end_to_end(tmp_path):
+    """bench.py --gpus 2 has never met a node: its multi-rank branch -- the self-spawn under torch.distributed.run, the sharded
+    cohort, finalize -> reduction -> max-over-ranks timing, the telemetry the line must carry (VERDICT r05 Next 5) -- is run here
+    with two REAL ranks on the one GPU of the box over a gloo wire (--rank-devices 0,0 --dist-backend gloo; RCCL refuses two ranks
+    on one device).  A plumbing test, not a measurement: one JSON line, n_gpus = 2, both ranks' elapsed times, the reduction
+    step's wall, value = the variants of BOTH ranks over the max-over-ranks time."""
+    import json
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_PORT=str(port))
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rank-devices", "0,0", "--dist-backend", "gloo",
+                          "--steps", "3", "--warmup", "1", "--variants", "60000", "--no-extras", "--no-cpu-baseline", "--pcoa-reps", "1"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=env, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert d["config"]["allreduce"] == "torch" and d["config"]["dist_backend"] == "gloo" and d["rccl_ranks"] is None
+    assert len(d["rank_elapsed_s"]) == 2 and 0 < d["rank_elapsed_min_s"] <= d["rank_elapsed_max_s"]
+    assert d["allreduce_ms"] > 0 and d["allreduce_event_ms"] is None
+    assert abs(d["value"] - 2 * 60000 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
+    assert abs(d["n1_equivalent_value"] - d["value"] / 2) < 1e-6 * d["value"]
+    assert d["nonzero_rows"] == 2504 and d["eigenvalues"][0] > d["eigenvalues"][1] > 0 and d["pcoa_wall_ms"] > 0
